@@ -1,0 +1,371 @@
+/*
+ * teal_oracle.c — CPU restatement of TEAL's activation-sparsity decode hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (teal_amd/) may link,
+ * import or call this file.  It is used by tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg, as the checker / the timed CPU baseline.
+ *
+ * What it restates (all citations are into /root/reference):
+ *   - the keep rule               kernels/sparse_gemv.py:75   idx = tl.abs(x0) > threshold
+ *   - the split-K sparse GEMV     kernels/sparse_gemv.py:50-83 (splitk_sparse_gemv_kernel)
+ *   - the 3-threshold QKV GEMV    kernels/sparse_gemv.py:152-194 (qkv_kernel)
+ *   - the dense prefill fallback  kernels/sparse_gemv.py:271,298 (torch.matmul(x, W.T))
+ *   - SparsifyFn.apply            utils/utils.py:51-52   x.abs().gt(thr) * x   (fp16 compare rule)
+ *
+ * Parity pinning: tests/test_oracle_golden.py checks the "ref" functions below
+ * bit-for-bit against outputs of the reference's own Triton kernels executed in
+ * this container under TRITON_INTERPRET=1 (tests/golden/, generator
+ * oracle/gen_golden.py).
+ *
+ * Layout contract (reference "column major" weight, kernels/sparse_gemv.py:68,106):
+ *   wT is the memory image of weight[N, Z] with strides (1, N), i.e. a row-major
+ *   [Z][N] array: element (m, n) lives at wT[m * N + n].
+ *
+ * dtype: 0 = IEEE fp16, 1 = bfloat16 (raw 16-bit patterns in uint16_t).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define TEAL_F16 0
+#define TEAL_BF16 1
+
+/* ------------------------------------------------------------------ */
+/* 16-bit float helpers (bit-exact, no compiler fp16 support needed)   */
+/* ------------------------------------------------------------------ */
+static inline float u32_as_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t f32_as_u32(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+static inline float half_to_float(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1Fu;
+    uint32_t man = h & 0x3FFu;
+    if (exp == 0) {
+        if (man == 0) return u32_as_f32(sign);
+        /* subnormal: value = man * 2^-24 */
+        float v = (float)man * (1.0f / 16777216.0f);
+        return sign ? -v : v;
+    }
+    if (exp == 31) return u32_as_f32(sign | 0x7F800000u | (man << 13));
+    return u32_as_f32(sign | ((exp + 112u) << 23) | (man << 13));
+}
+
+/* float -> fp16, round to nearest even (matches numpy / torch / v_cvt_f16_f32) */
+static inline uint16_t float_to_half(float f) {
+    uint32_t x = f32_as_u32(f);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t ax = x & 0x7FFFFFFFu;
+    if (ax >= 0x7F800000u) { /* inf / nan */
+        if (ax > 0x7F800000u) return (uint16_t)(sign | 0x7E00u | ((ax >> 13) & 0x3FFu));
+        return (uint16_t)(sign | 0x7C00u);
+    }
+    if (ax >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u); /* >= 65520 -> inf */
+    if (ax < 0x33000001u) return (uint16_t)sign;              /* <= 2^-25 -> 0 (tie to even) */
+    int e = (int)(ax >> 23) - 127;
+    uint32_t m = (ax & 0x7FFFFFu) | 0x800000u;
+    int shift;
+    uint32_t base;
+    if (e < -14) { shift = 13 + (-14 - e); base = 0; }           /* subnormal result */
+    else { shift = 13; base = (uint32_t)(e + 15) << 10; m &= 0x7FFFFFu; }
+    uint32_t q = m >> shift;
+    uint32_t rem = m & ((1u << shift) - 1u);
+    uint32_t half = 1u << (shift - 1);
+    uint32_t r = base + q;
+    if (rem > half || (rem == half && (r & 1u))) r += 1;
+    return (uint16_t)(sign | r);
+}
+
+static inline float bf16_to_float(uint16_t b) { return u32_as_f32((uint32_t)b << 16); }
+
+static inline uint16_t float_to_bf16(float f) {
+    uint32_t x = f32_as_u32(f);
+    if ((x & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((x >> 16) | 0x40u);
+    uint32_t lsb = (x >> 16) & 1u;
+    x += 0x7FFFu + lsb;
+    return (uint16_t)(x >> 16);
+}
+
+static inline float load16(uint16_t v, int dtype) {
+    return dtype == TEAL_BF16 ? bf16_to_float(v) : half_to_float(v);
+}
+static inline uint16_t store16(float f, int dtype) {
+    return dtype == TEAL_BF16 ? float_to_bf16(f) : float_to_half(f);
+}
+
+/* exported for tests of the helpers themselves */
+float teal_oracle_half_to_float(uint16_t h) { return half_to_float(h); }
+uint16_t teal_oracle_float_to_half(float f) { return float_to_half(f); }
+float teal_oracle_bf16_to_float(uint16_t h) { return bf16_to_float(h); }
+uint16_t teal_oracle_float_to_bf16(float f) { return float_to_bf16(f); }
+
+/* ------------------------------------------------------------------ */
+/* keep rule — kernels/sparse_gemv.py:75  `idx = tl.abs(x0) > threshold` */
+/* Triton promotes the 16-bit |x| to fp32 and compares with the fp32     */
+/* scalar kernel argument; strict '>'; NaN compares false.               */
+/* ------------------------------------------------------------------ */
+static inline int keep(uint16_t xv, int dtype, float tau) {
+    return fabsf(load16(xv, dtype)) > tau;
+}
+
+/* ascending kept-index list + count */
+int teal_oracle_compact(const uint16_t* x, int dtype, int Z, float tau,
+                        int32_t* idx_out, int32_t* count_out) {
+    if (!x || !count_out || Z < 0 || (dtype != 0 && dtype != 1)) return -1;
+    int c = 0;
+    for (int m = 0; m < Z; ++m)
+        if (keep(x[m], dtype, tau)) { if (idx_out) idx_out[c] = m; ++c; }
+    *count_out = c;
+    return 0;
+}
+
+/* SparsifyFn.apply — utils/utils.py:51-52: x.abs().gt(threshold) * x, where the
+ * python-float threshold is first rounded to x's dtype by torch's scalar compare
+ * (the survey's probe: this differs from the Triton rule on boundary values).
+ * tau_rounded is the threshold already rounded to `dtype`, as raw bits. */
+int teal_oracle_sparsify_fn_apply(const uint16_t* x, int dtype, int Z, uint16_t tau_rounded,
+                                  uint16_t* out) {
+    if (!x || !out) return -1;
+    float t = load16(tau_rounded, dtype);
+    for (int m = 0; m < Z; ++m) {
+        float v = load16(x[m], dtype);
+        /* mask(bool) * x : 0 * x keeps the sign of zero / NaN semantics of torch */
+        out[m] = (fabsf(v) > t) ? x[m] : store16(0.0f * v, dtype);
+    }
+    return 0;
+}
+
+/* threshold selection of qkv_kernel — kernels/sparse_gemv.py:167-168,181.
+ * Decided per output block from the block's first column. */
+static inline float qkv_tau(int col0, int N_q, int N_kv, float tq, float tk, float tv) {
+    int is_q = col0 < N_q;
+    int is_v = (N_q + N_kv) <= col0;
+    return is_q ? tq : (is_v ? tv : tk);
+}
+
+/* ------------------------------------------------------------------ */
+/* Bit-level restatement of the reference kernels as the Triton         */
+/* interpreter executes them: programs in (start_n outer, start_m inner) */
+/* order; inside a program an fp32 product tile summed over BLOCK_M rows */
+/* in ascending row order (kernels/sparse_gemv.py:78); the fp32 partial  */
+/* is cast to fp16 and added to Y in fp16 arithmetic (:83; Y is always   */
+/* fp16, :114-120).  Y is zeroed first (pre_hook init_to_zero, :8-12).   */
+/* Requires N % block_n == 0 like the reference (no N mask on the load). */
+/* ------------------------------------------------------------------ */
+int teal_oracle_ref_qkv_gemv(const uint16_t* x, const uint16_t* wT, uint16_t* y_f16,
+                             float tq, float tk, float tv, int Z, int N, int N_q, int N_kv,
+                             int dtype, int block_m, int block_n) {
+    if (!x || !wT || !y_f16 || Z <= 0 || N <= 0 || block_m <= 0 || block_n <= 0) return -1;
+    if (N % block_n != 0) return -2;
+    float* acc = (float*)malloc(sizeof(float) * (size_t)block_n);
+    if (!acc) return -3;
+    for (int n = 0; n < N; ++n) y_f16[n] = 0;
+    for (int n0 = 0; n0 < N; n0 += block_n) {
+        float tau = qkv_tau(n0, N_q, N_kv, tq, tk, tv);
+        for (int m0 = 0; m0 < Z; m0 += block_m) {
+            for (int j = 0; j < block_n; ++j) acc[j] = 0.0f;
+            for (int i = 0; i < block_m; ++i) {
+                int m = m0 + i;
+                float xv = 0.0f; /* tl.load(..., mask=rm < M, other=0.0) */
+                int kept = 0;
+                if (m < Z) { xv = load16(x[m], dtype); kept = fabsf(xv) > tau; }
+                const uint16_t* row = wT + (size_t)(m < Z ? m : 0) * N + n0;
+                for (int j = 0; j < block_n; ++j) {
+                    float a = kept ? load16(row[j], dtype) : 0.0f; /* masked load, other=0.0 */
+                    acc[j] = acc[j] + a * xv;                      /* fp32 mul, fp32 add      */
+                }
+            }
+            for (int j = 0; j < block_n; ++j) {
+                /* tl.atomic_add(fp16*, fp32): value cast to fp16, fp16 add */
+                float v = half_to_float(float_to_half(acc[j]));
+                y_f16[n0 + j] = float_to_half(half_to_float(y_f16[n0 + j]) + v);
+            }
+        }
+    }
+    free(acc);
+    return 0;
+}
+
+int teal_oracle_ref_sparse_gemv(const uint16_t* x, const uint16_t* wT, uint16_t* y_f16,
+                                float tau, int Z, int N, int dtype, int block_m, int block_n) {
+    return teal_oracle_ref_qkv_gemv(x, wT, y_f16, tau, tau, tau, Z, N, N, 0, dtype, block_m,
+                                    block_n);
+}
+
+/* ------------------------------------------------------------------ */
+/* Ground truth in double precision.  Thresholds are per column range    */
+/* [0,N_q) tq, [N_q,N_q+N_kv) tk, rest tv (granularity: exact columns —  */
+/* identical to the reference whenever BLOCK_N divides N_q and N_kv,     */
+/* which holds for every model shape).                  */
+/* ------------------------------------------------------------------ */
+int teal_oracle_truth64(const uint16_t* x, const uint16_t* wT, double* y, float tq, float tk,
+                        float tv, int Z, int N, int N_q, int N_kv, int dtype) {
+    if (!x || !wT || !y || Z <= 0 || N <= 0) return -1;
+    for (int n = 0; n < N; ++n) y[n] = 0.0;
+    for (int m = 0; m < Z; ++m) {
+        float xv = load16(x[m], dtype);
+        float ax = fabsf(xv);
+        int kq = ax > tq, kk = ax > tk, kv = ax > tv;
+        if (!(kq | kk | kv)) continue;
+        const uint16_t* row = wT + (size_t)m * N;
+        double xd = (double)xv;
+        int a = N_q, b = N_q + N_kv;
+        if (a > N) a = N;
+        if (b > N) b = N;
+        if (kq) for (int n = 0; n < a; ++n) y[n] += (double)load16(row[n], dtype) * xd;
+        if (kk) for (int n = a; n < b; ++n) y[n] += (double)load16(row[n], dtype) * xd;
+        if (kv) for (int n = b; n < N; ++n) y[n] += (double)load16(row[n], dtype) * xd;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Timed CPU baseline ("port"): fp32 accumulate over kept rows, one      */
+/* final rounding to the input dtype.  OpenMP over column tiles.         */
+/* ------------------------------------------------------------------ */
+static float g_h2f[65536];
+static int g_h2f_ready[2] = {0, 0};
+static float g_b2f_dummy;
+
+static void build_table(void) {
+    if (g_h2f_ready[0]) return;
+    for (uint32_t i = 0; i < 65536; ++i) g_h2f[i] = half_to_float((uint16_t)i);
+    g_h2f_ready[0] = 1;
+    (void)g_b2f_dummy;
+}
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2,f16c,fma")))
+static void axpy_f16_avx2(float* a, const uint16_t* row, float xm, int w) {
+    int j = 0;
+    __m256 xs = _mm256_set1_ps(xm);
+    for (; j + 8 <= w; j += 8) {
+        __m256 f = _mm256_cvtph_ps(_mm_loadu_si128((const __m128i*)(row + j)));
+        _mm256_storeu_ps(a + j, _mm256_fmadd_ps(f, xs, _mm256_loadu_ps(a + j)));
+    }
+    for (; j < w; ++j) a[j] += g_h2f[row[j]] * xm;
+}
+__attribute__((target("avx2,f16c,fma")))
+static void axpy_bf16_avx2(float* a, const uint16_t* row, float xm, int w) {
+    int j = 0;
+    __m256 xs = _mm256_set1_ps(xm);
+    for (; j + 8 <= w; j += 8) {
+        __m256i u = _mm256_cvtepu16_epi32(_mm_loadu_si128((const __m128i*)(row + j)));
+        __m256 f = _mm256_castsi256_ps(_mm256_slli_epi32(u, 16));
+        _mm256_storeu_ps(a + j, _mm256_fmadd_ps(f, xs, _mm256_loadu_ps(a + j)));
+    }
+    for (; j < w; ++j) a[j] += u32_as_f32((uint32_t)row[j] << 16) * xm;
+}
+static int have_avx2(void) {
+    static int v = -1;
+    if (v < 0) v = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("f16c") &&
+                   __builtin_cpu_supports("fma");
+    return v;
+}
+#else
+static int have_avx2(void) { return 0; }
+static void axpy_f16_avx2(float* a, const uint16_t* r, float x, int w) { (void)a; (void)r; (void)x; (void)w; }
+static void axpy_bf16_avx2(float* a, const uint16_t* r, float x, int w) { (void)a; (void)r; (void)x; (void)w; }
+#endif
+
+int teal_oracle_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+int teal_oracle_fast_qkv_gemv(const uint16_t* x, const uint16_t* wT, uint16_t* y, float tq,
+                              float tk, float tv, int Z, int N, int N_q, int N_kv, int dtype) {
+    if (!x || !wT || !y || Z <= 0 || N <= 0) return -1;
+    build_table();
+    int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)Z * 3);
+    float* xv = (float*)malloc(sizeof(float) * (size_t)Z);
+    if (!idx || !xv) { free(idx); free(xv); return -3; }
+    int32_t* lists[3] = {idx, idx + Z, idx + 2 * (size_t)Z};
+    int cnt[3];
+    float taus[3] = {tq, tk, tv};
+    for (int m = 0; m < Z; ++m) xv[m] = load16(x[m], dtype);
+    for (int s = 0; s < 3; ++s) {
+        int c = 0;
+        for (int m = 0; m < Z; ++m) if (fabsf(xv[m]) > taus[s]) lists[s][c++] = m;
+        cnt[s] = c;
+    }
+    const int TILE = 256;
+    const int simd = have_avx2();
+    int ntiles = (N + TILE - 1) / TILE;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int t = 0; t < ntiles; ++t) {
+        int n0 = t * TILE;
+        int n1 = n0 + TILE < N ? n0 + TILE : N;
+        /* a tile may straddle a segment boundary only if N_q / N_kv are not
+         * multiples of TILE; handle generally by per-column segment lookup */
+        float acc[256];
+        for (int j = 0; j < TILE; ++j) acc[j] = 0.0f;
+        int c = n0;
+        while (c < n1) {
+            int seg = c < N_q ? 0 : (c < N_q + N_kv ? 1 : 2);
+            int segend = seg == 0 ? N_q : (seg == 1 ? N_q + N_kv : N);
+            int e = segend < n1 ? segend : n1;
+            const int32_t* L = lists[seg];
+            int w = e - c;
+            float* a = acc + (c - n0);
+            for (int k = 0; k < cnt[seg]; ++k) {
+                int m = L[k];
+                float xm = xv[m];
+                const uint16_t* row = wT + (size_t)m * N + c;
+                if (simd) {
+                    if (dtype == TEAL_BF16) axpy_bf16_avx2(a, row, xm, w);
+                    else axpy_f16_avx2(a, row, xm, w);
+                } else if (dtype == TEAL_BF16)
+                    for (int j = 0; j < w; ++j) a[j] += u32_as_f32((uint32_t)row[j] << 16) * xm;
+                else
+                    for (int j = 0; j < w; ++j) a[j] += g_h2f[row[j]] * xm;
+            }
+            c = e;
+        }
+        for (int j = 0; j < n1 - n0; ++j) y[n0 + j] = store16(acc[j], dtype);
+    }
+    free(idx);
+    free(xv);
+    return 0;
+}
+
+int teal_oracle_fast_sparse_gemv(const uint16_t* x, const uint16_t* wT, uint16_t* y, float tau,
+                                 int Z, int N, int dtype) {
+    return teal_oracle_fast_qkv_gemv(x, wT, y, tau, tau, tau, Z, N, N, 0, dtype);
+}
+
+/* dense x @ W.T  (kernels/sparse_gemv.py:271): every row kept */
+int teal_oracle_fast_dense_gemv(const uint16_t* x, const uint16_t* wT, uint16_t* y, int Z, int N,
+                                int dtype) {
+    return teal_oracle_fast_sparse_gemv(x, wT, y, -1.0f, Z, N, dtype);
+}
+
+/* ------------------------------------------------------------------ */
+/* Portable data generator: value k/2048 - 0.5 with k = 11 hashed bits,  */
+/* exactly representable in fp16 and bf16-roundable; bit-identical to    */
+/* oracle/teal_oracle.py:hash_uniform (numpy) so big W never needs to be */
+/* stored in a fixture.                                                  */
+/* ------------------------------------------------------------------ */
+static inline uint32_t mix32(uint32_t i, uint32_t seed) {
+    uint32_t h = i * 2654435761u + seed * 0x9E3779B9u;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+int teal_oracle_hash_uniform(uint16_t* out, size_t n, uint32_t seed, float scale, int dtype) {
+    if (!out) return -1;
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t h = mix32((uint32_t)i, seed);
+        float v = ((float)(int)(h >> 21) - 1024.0f) * (1.0f / 2048.0f) * scale;
+        out[i] = store16(v, dtype);
+    }
+    return 0;
+}

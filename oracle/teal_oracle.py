@@ -1,0 +1,255 @@
+"""ctypes front-end of the CPU oracle (oracle/teal_oracle.c) + numpy restatements.
+
+TEST INFRASTRUCTURE ONLY — see the header of oracle/teal_oracle.c.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package teal_amd/ never does.
+
+Reference anchors (into /root/reference):
+  keep rule .................. kernels/sparse_gemv.py:75
+  split-K sparse GEMV ........ kernels/sparse_gemv.py:50-83
+  3-threshold QKV GEMV ....... kernels/sparse_gemv.py:152-194
+  SparsifyFn.apply ........... utils/utils.py:51-52
+  Distribution.icdf .......... gpt-fast/distribution.py:48-66
+  greedy lookup .............. utils/utils.py:243-259
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libteal_oracle.so")
+_lib = None
+
+F16, BF16 = 0, 1
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/teal_oracle.c with gcc (Makefile next to it)."""
+    src = os.path.join(_HERE, "teal_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libteal_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        u16p = ctypes.POINTER(ctypes.c_uint16)
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        f64p = ctypes.POINTER(ctypes.c_double)
+        c_int, c_float = ctypes.c_int, ctypes.c_float
+        L.teal_oracle_compact.argtypes = [u16p, c_int, c_int, c_float, i32p, i32p]
+        L.teal_oracle_sparsify_fn_apply.argtypes = [u16p, c_int, c_int, ctypes.c_uint16, u16p]
+        L.teal_oracle_ref_qkv_gemv.argtypes = [u16p, u16p, u16p, c_float, c_float, c_float, c_int, c_int,
+                                               c_int, c_int, c_int, c_int, c_int]
+        L.teal_oracle_ref_sparse_gemv.argtypes = [u16p, u16p, u16p, c_float, c_int, c_int, c_int, c_int, c_int]
+        L.teal_oracle_truth64.argtypes = [u16p, u16p, f64p, c_float, c_float, c_float, c_int, c_int, c_int,
+                                          c_int, c_int]
+        L.teal_oracle_fast_qkv_gemv.argtypes = [u16p, u16p, u16p, c_float, c_float, c_float, c_int, c_int,
+                                                c_int, c_int, c_int]
+        L.teal_oracle_fast_sparse_gemv.argtypes = [u16p, u16p, u16p, c_float, c_int, c_int, c_int]
+        L.teal_oracle_fast_dense_gemv.argtypes = [u16p, u16p, u16p, c_int, c_int, c_int]
+        L.teal_oracle_hash_uniform.argtypes = [u16p, ctypes.c_size_t, ctypes.c_uint32, c_float, c_int]
+        L.teal_oracle_num_threads.restype = c_int
+        L.teal_oracle_half_to_float.argtypes = [ctypes.c_uint16]
+        L.teal_oracle_half_to_float.restype = c_float
+        L.teal_oracle_float_to_half.argtypes = [c_float]
+        L.teal_oracle_float_to_half.restype = ctypes.c_uint16
+        L.teal_oracle_bf16_to_float.argtypes = [ctypes.c_uint16]
+        L.teal_oracle_bf16_to_float.restype = c_float
+        L.teal_oracle_float_to_bf16.argtypes = [c_float]
+        L.teal_oracle_float_to_bf16.restype = ctypes.c_uint16
+        _lib = L
+    return _lib
+
+
+def _u16(a: np.ndarray):
+    assert a.dtype == np.uint16 and a.flags["C_CONTIGUOUS"], (a.dtype, a.flags)
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16))
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"oracle {what} failed rc={rc}")
+
+
+# ----------------------------------------------------------------------------------------
+# raw-bits helpers: all oracle entry points take uint16 bit patterns
+# ----------------------------------------------------------------------------------------
+def to_bits(a, dtype: int) -> np.ndarray:
+    """float array -> raw 16-bit patterns of fp16 (dtype 0) or bf16 (dtype 1), RNE."""
+    a = np.asarray(a)
+    if a.dtype == np.uint16:
+        return np.ascontiguousarray(a)
+    if dtype == F16:
+        return np.ascontiguousarray(a.astype(np.float16)).view(np.uint16)
+    f = np.ascontiguousarray(a.astype(np.float32)).view(np.uint32)
+    lsb = (f >> 16) & 1
+    r = ((f + 0x7FFF + lsb) >> 16).astype(np.uint16)
+    nan = (f & 0x7FFFFFFF) > 0x7F800000
+    r[nan] = ((f[nan] >> 16) | 0x40).astype(np.uint16)
+    return r
+
+
+def from_bits(b: np.ndarray, dtype: int) -> np.ndarray:
+    """raw 16-bit patterns -> float32 values."""
+    b = np.ascontiguousarray(b).view(np.uint16)
+    if dtype == F16:
+        return b.view(np.float16).astype(np.float32)
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def ulp16(v, dtype: int) -> np.ndarray:
+    """spacing of the 16-bit format at |v| (fp16: 10 mantissa bits, bf16: 7)."""
+    v = np.abs(np.asarray(v, dtype=np.float64))
+    mant = 10 if dtype == F16 else 7
+    emin = -14 if dtype == F16 else -126
+    e = np.floor(np.log2(np.maximum(v, 2.0 ** emin)))
+    return 2.0 ** (e - mant)
+
+
+# ----------------------------------------------------------------------------------------
+# portable data generator (bit-identical to teal_oracle_hash_uniform in C)
+# ----------------------------------------------------------------------------------------
+def hash_uniform(n: int, seed: int, scale: float = 1.0, dtype: int = F16, offset: int = 0) -> np.ndarray:
+    """U(-0.5, 0.5)*scale on an 11-bit grid, as raw 16-bit patterns. numpy restatement."""
+    i = (np.arange(offset, offset + n, dtype=np.uint64)) & 0xFFFFFFFF
+    h = (i * np.uint64(2654435761) + np.uint64((seed * 0x9E3779B9) & 0xFFFFFFFF)) & 0xFFFFFFFF
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x85EBCA6B)) & 0xFFFFFFFF
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xC2B2AE35)) & 0xFFFFFFFF
+    h ^= h >> np.uint64(16)
+    v = ((h >> np.uint64(21)).astype(np.float32) - np.float32(1024.0)) * np.float32(1.0 / 2048.0) * np.float32(scale)
+    return to_bits(v, dtype)
+
+
+def hash_uniform_c(n: int, seed: int, scale: float = 1.0, dtype: int = F16) -> np.ndarray:
+    out = np.empty(n, dtype=np.uint16)
+    _check(lib().teal_oracle_hash_uniform(_u16(out), n, seed & 0xFFFFFFFF, scale, dtype), "hash_uniform")
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# keep rule / compaction
+# ----------------------------------------------------------------------------------------
+def compact(x_bits: np.ndarray, tau: float, dtype: int = F16) -> np.ndarray:
+    """ascending indices m with float32(|x[m]|) > float32(tau) (kernels/sparse_gemv.py:75)."""
+    x_bits = np.ascontiguousarray(x_bits.reshape(-1))
+    idx = np.empty(x_bits.size, dtype=np.int32)
+    cnt = ctypes.c_int32(0)
+    _check(lib().teal_oracle_compact(_u16(x_bits), dtype, x_bits.size, tau,
+                                     idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ctypes.byref(cnt)),
+           "compact")
+    return idx[: cnt.value].copy()
+
+
+def compact_np(x_bits: np.ndarray, tau: float, dtype: int = F16) -> np.ndarray:
+    """independent numpy restatement of the same rule."""
+    v = from_bits(x_bits.reshape(-1), dtype)
+    return np.nonzero(np.abs(v) > np.float32(tau))[0].astype(np.int32)
+
+
+def sparsify_fn_apply(x_bits: np.ndarray, tau: float, dtype: int = F16) -> np.ndarray:
+    """utils/utils.py:51-52 semantics (threshold rounded to x's dtype before the compare)."""
+    x_bits = np.ascontiguousarray(x_bits.reshape(-1))
+    out = np.empty_like(x_bits)
+    t = int(to_bits(np.array([tau], dtype=np.float32), dtype)[0])
+    _check(lib().teal_oracle_sparsify_fn_apply(_u16(x_bits), dtype, x_bits.size, t, _u16(out)), "sparsify")
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# GEMV restatements
+# ----------------------------------------------------------------------------------------
+def ref_sparse_gemv(x_bits, wT_bits, tau, Z, N, dtype=F16, block_m=128, block_n=512) -> np.ndarray:
+    """bit-level restatement of splitk_sparse_gemv_kernel (fp16 output bits)."""
+    y = np.empty(N, dtype=np.uint16)
+    _check(lib().teal_oracle_ref_sparse_gemv(_u16(x_bits), _u16(wT_bits), _u16(y), tau, Z, N, dtype,
+                                             block_m, block_n), "ref_sparse_gemv")
+    return y
+
+
+def ref_qkv_gemv(x_bits, wT_bits, tq, tk, tv, Z, N, N_q, N_kv, dtype=F16, block_m=128, block_n=512):
+    y = np.empty(N, dtype=np.uint16)
+    _check(lib().teal_oracle_ref_qkv_gemv(_u16(x_bits), _u16(wT_bits), _u16(y), tq, tk, tv, Z, N, N_q, N_kv,
+                                          dtype, block_m, block_n), "ref_qkv_gemv")
+    return y
+
+
+def truth64(x_bits, wT_bits, Z, N, tq, tk=None, tv=None, N_q=None, N_kv=0, dtype=F16) -> np.ndarray:
+    """double-precision sum over kept rows (thresholds per column range)."""
+    if tk is None:
+        tk, tv, N_q, N_kv = tq, tq, N, 0
+    y = np.empty(N, dtype=np.float64)
+    _check(lib().teal_oracle_truth64(_u16(x_bits), _u16(wT_bits), y.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                     tq, tk, tv, Z, N, N_q, N_kv, dtype), "truth64")
+    return y
+
+
+def truth64_np(x_bits, wT_bits, Z, N, tau, dtype=F16) -> np.ndarray:
+    """independent numpy restatement (small shapes)."""
+    x = from_bits(x_bits, dtype).astype(np.float64)
+    W = from_bits(wT_bits, dtype).astype(np.float64).reshape(Z, N)
+    keep = np.abs(from_bits(x_bits, dtype)) > np.float32(tau)
+    return (W[keep] * x[keep, None]).sum(axis=0)
+
+
+def fast_sparse_gemv(x_bits, wT_bits, tau, Z, N, dtype=F16) -> np.ndarray:
+    """fp32-accumulate / round-once CPU port (OpenMP); the timed CPU baseline."""
+    y = np.empty(N, dtype=np.uint16)
+    _check(lib().teal_oracle_fast_sparse_gemv(_u16(x_bits), _u16(wT_bits), _u16(y), tau, Z, N, dtype), "fast")
+    return y
+
+
+def fast_qkv_gemv(x_bits, wT_bits, tq, tk, tv, Z, N, N_q, N_kv, dtype=F16) -> np.ndarray:
+    y = np.empty(N, dtype=np.uint16)
+    _check(lib().teal_oracle_fast_qkv_gemv(_u16(x_bits), _u16(wT_bits), _u16(y), tq, tk, tv, Z, N, N_q, N_kv,
+                                           dtype), "fast_qkv")
+    return y
+
+
+def fast_dense_gemv(x_bits, wT_bits, Z, N, dtype=F16) -> np.ndarray:
+    y = np.empty(N, dtype=np.uint16)
+    _check(lib().teal_oracle_fast_dense_gemv(_u16(x_bits), _u16(wT_bits), _u16(y), Z, N, dtype), "dense")
+    return y
+
+
+def num_threads() -> int:
+    return int(lib().teal_oracle_num_threads())
+
+
+# ----------------------------------------------------------------------------------------
+# threshold math (load-time, fp32) — restated in numpy from gpt-fast/distribution.py:17-66
+# ----------------------------------------------------------------------------------------
+def icdf_np(counts: np.ndarray, centers: np.ndarray, q: float) -> float:
+    """Distribution.icdf(q) with torch's fp32 arithmetic restated in numpy.
+
+    total = counts.sum() (fp32), cum = cumsum(counts) (fp32), target = q*total (fp32),
+    idx = searchsorted(cum, target) (left), linear interpolation between centres idx-1, idx.
+    torch.cumsum / sum on CPU fp32 accumulate sequentially in fp32 for cumsum; `sum` uses
+    a vectorised pairwise order, so callers pass torch-produced totals when bit-parity with
+    the fixtures matters (tests/test_thresholds.py uses teal_amd.distribution for that and
+    this function only as an independent cross-check within 1 ulp).
+    """
+    counts = np.asarray(counts, dtype=np.float32)
+    centers = np.asarray(centers, dtype=np.float32)
+    cum = np.cumsum(counts, dtype=np.float32)
+    total = np.float32(counts.sum(dtype=np.float32))
+    target = np.float32(q) * total
+    idx = int(np.searchsorted(cum, target, side="left"))
+    if idx == 0:
+        return float(centers[0])
+    if idx == len(centers):
+        return float(centers[-1])
+    lo_c, hi_c = cum[idx - 1], cum[idx]
+    lo_v, hi_v = centers[idx - 1], centers[idx]
+    frac = np.float32(target - lo_c) / np.float32(hi_c - lo_c)
+    return float(np.float32(lo_v + frac * np.float32(hi_v - lo_v)))
