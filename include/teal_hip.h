@@ -1,0 +1,114 @@
+/*
+ * teal_hip.h — C ABI of libteal_hip.so, the MI355X (gfx950) implementation of TEAL's
+ * activation-sparsity decode hot path.
+ *
+ * Every entry point replaces one piece of the reference's Triton path; citations are
+ * into the reference tree (FasterDecoding/TEAL @ 2024-10-22):
+ *
+ *   teal_sparse_gemv       <- kernels/sparse_gemv.py:87-142  splitk_sparse_gemv()  + :50-83 kernel
+ *                             (+ the init_to_zero("Y") pre-hook launch, :8-12, which disappears)
+ *   teal_sparse_qkv_gemv   <- kernels/sparse_gemv.py:196-237 qkv_gemv()            + :152-194 kernel
+ *   teal_compact           <- kernels/sparse_gemv.py:75      idx = tl.abs(x0) > threshold
+ *                             (exposed standalone so index sets can be tested bit-exactly)
+ *   teal_dense_gemv        <- kernels/sparse_gemv.py:301-307 DenseGEMV / torch.matmul(x, W.T) at S == 1
+ *   teal_sparse_gateup_silu, teal_rmsnorm, ...  (fusions either side of the path, SURVEY §8(f) rank 1;
+ *                             gpt-fast/model.py:258-259,158-161,289-291)
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types, no exceptions across the boundary.
+ *   - All pointers are DEVICE pointers owned by the caller (PyTorch); the library borrows them for
+ *     the duration of the stream-ordered launch and keeps no mutable global state (only immutable
+ *     device properties cached by teal_init()).
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Every call is
+ *     asynchronous, allocation-free and hipGraph-capture safe.
+ *   - dtype: 0 = fp16, 1 = bf16 (x, weights and y share it).
+ *   - Weight layout: the reference's "column major" weight[N, Z] with strides (1, N), i.e. the
+ *     memory image is W^T row-major [Z][N]: element (m, n) at wT[m * N + n]
+ *     (kernels/sparse_gemv.py:68,106).  N % 8 == 0 (16-byte rows), 1 <= Z <= 65536.
+ *   - Keep rule: row m is kept iff float32(|x[m]|) > float32(tau)  (strict; kernels/sparse_gemv.py:75).
+ *     In the GEMV entry points a NaN x[m] additionally propagates NaN into every output column of its
+ *     threshold group, as the reference's `0 * NaN` on masked rows does.
+ *   - Arithmetic: fp32 multiply-accumulate over the kept rows, ONE rounding to dtype at the end
+ *     (the reference rounds through fp16 atomics, kernels/sparse_gemv.py:83); no atomics, results are
+ *     bit-reproducible run to run.
+ *   - Return value: 0 on success, negative TEAL_ERR_* otherwise (teal_strerror()).
+ */
+#ifndef TEAL_HIP_H
+#define TEAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TEAL_OK 0
+#define TEAL_ERR_ARG (-1)       /* null pointer / non-positive size */
+#define TEAL_ERR_DTYPE (-2)     /* dtype not 0 (fp16) / 1 (bf16) */
+#define TEAL_ERR_SHAPE (-3)     /* N % 8 != 0, Z > 65536, bad N_q / N_kv */
+#define TEAL_ERR_ALIGN (-4)     /* pointer not 16-byte aligned */
+#define TEAL_ERR_WORKSPACE (-5) /* workspace too small (teal_workspace_bytes) */
+#define TEAL_ERR_LAUNCH (-6)    /* hipGetLastError() after the launch */
+#define TEAL_ERR_NO_DEVICE (-7) /* no HIP device / teal_init failed */
+#define TEAL_ERR_CONFIG (-8)    /* invalid tuning override */
+
+#define TEAL_F16 0
+#define TEAL_BF16 1
+
+int teal_version(void);
+const char* teal_strerror(int code);
+
+/* Cache immutable device properties (CU count).  Call once per process before any launch that
+ * may happen during stream capture.  Returns the CU count (> 0) or a negative error. */
+int teal_init(void);
+
+/* Bytes of fp32 split-K workspace a GEMV of this shape may need (upper bound over all launch
+ * geometries).  The caller allocates once and reuses; distinct streams need distinct workspaces. */
+size_t teal_workspace_bytes(int Z, int N);
+
+/* idx_out[0..count) = ascending m with float32(|x[m]|) > float32(tau); *count_out = count.
+ * idx_out must hold Z int32.  (kernels/sparse_gemv.py:75) */
+int teal_compact(const void* x, float tau, int Z, int dtype, int32_t* idx_out, int32_t* count_out,
+                 void* stream);
+
+/* y[n] = sum_{m kept} wT[m*N + n] * x[m]            (kernels/sparse_gemv.py:87-142) */
+int teal_sparse_gemv(const void* x, const void* wT, void* y, float tau, int Z, int N, int dtype,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* Same on the fused wqkv weight with a threshold per column range:
+ * columns [0,N_q) tau_q, [N_q,N_q+N_kv) tau_k, [N_q+N_kv,N) tau_v   (kernels/sparse_gemv.py:196-237;
+ * N_q = N - 2*kv_size, N_kv = kv_size there).  N_q and N_kv must be multiples of 8. */
+int teal_sparse_qkv_gemv(const void* x, const void* wT, void* y, float tau_q, float tau_k,
+                         float tau_v, int Z, int N, int N_q, int N_kv, int dtype, void* ws,
+                         size_t ws_bytes, void* stream);
+
+/* y = x @ W^T with every row kept (prefill-free decode of un-sparsified layers, e.g. lm_head).
+ * (kernels/sparse_gemv.py:301-307) */
+int teal_dense_gemv(const void* x, const void* wT, void* y, int Z, int N, int dtype, void* ws,
+                    size_t ws_bytes, void* stream);
+
+/* ---- fusions around the path ------------------------------------------ */
+
+/* h[n] = silu(gate[n]) * up[n] with gate = sparse_gemv(x, w1T, tau_gate), up = sparse_gemv(x, w3T,
+ * tau_up), both [Z][N]; gate/up are rounded to dtype before the activation and the product, as the
+ * unfused reference sequence does (gpt-fast/model.py:258-259).  One launch, one shared read of x. */
+int teal_sparse_gateup_silu(const void* x, const void* w1T, const void* w3T, void* h, float tau_gate,
+                            float tau_up, int Z, int N, int dtype, void* ws, size_t ws_bytes,
+                            void* stream);
+
+/* ---- tuning / introspection ------------------------------------------------------------------ */
+
+/* Override the launch geometry picked from (Z, N, CU count): lanes per row segment (8/16/32/64),
+ * waves per workgroup (4/8/16), split-K factor (>= 1) and unroll depth (4/8).  0 = automatic.
+ * Process-global; meant for benchmark sweeps only. */
+int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll);
+
+/* The geometry a GEMV of this shape would use: out[0..5) = {lanes_per_row, waves, split, unroll,
+ * workgroups}. */
+int teal_get_config(int Z, int N, int nseg, int* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEAL_HIP_H */

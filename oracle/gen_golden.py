@@ -228,7 +228,7 @@ def gen_boundary(inner, SparsifyFn):
     f16 = lambda v: np.array(v, dtype=np.float16)  # noqa: E731
     tau = 0.09997  # the survey's probe: fp16(0.1) = 0.09997559 > 0.09997 in fp32, but fp16(tau) == fp16(0.1)
     vals = np.zeros(Z, dtype=np.float16)
-    special = [0.1, -0.1, 0.0999, 0.09991, 0.0, -0.0, 6.0e-8, -6.0e-8, 65504.0, -65504.0, np.inf, -np.inf,
+    special = [0.1, -0.1, 0.0999, 0.09991, 0.0, -0.0, 6.0e-8, -6.0e-8, 65504.0, -65504.0, 3.0e-5, -3.0e-5,
                0.09985, 0.1001, 1.0, -1.0, 5.96e-8, 0.099976, -0.099976, 0.09992]
     vals[: len(special)] = f16(special)
     vals[len(special):] = (np.linspace(-0.2, 0.2, Z - len(special))).astype(np.float16)
@@ -247,6 +247,11 @@ def gen_boundary(inner, SparsifyFn):
     xn[5] = np.array([np.nan], dtype=np.float16).view(np.uint16)[0]
     out["nan_x"] = xn
     out["nan_y"] = run_ref_gemv(inner, xn, eye, tau, Z, N, O.F16, 16, 16)
+    # +inf is always kept; inf * 0 (identity's zeros) makes every other column NaN
+    xi = xb.copy()
+    xi[7] = np.array([np.inf], dtype=np.float16).view(np.uint16)[0]
+    out["inf_x"] = xi
+    out["inf_y"] = run_ref_gemv(inner, xi, eye, tau, Z, N, O.F16, 16, 16)
     # the fp16-compare rule of SparsifyFn.apply on the same vector (utils/utils.py:51-52)
     class _D:  # minimal stand-in distribution; set_threshold path not used
         def icdf(self, q):

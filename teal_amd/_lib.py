@@ -1,0 +1,85 @@
+"""Loader for libteal_hip.so (the C ABI of include/teal_hip.h).
+
+The product path has NO CPU fallback: if the HIP library cannot be built/loaded, every op
+raises.  `build()` cross-compiles for gfx950 with hipcc (works without a GPU present).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import shutil
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+SRC = os.path.join(_PKG, "csrc", "teal_kernels.hip")
+INCLUDE = os.path.join(_ROOT, "include")
+LIB_PATH = os.path.join(_PKG, "libteal_hip.so")
+
+# every symbol include/teal_hip.h declares
+EXPORTS = (
+    "teal_version", "teal_strerror", "teal_init", "teal_workspace_bytes", "teal_compact",
+    "teal_sparse_gemv", "teal_sparse_qkv_gemv", "teal_dense_gemv", "teal_sparse_gateup_silu",
+    "teal_set_tuning", "teal_get_config",
+)
+
+_lib = None
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libteal_hip.so (no CPU fallback exists)")
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> teal_amd/libteal_hip.so (in-tree, travels with the repo)."""
+    deps = [SRC, os.path.join(INCLUDE, "teal_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed",
+           f"-I{INCLUDE}", SRC, "-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the library and declare signatures. Raises if it is missing (never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). teal_amd has no CPU/eager fallback for the sparse GEMV path.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, cf, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+    L.teal_version.restype = ci
+    L.teal_strerror.argtypes = [ci]
+    L.teal_strerror.restype = ctypes.c_char_p
+    L.teal_init.restype = ci
+    L.teal_workspace_bytes.argtypes = [ci, ci]
+    L.teal_workspace_bytes.restype = sz
+    L.teal_compact.argtypes = [vp, cf, ci, ci, vp, vp, vp]
+    L.teal_sparse_gemv.argtypes = [vp, vp, vp, cf, ci, ci, ci, vp, sz, vp]
+    L.teal_sparse_qkv_gemv.argtypes = [vp, vp, vp, cf, cf, cf, ci, ci, ci, ci, ci, vp, sz, vp]
+    L.teal_dense_gemv.argtypes = [vp, vp, vp, ci, ci, ci, vp, sz, vp]
+    L.teal_sparse_gateup_silu.argtypes = [vp, vp, vp, vp, cf, cf, ci, ci, ci, vp, sz, vp]
+    L.teal_set_tuning.argtypes = [ci, ci, ci, ci]
+    L.teal_get_config.argtypes = [ci, ci, ci, ctypes.POINTER(ci)]
+    for name in EXPORTS:
+        getattr(L, name)  # AttributeError if the .so is stale
+        if getattr(L, name).restype is None:
+            getattr(L, name).restype = ci
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().teal_strerror(rc).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {rc})")

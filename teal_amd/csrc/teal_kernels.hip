@@ -1,0 +1,611 @@
+// teal_kernels.hip — hand-written HIP kernels (gfx950 / CDNA4, wave64) for TEAL's
+// activation-sparsity decode hot path, behind the C ABI of include/teal_hip.h.
+//
+// Replaces (reference tree FasterDecoding/TEAL @ 2024-10-22):
+//   kernels/sparse_gemv.py:50-83    splitk_sparse_gemv_kernel   -> sparse_gemv_kernel<>
+//   kernels/sparse_gemv.py:152-194  qkv_kernel                  -> sparse_gemv_kernel<> (3 segments)
+//   kernels/sparse_gemv.py:8-12     init_to_zero("Y") memset    -> gone (no accumulation into Y)
+//   kernels/sparse_gemv.py:83       fp16 tl.atomic_add split-K  -> fp32 slabs + ordered reduce
+//
+// Design (DESIGN.md has the long form):
+//   * One workgroup = one column tile (LPR lanes x 16 B = BN columns) x one even share of the
+//     kept-row list.  Each workgroup re-derives the kept list itself: a wave64 ballot per 64
+//     activations, a prefix sum over the ballot popcounts in LDS, then the (row, x) pairs of its
+//     share are scattered into an LDS list in ascending row order.  Because shares are cut from the
+//     compacted list (not from the raw Z range) every workgroup streams the same number of rows.
+//   * Main loop: each wave walks the LDS list RPW = 64/LPR rows at a time; a lane issues U
+//     independent 16-byte non-temporal loads (weights are read exactly once per token) before the
+//     first FMA, fp32 accumulators, no LDS staging of weights (GEMV has no reuse).
+//   * Reduction: shuffle across the RPW row groups of a wave, LDS across waves (fixed order),
+//     fp32 slab per K-slice, second tiny kernel sums slabs in slice order and rounds once.
+//     No atomics anywhere: bit-reproducible, and bf16 needs no special path.
+//   * HBM-bound skinny GEMV: no MFMA on purpose (north_star).
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdint.h>
+
+#include "teal_hip.h"
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kMaxSeg = 3;
+constexpr int kMaxSplit = 32;
+
+struct Seg {
+    const void* w;  // weight image of this segment: row-major [Z][ld]
+    void* y;        // output of this segment (element 0 = first column of the segment)
+    float tau;
+    int ld;      // row stride in elements
+    int col0;    // first column of the segment inside a weight row
+    int ncols;   // columns in the segment
+    int tile0;   // first tile id of the segment
+    int ws_off;  // column offset of the segment inside a workspace slab
+};
+
+struct Params {
+    const void* x;
+    float* ws;  // [split][ws_ld] fp32 partial slabs
+    int Z;
+    int nseg;
+    int ntiles;
+    int split;
+    int ws_ld;
+    int cap;       // LDS list capacity (entries)
+    int to_ws;     // 1: always write fp32 slabs (an epilogue kernel follows)
+    Seg seg[kMaxSeg];
+};
+
+__device__ __forceinline__ float bits_to_float(uint32_t b16, bool bf16) {
+    if (bf16) return __uint_as_float(b16 << 16);
+    _Float16 h = __builtin_bit_cast(_Float16, (uint16_t)b16);
+    return (float)h;
+}
+
+template <bool BF16>
+__device__ __forceinline__ uint16_t float_to_bits(float f) {
+    if (BF16) {
+        uint32_t u = __float_as_uint(f);
+        if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    }
+    _Float16 h = (_Float16)f;  // v_cvt_f16_f32, round-to-nearest-even
+    return __builtin_bit_cast(uint16_t, h);
+}
+
+// keep rule of the reference kernel: float32(|x|) > float32(tau)  (kernels/sparse_gemv.py:75)
+__device__ __forceinline__ bool keep_rule(float v, float tau) { return fabsf(v) > tau; }
+
+template <bool BF16>
+__device__ __forceinline__ void fma8(float (&acc)[8], const u32x4 w, const float xv) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t q = w[j];
+        float lo, hi;
+        if (BF16) {
+            lo = __uint_as_float(q << 16);
+            hi = __uint_as_float(q & 0xFFFF0000u);
+        } else {
+            const f16x2 h = __builtin_bit_cast(f16x2, q);
+            lo = (float)h.x;
+            hi = (float)h.y;
+        }
+        acc[2 * j] = fmaf(lo, xv, acc[2 * j]);
+        acc[2 * j + 1] = fmaf(hi, xv, acc[2 * j + 1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Workgroup-wide compaction of x against one threshold.
+//   phase A: one ballot per 64-element chunk -> masks[] in LDS
+//   phase B: wave 0 turns popcounts into an exclusive prefix (prefix[nch] = total kept)
+// `nan_keeps`: GEMV mode — a NaN activation is kept so that it poisons the output like the
+// reference's masked `0 * NaN` does; teal_compact uses the pure rule.
+// ------------------------------------------------------------------------------------------------
+template <int WAVES, bool BF16>
+__device__ __forceinline__ void wg_ballot_prefix(const uint16_t* __restrict__ x, const int Z,
+                                                 const float tau, const bool nan_keeps,
+                                                 unsigned long long* masks, int* prefix) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nch = (Z + 63) >> 6;
+    for (int c = wave; c < nch; c += WAVES) {
+        const int m = (c << 6) + lane;
+        bool k = false;
+        if (m < Z) {
+            const float v = bits_to_float(x[m], BF16);
+            k = keep_rule(v, tau) || (nan_keeps && (v != v));
+        }
+        const unsigned long long mask = __ballot(k);
+        if (lane == 0) masks[c] = mask;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        int base = 0;
+        for (int g0 = 0; g0 < nch; g0 += 64) {
+            const int c = g0 + lane;
+            const int v = (c < nch) ? __popcll(masks[c]) : 0;
+            int incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(incl, d);
+                if (lane >= d) incl += t;
+            }
+            if (c < nch) prefix[c] = base + incl - v;
+            base += __shfl(incl, 63);
+        }
+        if (lane == 0) prefix[nch] = base;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ int lane_rank(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// ------------------------------------------------------------------------------------------------
+// The sparse GEMV.  grid = ntiles * split workgroups of WAVES*64 threads.
+// ------------------------------------------------------------------------------------------------
+template <int LPR, int WAVES, int U, bool BF16>
+__global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p) {
+    constexpr int RPW = 64 / LPR;  // rows a wave touches per load instruction
+    constexpr int BN = LPR * 8;    // columns per tile (16 B per lane)
+    constexpr int T = WAVES * 64;
+    constexpr int STRIDE = WAVES * RPW;  // list entries consumed per workgroup step
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int Z = p.Z;
+    const int nch = (Z + 63) >> 6;
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(smem);
+    int* prefix = reinterpret_cast<int*>(masks + nch);
+    uint32_t* list = reinterpret_cast<uint32_t*>(prefix + ((nch + 2) & ~1));
+    float* red = reinterpret_cast<float*>(list + p.cap);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x % p.ntiles;
+    const int slice = blockIdx.x / p.ntiles;
+
+    int s = 0;
+    if (p.nseg > 1 && tile >= p.seg[1].tile0) s = 1;
+    if (p.nseg > 2 && tile >= p.seg[2].tile0) s = 2;
+    const Seg sg = p.seg[s];
+    const int tcol0 = (tile - sg.tile0) * BN;  // first column of the tile inside the segment
+
+    const uint16_t* __restrict__ x = reinterpret_cast<const uint16_t*>(p.x);
+
+    // ---- mask + prefix over the whole activation vector ----------------------------------------
+    wg_ballot_prefix<WAVES, BF16>(x, Z, sg.tau, true, masks, prefix);
+    const int total = prefix[nch];
+    const int lo = (int)(((long long)total * slice) / p.split);
+    const int hi = (int)(((long long)total * (slice + 1)) / p.split);
+    const int nloc = hi - lo;
+
+    // ---- scatter this share's (row, x) pairs into the LDS list, ascending ------------------------
+    for (int c = wave; c < nch; c += WAVES) {
+        const int base = prefix[c];
+        const int next = prefix[c + 1];
+        if (next <= lo || base >= hi) continue;  // chunk entirely outside the share (wave-uniform)
+        const unsigned long long mask = masks[c];
+        const int m = (c << 6) + lane;
+        if ((mask >> lane) & 1ull) {
+            const int pos = base + lane_rank(mask);
+            if (pos >= lo && pos < hi) list[pos - lo] = ((uint32_t)m << 16) | (uint32_t)x[m];
+        }
+    }
+    __syncthreads();
+
+    // ---- stream the kept rows ----------------------------------------------------------------------
+    const int g = lane / LPR;   // row group inside the wave
+    const int cl = lane % LPR;  // 16-byte column slot inside the tile
+    const int col = tcol0 + cl * 8;
+    const bool col_ok = col < sg.ncols;  // ragged last tile
+    const char* wp = reinterpret_cast<const char*>(sg.w) +
+                     ((size_t)(sg.col0 + (col_ok ? col : 0))) * 2;
+    const size_t ldb = (size_t)sg.ld * 2;
+
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+
+    int eb = wave * RPW;  // wave-uniform list position
+    if (col_ok) {
+        // full steps: every lane of the wave has U valid entries
+        for (; eb + (U - 1) * STRIDE + RPW <= nloc; eb += U * STRIDE) {
+            u32x4 w[U];
+            float xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t ent = list[eb + u * STRIDE + g];
+                xv[u] = bits_to_float(ent & 0xFFFFu, BF16);
+                w[u] = __builtin_nontemporal_load(
+                    reinterpret_cast<const u32x4*>(wp + (size_t)(ent >> 16) * ldb));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) fma8<BF16>(acc, w[u], xv[u]);
+        }
+        // tail: clamp the entry index, zero the contribution of clamped lanes
+        if (eb < nloc) {
+            u32x4 w[U];
+            float xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = eb + u * STRIDE + g;
+                const bool ok = e < nloc;
+                const uint32_t ent = list[ok ? e : nloc - 1];
+                xv[u] = ok ? bits_to_float(ent & 0xFFFFu, BF16) : 0.0f;
+                u32x4 t = __builtin_nontemporal_load(
+                    reinterpret_cast<const u32x4*>(wp + (size_t)(ent >> 16) * ldb));
+                if (!ok) t = (u32x4){0u, 0u, 0u, 0u};
+                w[u] = t;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) fma8<BF16>(acc, w[u], xv[u]);
+        }
+    }
+
+    // ---- reduce: row groups of the wave, then waves (fixed order) --------------------------------
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], off);
+    }
+    if (lane < LPR) {
+        float* r = red + wave * BN + lane * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = acc[j];
+    }
+    __syncthreads();
+    for (int t = tid; t < BN; t += T) {
+        const int c = tcol0 + t;
+        if (c >= sg.ncols) break;
+        float sum = 0.0f;
+#pragma unroll
+        for (int wv = 0; wv < WAVES; ++wv) sum += red[wv * BN + t];
+        if (p.split == 1 && !p.to_ws) {
+            reinterpret_cast<uint16_t*>(sg.y)[c] = float_to_bits<BF16>(sum);
+        } else {
+            p.ws[(size_t)slice * p.ws_ld + sg.ws_off + c] = sum;
+        }
+    }
+}
+
+// y[n] = round(sum_s ws[s][n]) in slice order; one thread per column.
+template <bool BF16>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const Params p) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= p.ws_ld) return;
+    int s = 0;
+    if (p.nseg > 1 && n >= p.seg[1].ws_off) s = 1;
+    if (p.nseg > 2 && n >= p.seg[2].ws_off) s = 2;
+    float sum = 0.0f;
+    for (int k = 0; k < p.split; ++k) sum += p.ws[(size_t)k * p.ws_ld + n];
+    reinterpret_cast<uint16_t*>(p.seg[s].y)[n - p.seg[s].ws_off] = float_to_bits<BF16>(sum);
+}
+
+// h[n] = silu(gate[n]) * up[n] from the fp32 slabs of a 2-segment (gate | up) GEMV.
+// gate and up are rounded to dtype first, silu is rounded, then the product is rounded — the same
+// roundings the unfused fp16 sequence F.silu(g) * u performs (gpt-fast/model.py:258-259).
+template <bool BF16>
+__global__ __launch_bounds__(256) void gateup_silu_epilogue_kernel(const Params p, void* h) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int N = p.seg[0].ncols;
+    if (n >= N) return;
+    float g = 0.0f, u = 0.0f;
+    for (int k = 0; k < p.split; ++k) {
+        g += p.ws[(size_t)k * p.ws_ld + n];
+        u += p.ws[(size_t)k * p.ws_ld + N + n];
+    }
+    const float g16 = bits_to_float(float_to_bits<BF16>(g), BF16);
+    const float u16 = bits_to_float(float_to_bits<BF16>(u), BF16);
+    const float sl = g16 / (1.0f + expf(-g16));
+    const float sl16 = bits_to_float(float_to_bits<BF16>(sl), BF16);
+    reinterpret_cast<uint16_t*>(h)[n] = float_to_bits<BF16>(sl16 * u16);
+}
+
+// Standalone compaction (one workgroup): ascending kept indices + count to global memory.
+template <bool BF16>
+__global__ __launch_bounds__(1024) void compact_kernel(const uint16_t* __restrict__ x, const int Z,
+                                                       const float tau, int32_t* __restrict__ idx_out,
+                                                       int32_t* __restrict__ count_out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int nch = (Z + 63) >> 6;
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(smem);
+    int* prefix = reinterpret_cast<int*>(masks + nch);
+    wg_ballot_prefix<16, BF16>(x, Z, tau, false, masks, prefix);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int c = wave; c < nch; c += 16) {
+        const unsigned long long mask = masks[c];
+        if ((mask >> lane) & 1ull) idx_out[prefix[c] + lane_rank(mask)] = (c << 6) + lane;
+    }
+    if (threadIdx.x == 0) *count_out = prefix[nch];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct Config {
+    int lpr, waves, split, unroll;
+};
+
+int g_num_cu = 0;
+Config g_override = {0, 0, 0, 0};
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+size_t lds_bytes(int Z, int cap, int waves, int lpr) {
+    const int nch = (Z + 63) >> 6;
+    return (size_t)nch * 8 + (size_t)((nch + 2) & ~1) * 4 + (size_t)cap * 4 +
+           (size_t)waves * lpr * 8 * 4;
+}
+
+int count_tiles(const Params& p, int bn) {
+    int t = 0;
+    for (int i = 0; i < p.nseg; ++i) t += (p.seg[i].ncols + bn - 1) / bn;
+    return t;
+}
+
+// Launch geometry from (Z, columns, CU count).  Deterministic: no autotune at first call.
+Config pick_config(int Z, int ncols_total, int nseg_tiles_hint) {
+    (void)nseg_tiles_hint;
+    const int ncu = g_num_cu > 0 ? g_num_cu : 256;
+    Config c;
+    c.lpr = 8;
+    c.waves = 8;
+    c.unroll = 4;
+    const int tiles = (ncols_total + c.lpr * 8 - 1) / (c.lpr * 8);
+    // aim at ~4 workgroups of 8 waves per CU, but keep >= 64 list entries per workgroup step
+    int split = (4 * ncu + tiles - 1) / tiles;
+    const int max_by_rows = Z / (2 * c.waves * (64 / c.lpr) * 2);  // >= 2 steps at 50 % kept
+    if (split > max_by_rows) split = max_by_rows;
+    if (split < 1) split = 1;
+    if (split > kMaxSplit) split = kMaxSplit;
+    c.split = split;
+    if (g_override.lpr) c.lpr = g_override.lpr;
+    if (g_override.waves) c.waves = g_override.waves;
+    if (g_override.split) c.split = g_override.split;
+    if (g_override.unroll) c.unroll = g_override.unroll;
+    // LDS list capacity: stay inside the 64 KB a workgroup gets without opting in to more
+    while ((size_t)((Z + c.split - 1) / c.split) * 4 > 40 * 1024 && c.split < kMaxSplit) ++c.split;
+    return c;
+}
+
+template <int LPR, int WAVES, int U>
+hipError_t launch_gemv_t(const Params& p, int dtype, size_t lds, hipStream_t st) {
+    const dim3 grid(p.ntiles * p.split), block(WAVES * 64);
+    if (dtype == TEAL_BF16)
+        hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, true>), grid, block, lds, st, p);
+    else
+        hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, false>), grid, block, lds, st, p);
+    return hipGetLastError();
+}
+
+template <int LPR, int WAVES>
+hipError_t launch_gemv_u(const Params& p, int dtype, size_t lds, int unroll, hipStream_t st) {
+    switch (unroll) {
+        case 2: return launch_gemv_t<LPR, WAVES, 2>(p, dtype, lds, st);
+        case 4: return launch_gemv_t<LPR, WAVES, 4>(p, dtype, lds, st);
+        case 8: return launch_gemv_t<LPR, WAVES, 8>(p, dtype, lds, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int LPR>
+hipError_t launch_gemv_w(const Params& p, int dtype, size_t lds, const Config& c, hipStream_t st) {
+    switch (c.waves) {
+        case 4: return launch_gemv_u<LPR, 4>(p, dtype, lds, c.unroll, st);
+        case 8: return launch_gemv_u<LPR, 8>(p, dtype, lds, c.unroll, st);
+        case 16: return launch_gemv_u<LPR, 16>(p, dtype, lds, c.unroll, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_gemv(const Params& p, int dtype, size_t lds, const Config& c, hipStream_t st) {
+    switch (c.lpr) {
+        case 8: return launch_gemv_w<8>(p, dtype, lds, c, st);
+        case 16: return launch_gemv_w<16>(p, dtype, lds, c, st);
+        case 32: return launch_gemv_w<32>(p, dtype, lds, c, st);
+        case 64: return launch_gemv_w<64>(p, dtype, lds, c, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// Common driver: fills geometry fields of `p` (segments' w/y/tau/ld/col0/ncols are set by the
+// caller), launches the GEMV and, if needed, the ordered slab reduce.
+int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStream_t st,
+             Config* used) {
+    int total_cols = 0;
+    for (int i = 0; i < p.nseg; ++i) total_cols += p.seg[i].ncols;
+    Config c = pick_config(p.Z, total_cols, p.nseg);
+    const int bn = c.lpr * 8;
+    int t = 0, off = 0;
+    for (int i = 0; i < p.nseg; ++i) {
+        p.seg[i].tile0 = t;
+        p.seg[i].ws_off = off;
+        t += (p.seg[i].ncols + bn - 1) / bn;
+        off += p.seg[i].ncols;
+    }
+    p.ntiles = t;
+    p.split = c.split;
+    p.ws_ld = off;
+    p.cap = (p.Z + c.split - 1) / c.split + 1;
+    p.to_ws = to_ws ? 1 : 0;
+    p.ws = reinterpret_cast<float*>(ws);
+    const size_t lds = lds_bytes(p.Z, p.cap, c.waves, c.lpr);
+    if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
+    if (c.split > 1 || to_ws) {
+        if (!ws || ws_bytes < (size_t)c.split * off * sizeof(float)) return TEAL_ERR_WORKSPACE;
+        if (!aligned16(ws)) return TEAL_ERR_ALIGN;
+    }
+    if (used) *used = c;
+    if (launch_gemv(p, dtype, lds, c, st) != hipSuccess) return TEAL_ERR_LAUNCH;
+    if (c.split > 1 && !to_ws) {
+        const dim3 grid((off + 255) / 256), block(256);
+        if (dtype == TEAL_BF16)
+            hipLaunchKernelGGL((splitk_reduce_kernel<true>), grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL((splitk_reduce_kernel<false>), grid, block, 0, st, p);
+        if (hipGetLastError() != hipSuccess) return TEAL_ERR_LAUNCH;
+    }
+    return TEAL_OK;
+}
+
+int check_common(const void* x, const void* w, const void* y, int Z, int N, int dtype) {
+    if (!x || !w || !y || Z <= 0 || N <= 0) return TEAL_ERR_ARG;
+    if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
+    if ((N & 7) != 0 || Z > 65536) return TEAL_ERR_SHAPE;
+    if (!aligned16(w) || (reinterpret_cast<uintptr_t>(x) & 1u) || (reinterpret_cast<uintptr_t>(y) & 1u))
+        return TEAL_ERR_ALIGN;
+    if (g_num_cu <= 0 && teal_init() <= 0) return TEAL_ERR_NO_DEVICE;
+    return TEAL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int teal_version(void) { return 100; }
+
+const char* teal_strerror(int code) {
+    switch (code) {
+        case TEAL_OK: return "ok";
+        case TEAL_ERR_ARG: return "bad argument (null pointer or non-positive size)";
+        case TEAL_ERR_DTYPE: return "unsupported dtype (0 = fp16, 1 = bf16)";
+        case TEAL_ERR_SHAPE: return "unsupported shape (need N % 8 == 0, Z <= 65536, segment sizes % 8 == 0)";
+        case TEAL_ERR_ALIGN: return "pointer not sufficiently aligned (weights/workspace 16 B)";
+        case TEAL_ERR_WORKSPACE: return "split-K workspace missing or too small (teal_workspace_bytes)";
+        case TEAL_ERR_LAUNCH: return "HIP kernel launch failed";
+        case TEAL_ERR_NO_DEVICE: return "no HIP device available";
+        case TEAL_ERR_CONFIG: return "invalid tuning override";
+        default: return "unknown error";
+    }
+}
+
+int teal_init(void) {
+    if (g_num_cu > 0) return g_num_cu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return TEAL_ERR_NO_DEVICE;
+    int cu = 0;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
+        return TEAL_ERR_NO_DEVICE;
+    g_num_cu = cu;
+    return cu;
+}
+
+size_t teal_workspace_bytes(int Z, int N) {
+    (void)Z;
+    if (N <= 0) return 0;
+    // kMaxSplit slabs of N columns; the fused gate|up GEMV uses two segments of N columns
+    return (size_t)kMaxSplit * (size_t)N * 2 * sizeof(float);
+}
+
+int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll) {
+    auto in = [](int v, std::initializer_list<int> ok) {
+        for (int o : ok) if (v == o) return true;
+        return false;
+    };
+    if (!in(lanes_per_row, {0, 8, 16, 32, 64}) || !in(waves, {0, 4, 8, 16}) ||
+        !in(unroll, {0, 2, 4, 8}) || split < 0 || split > kMaxSplit)
+        return TEAL_ERR_CONFIG;
+    g_override = {lanes_per_row, waves, split, unroll};
+    return TEAL_OK;
+}
+
+int teal_get_config(int Z, int N, int nseg, int* out) {
+    if (!out || Z <= 0 || N <= 0) return TEAL_ERR_ARG;
+    const Config c = pick_config(Z, N, nseg);
+    out[0] = c.lpr;
+    out[1] = c.waves;
+    out[2] = c.split;
+    out[3] = c.unroll;
+    out[4] = ((N + c.lpr * 8 - 1) / (c.lpr * 8)) * c.split;
+    return TEAL_OK;
+}
+
+int teal_compact(const void* x, float tau, int Z, int dtype, int32_t* idx_out, int32_t* count_out,
+                 void* stream) {
+    if (!x || !idx_out || !count_out || Z <= 0) return TEAL_ERR_ARG;
+    if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
+    if (Z > 65536) return TEAL_ERR_SHAPE;
+    const int nch = (Z + 63) >> 6;
+    const size_t lds = (size_t)nch * 8 + (size_t)(nch + 2) * 4;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const uint16_t* xp = reinterpret_cast<const uint16_t*>(x);
+    if (dtype == TEAL_BF16)
+        hipLaunchKernelGGL((compact_kernel<true>), dim3(1), dim3(1024), lds, st, xp, Z, tau, idx_out, count_out);
+    else
+        hipLaunchKernelGGL((compact_kernel<false>), dim3(1), dim3(1024), lds, st, xp, Z, tau, idx_out, count_out);
+    return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
+}
+
+int teal_sparse_qkv_gemv(const void* x, const void* wT, void* y, float tau_q, float tau_k,
+                         float tau_v, int Z, int N, int N_q, int N_kv, int dtype, void* ws,
+                         size_t ws_bytes, void* stream) {
+    int rc = check_common(x, wT, y, Z, N, dtype);
+    if (rc != TEAL_OK) return rc;
+    if (N_q < 0 || N_kv < 0 || N_q + N_kv > N || (N_q & 7) || (N_kv & 7)) return TEAL_ERR_SHAPE;
+    Params p = {};
+    p.x = x;
+    p.Z = Z;
+    const int widths[3] = {N_q, N_kv, N - N_q - N_kv};
+    const float taus[3] = {tau_q, tau_k, tau_v};
+    int col = 0, ns = 0;
+    for (int i = 0; i < 3; ++i) {
+        if (widths[i] > 0) {
+            Seg& sgm = p.seg[ns++];
+            sgm.w = wT;
+            sgm.y = reinterpret_cast<uint16_t*>(y) + col;
+            sgm.tau = taus[i];
+            sgm.ld = N;
+            sgm.col0 = col;
+            sgm.ncols = widths[i];
+        }
+        col += widths[i];
+    }
+    p.nseg = ns;
+    return run_gemv(p, dtype, ws, ws_bytes, false, reinterpret_cast<hipStream_t>(stream), nullptr);
+}
+
+int teal_sparse_gemv(const void* x, const void* wT, void* y, float tau, int Z, int N, int dtype,
+                     void* ws, size_t ws_bytes, void* stream) {
+    return teal_sparse_qkv_gemv(x, wT, y, tau, tau, tau, Z, N, N, 0, dtype, ws, ws_bytes, stream);
+}
+
+int teal_dense_gemv(const void* x, const void* wT, void* y, int Z, int N, int dtype, void* ws,
+                    size_t ws_bytes, void* stream) {
+    // |x| > -inf keeps every finite and infinite activation; NaN propagates via nan_keeps.
+    return teal_sparse_gemv(x, wT, y, -INFINITY, Z, N, dtype, ws, ws_bytes, stream);
+}
+
+int teal_sparse_gateup_silu(const void* x, const void* w1T, const void* w3T, void* h, float tau_gate,
+                            float tau_up, int Z, int N, int dtype, void* ws, size_t ws_bytes,
+                            void* stream) {
+    int rc = check_common(x, w1T, h, Z, N, dtype);
+    if (rc != TEAL_OK) return rc;
+    if (!w3T) return TEAL_ERR_ARG;
+    if (!aligned16(w3T)) return TEAL_ERR_ALIGN;
+    Params p = {};
+    p.x = x;
+    p.Z = Z;
+    p.nseg = 2;
+    p.seg[0].w = w1T; p.seg[0].y = nullptr; p.seg[0].tau = tau_gate; p.seg[0].ld = N; p.seg[0].col0 = 0; p.seg[0].ncols = N;
+    p.seg[1].w = w3T; p.seg[1].y = nullptr; p.seg[1].tau = tau_up;   p.seg[1].ld = N; p.seg[1].col0 = 0; p.seg[1].ncols = N;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    rc = run_gemv(p, dtype, ws, ws_bytes, true, st, nullptr);
+    if (rc != TEAL_OK) return rc;
+    const dim3 grid((N + 255) / 256), block(256);
+    if (dtype == TEAL_BF16)
+        hipLaunchKernelGGL((gateup_silu_epilogue_kernel<true>), grid, block, 0, st, p, h);
+    else
+        hipLaunchKernelGGL((gateup_silu_epilogue_kernel<false>), grid, block, 0, st, p, h);
+    return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+"""Model-side plugin swap: what gpt-fast/generate.py:256-331 (`monkeypatch_layer`) does to each
+TransformerBlock — load 4 histograms, derive 7 thresholds, install the gemv ops + thresholds as
+attributes, re-lay the 5 projection weights column-major, swap the forwards.
+
+The attribute bundle is exactly the reference's:
+  feed_forward: gemv1_kernel gemv1 gemv2_kernel gemv2 thresh_up thresh_gate thresh_down sparsity_bin
+  attention:    gemv1_kernel gemv1 gemv2_kernel gemv2 thresh_q thresh_k thresh_v thresh_o sparsity_bin
+so an unmodified gpt-fast model.py (`_new_attn_forward` / `_new_ffn_forward`, model.py:163-190,
+258-259) runs on these ops.  Extensions (not in the reference): per-projection sparsities
+(`sparsities` dict — wires the block-wise greedy tables the reference imports but never uses,
+generate.py:260-264), and explicit `thresholds` for synthetic models.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from .distribution import Distribution, threshold_for_sparsity
+from .kernels.sparse_gemv import SparseGEMV, SparseQKVGEMV
+from .utils import PROJS
+
+# projection -> (sub-directory, histogram key)   (gpt-fast/generate.py:278-287)
+PROJ_HIST = {"q": ("self_attn", "h1"), "k": ("self_attn", "h1"), "v": ("self_attn", "h1"),
+             "o": ("self_attn", "h2"), "gate": ("mlp", "h1"), "up": ("mlp", "h1"), "down": ("mlp", "h2")}
+
+
+def layer_thresholds(layer_idx: int, hist_path: str, sparsities: Dict[str, Sequence[float]]) -> Dict[str, float]:
+    """7 thresholds of one layer from its histograms: tau = icdf(0.5 + 0.5*s)."""
+    cache: Dict[tuple, Distribution] = {}
+    out = {}
+    for proj in PROJS:
+        sub, h = PROJ_HIST[proj]
+        if (sub, h) not in cache:
+            cache[(sub, h)] = Distribution(os.path.join(hist_path, f"layer-{layer_idx}", sub), h)
+        out[proj] = threshold_for_sparsity(cache[(sub, h)], sparsities[proj][layer_idx])
+    return out
+
+
+def to_column_major(linear: torch.nn.Linear) -> None:
+    """weight.data = weight.data.T.contiguous().T : shape stays [N, Z], memory becomes W^T [Z][N]
+    (gpt-fast/generate.py:296-317)."""
+    w = linear.weight.data
+    if w.stride(0) == 1 and w.stride(1) == w.shape[0]:
+        return
+    linear.weight.data = w.T.contiguous().T
+
+
+def monkeypatch_layer(layer_idx: int, layer, sparsity, hist_path: Optional[str], device: str = "cuda", *,
+                      sparsities: Optional[Dict[str, Sequence[float]]] = None,
+                      thresholds: Optional[Dict[str, float]] = None) -> Dict[str, float]:
+    """Install the sparse-GEMV plugin on one gpt-fast TransformerBlock. Returns the thresholds."""
+    if thresholds is None:
+        if hist_path is None:
+            raise ValueError("need hist_path (calibration histograms) or explicit thresholds")
+        if sparsities is None:
+            n = layer_idx + 1
+            sparsities = {p: [sparsity] * n for p in PROJS}
+        thresholds = layer_thresholds(layer_idx, hist_path, sparsities)
+    ff, attn = layer.feed_forward, layer.attention
+
+    ff.gemv1_kernel = SparseGEMV.initialize("sparse_gemv", device)
+    ff.gemv1 = ff.gemv1_kernel.operator(True)
+    ff.thresh_up = thresholds["up"]
+    ff.thresh_gate = thresholds["gate"]
+    ff.sparsity_bin = 0
+    to_column_major(ff.w1)
+    to_column_major(ff.w3)
+    ff.gemv2_kernel = SparseGEMV.initialize("sparse_gemv", device)
+    ff.gemv2 = ff.gemv2_kernel.operator(True)
+    ff.thresh_down = thresholds["down"]
+    to_column_major(ff.w2)
+
+    attn.gemv1_kernel = SparseQKVGEMV.initialize("sparse_qkv_gemv", device)
+    attn.gemv1 = attn.gemv1_kernel.operator(True)
+    attn.thresh_q = thresholds["q"]
+    attn.thresh_k = thresholds["k"]
+    attn.thresh_v = thresholds["v"]
+    attn.sparsity_bin = 0
+    to_column_major(attn.wqkv)
+    attn.gemv2_kernel = SparseGEMV.initialize("sparse_gemv", device)
+    attn.gemv2 = attn.gemv2_kernel.operator(True)
+    attn.thresh_o = thresholds["o"]
+    to_column_major(attn.wo)
+
+    ff.apply_monkeypatch()
+    attn.apply_monkeypatch()
+    return thresholds

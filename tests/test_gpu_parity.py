@@ -1,0 +1,284 @@
+"""GPU (MI355X): the HIP path, called through the C ABI, against the oracle and the golden fixtures.
+
+Bars (BASELINE.json north_star / SURVEY §8(c)):
+  * index sets: bit-exact vs {m : float32(|x[m]|) > float32(tau)}, ascending;
+  * GEMV: |y - truth64| <= 1e-3*max(1,|truth64|) + 1 ulp_out(truth64)   AND
+          max|y - truth64| <= max|y_ref - truth64| (never worse than the reference kernel's own
+          fp16-atomic result on the same input, from the fixtures);
+  * bit-reproducible run to run (no atomics).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import (GOLDEN, bits_from_torch, colmajor_weight, kat_weights, load_kat, ref_keys, tolerance,
+                     torch_from_bits)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+GEMV_KATS = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "kat_gemv_*.npz")))
+QKV_KATS = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "kat_qkv_*.npz")))
+INDEX_KATS = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "kat_index_*.npz")))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from teal_amd import runtime
+    assert runtime.init() > 0
+    yield
+    from teal_amd import _lib
+    _lib.load().teal_set_tuning(0, 0, 0, 0)
+
+
+def K():
+    import teal_amd.kernels as k
+    return k
+
+
+def check_gemv(O, y_bits, truth, dtype, ref_err=None, what=""):
+    y = O.from_bits(y_bits, dtype).astype(np.float64)
+    err = np.abs(y - truth)
+    tol = tolerance(O, truth, dtype)
+    bad = err > tol
+    assert not bad.any(), f"{what}: {bad.sum()} columns outside tolerance, worst {err.max():.3e} (tol {tol[err.argmax()]:.3e})"
+    if ref_err is not None:
+        assert err.max() <= ref_err + 1e-12, f"{what}: worse than the reference kernel ({err.max():.3e} > {ref_err:.3e})"
+    return err.max()
+
+
+# ---------------------------------------------------------------------------------- index sets
+@pytest.mark.parametrize("name", INDEX_KATS + GEMV_KATS)
+def test_compact_bit_exact_golden(oracle, name):
+    k = load_kat(name)
+    dtype, tau = int(k["dtype"]), float(k["tau"])
+    x = torch_from_bits(k["x"], dtype, DEV)
+    idx, n = K().compact(x, tau)
+    assert n == k["kept"].size
+    assert np.array_equal(idx.cpu().numpy(), k["kept"])
+
+
+@pytest.mark.parametrize("Z", [1, 63, 64, 65, 1000, 4096, 11008, 14336, 28672, 65536])
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_compact_bit_exact_random(oracle, Z, dtype):
+    rng = np.random.default_rng(Z * 2 + dtype)
+    xb = oracle.to_bits(rng.standard_normal(Z).astype(np.float32), dtype)
+    for tau in (0.0, 0.3, 0.6744897, 5.0, -1.0):
+        idx, n = K().compact(torch_from_bits(xb, dtype, DEV), tau)
+        assert np.array_equal(idx.cpu().numpy(), oracle.compact(xb, tau, dtype)), (Z, dtype, tau)
+
+
+def test_compact_boundary_values(oracle):
+    k = load_kat("kat_boundary.npz")
+    for xb in (k["x"], k["nan_x"], k["inf_x"]):
+        x = torch_from_bits(xb, 0, DEV)
+        for name in ("tau_probe", "tau_zero", "tau_tiny", "tau_exact_x", "tau_below_x"):
+            tau = float(k[f"{name}_tau"])
+            idx, _ = K().compact(x, tau)
+            assert np.array_equal(idx.cpu().numpy(), oracle.compact(xb, tau, 0))
+    idx, _ = K().compact(torch_from_bits(k["x"], 0, DEV), float(k["tau_probe_tau"]))
+    assert 0 in idx.cpu().numpy()  # fp16(0.1) kept at tau=0.09997: the fp32 rule, not torch's fp16 one
+
+
+# ---------------------------------------------------------------------------------- GEMV vs golden
+@pytest.mark.parametrize("name", GEMV_KATS)
+def test_sparse_gemv_golden(oracle, name):
+    k = load_kat(name)
+    Z, N, dtype, tau = int(k["Z"]), int(k["N"]), int(k["dtype"]), float(k["tau"])
+    wb = kat_weights(oracle, k)
+    x = torch_from_bits(k["x"], dtype, DEV).view(1, 1, Z)
+    W = colmajor_weight(wb, Z, N, dtype, DEV)
+    truth = k["y_truth64"]
+    ref_err = max(np.abs(oracle.from_bits(k[r], 0).astype(np.float64) - truth).max() for r in ref_keys(k))
+    y = K().splitk_sparse_gemv(x, W, tau, 0)
+    assert y.shape == (1, 1, N) and y.dtype == x.dtype
+    e = check_gemv(oracle, bits_from_torch(y.view(-1)), truth, dtype, ref_err, name)
+    # deterministic: second call is bit-identical
+    y2 = K().splitk_sparse_gemv(x, W, tau, 0)
+    assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
+    # through the registered op as monkeypatch_layer installs it
+    op = K().SparseGEMV.initialize("sparse_gemv", "cuda").operator(True)
+    y3 = op(x, W, tau, 0)
+    assert torch.equal(y.view(torch.int16), y3.view(torch.int16))
+    print(f"{name}: max|err| {e:.2e} (reference kernel {ref_err:.2e})")
+
+
+@pytest.mark.parametrize("name", QKV_KATS)
+def test_qkv_gemv_golden(oracle, name):
+    k = load_kat(name)
+    Z, N, N_q, N_kv, dtype = (int(k[n]) for n in ("Z", "N", "N_q", "N_kv", "dtype"))
+    tq, tk, tv = float(k["tau_q"]), float(k["tau_k"]), float(k["tau_v"])
+    wb = kat_weights(oracle, k)
+    x = torch_from_bits(k["x"], dtype, DEV).view(1, 1, Z)
+    W = colmajor_weight(wb, Z, N, dtype, DEV)
+    truth = k["y_truth64"]
+    ref_err = max(np.abs(oracle.from_bits(k[r], 0).astype(np.float64) - truth).max() for r in ref_keys(k))
+    y = K().qkv_gemv(x, W, tq, tk, tv, 0, N_kv)
+    check_gemv(oracle, bits_from_torch(y.view(-1)), truth, dtype, ref_err, name)
+    op = K().SparseQKVGEMV.initialize("sparse_qkv_gemv", "cuda").operator(True)
+    assert torch.equal(op(x, W, tq, tk, tv, 0, N_kv).view(torch.int16), y.view(torch.int16))
+
+
+def test_boundary_nan_inf_propagate_like_reference(oracle):
+    k = load_kat("kat_boundary.npz")
+    Z = k["x"].size
+    eye = np.eye(Z, dtype=np.float16).view(np.uint16).reshape(-1).copy()
+    W = colmajor_weight(eye, Z, Z, 0, DEV)
+    for name in ("tau_probe", "tau_zero", "tau_tiny", "tau_exact_x", "tau_below_x"):
+        y = K().splitk_sparse_gemv(torch_from_bits(k["x"], 0, DEV).view(1, 1, Z), W, float(k[f"{name}_tau"]), 0)
+        # identity weights: no rounding involved, so the reference output is reproduced bit-for-bit
+        assert np.array_equal(bits_from_torch(y.view(-1)), k[f"{name}_y"]), name
+    yn = K().splitk_sparse_gemv(torch_from_bits(k["nan_x"], 0, DEV).view(1, 1, Z), W, float(k["tau_probe_tau"]), 0)
+    assert torch.isnan(yn).all()  # the reference's 0*NaN poisons every column
+    yi = K().splitk_sparse_gemv(torch_from_bits(k["inf_x"], 0, DEV).view(1, 1, Z), W, float(k["tau_probe_tau"]), 0).view(-1)
+    ri = oracle.from_bits(k["inf_y"], 0)
+    assert np.array_equal(np.isnan(ri), torch.isnan(yi).cpu().numpy()) and torch.isinf(yi[7])
+
+
+# ---------------------------------------------------------------------------------- shapes / geometry
+@pytest.mark.parametrize("Z,N", [(64, 8), (100, 72), (257, 520), (1000, 1000), (4096, 4104), (3000, 11008)])
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_ragged_shapes_vs_oracle(oracle, Z, N, dtype):
+    xb = oracle.hash_uniform(Z, 11 + Z, 4.0, dtype)
+    wb = oracle.hash_uniform_c(Z * N, 13 + N, 0.1, dtype)
+    x = torch_from_bits(xb, dtype, DEV).view(1, 1, Z)
+    W = colmajor_weight(wb, Z, N, dtype, DEV)
+    for tau in (-1.0, 0.0, 0.9, 1.7, 100.0):  # dense ... everything dropped
+        truth = oracle.truth64(xb, wb, Z, N, tau, dtype=dtype)
+        y = K().splitk_sparse_gemv(x, W, tau, 0)
+        check_gemv(oracle, bits_from_torch(y.view(-1)), truth, dtype, None, f"{Z}x{N} tau={tau}")
+    yd = K().dense_gemv(x, W)
+    check_gemv(oracle, bits_from_torch(yd.view(-1)), oracle.truth64(xb, wb, Z, N, -1.0, dtype=dtype), dtype)
+
+
+def test_every_launch_geometry_agrees(oracle):
+    """all (lanes_per_row, waves, split, unroll) variants compute the same GEMV (within rounding)."""
+    from teal_amd import _lib
+    L = _lib.load()
+    Z, N, dtype = 1536, 1280, 0
+    xb = oracle.hash_uniform(Z, 5, 4.0, dtype)
+    wb = oracle.hash_uniform_c(Z * N, 6, 0.1, dtype)
+    x = torch_from_bits(xb, dtype, DEV).view(1, 1, Z)
+    W = colmajor_weight(wb, Z, N, dtype, DEV)
+    truth = oracle.truth64(xb, wb, Z, N, 1.0, 0.5, 1.5, 512, 256, dtype)
+    try:
+        for lpr in (8, 16, 32, 64):
+            for waves in (4, 8, 16):
+                for split in (1, 2, 5, 32):
+                    for unroll in (2, 4, 8):
+                        assert L.teal_set_tuning(lpr, waves, split, unroll) == 0
+                        y = K().qkv_gemv(x, W, 1.0, 0.5, 1.5, 0, 256)
+                        check_gemv(oracle, bits_from_torch(y.view(-1)), truth, dtype, None, f"cfg {lpr},{waves},{split},{unroll}")
+    finally:
+        L.teal_set_tuning(0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("Z,N,dtype,s", [(8192, 8192, 0, 0.5), (8192, 28672, 0, 0.5), (28672, 8192, 0, 0.5),
+                                         (14336, 4096, 1, 0.4), (4096, 12288, 0, 0.5)])
+def test_full_size_shapes_vs_cpu_port(oracle, Z, N, dtype, s):
+    """BASELINE full sizes (70B / 8B shapes): HIP vs the oracle's fp32 CPU port + truth64 on a column sample."""
+    xb = oracle.hash_uniform(Z, 21 + Z, 4.0, dtype)
+    wb = oracle.hash_uniform_c(Z * N, 23 + N, 0.08, dtype)
+    tau = 2.0 * s  # x ~ U(-2, 2): P(|x| <= tau) = s
+    x = torch_from_bits(xb, dtype, DEV).view(1, 1, Z)
+    W = colmajor_weight(wb, Z, N, dtype, DEV)
+    y = bits_from_torch(K().splitk_sparse_gemv(x, W, tau, 0).view(-1))
+    truth = oracle.truth64(xb, wb, Z, N, tau, dtype=dtype)
+    check_gemv(oracle, y, truth, dtype, None, f"{Z}x{N}")
+    cpu = oracle.from_bits(oracle.fast_sparse_gemv(xb, wb, tau, Z, N, dtype), dtype)
+    # both round an fp32 sum once: they may differ by one ulp where the sums differ in the last bits
+    assert (np.abs(oracle.from_bits(y, dtype) - cpu) <= 2 * oracle.ulp16(truth, dtype) + 1e-6).all()
+
+
+def test_linearity_property_full_size(oracle):
+    """size-independent property: gemv(a*x) == a*gemv(x) exactly for a power of two (kept set fixed by scaling tau)."""
+    Z, N = 4096, 11008
+    xb = oracle.hash_uniform(Z, 31, 2.0, 0)
+    W = colmajor_weight(oracle.hash_uniform_c(Z * N, 32, 0.05, 0), Z, N, 0, DEV)
+    x = torch_from_bits(xb, 0, DEV).view(1, 1, Z)
+    y1 = K().splitk_sparse_gemv(x, W, 0.5, 0)
+    y2 = K().splitk_sparse_gemv(x * 2, W, 1.0, 0)
+    assert torch.equal((y1 * 2).view(torch.int16), y2.view(torch.int16))
+    # dropping rows by zeroing them == raising the threshold
+    xz = torch.where(x.abs().float() > 0.5, x, torch.zeros_like(x))
+    y3 = K().splitk_sparse_gemv(xz, W, 0.0, 0)
+    assert torch.equal(y1.view(torch.int16), y3.view(torch.int16))
+
+
+# ---------------------------------------------------------------------------------- fusion, graphs, errors
+def test_gateup_silu_fusion_equals_unfused_sequence(oracle):
+    for dtype, Z, N in ((0, 4096, 11008), (1, 4096, 14336), (0, 512, 1032)):
+        xb = oracle.hash_uniform(Z, 41, 4.0, dtype)
+        x = torch_from_bits(xb, dtype, DEV).view(1, 1, Z)
+        W1 = colmajor_weight(oracle.hash_uniform_c(Z * N, 42, 0.08, dtype), Z, N, dtype, DEV)
+        W3 = colmajor_weight(oracle.hash_uniform_c(Z * N, 43, 0.08, dtype), Z, N, dtype, DEV)
+        g = K().splitk_sparse_gemv(x, W1, 0.9, 0)
+        u = K().splitk_sparse_gemv(x, W3, 1.1, 0)
+        want = torch.nn.functional.silu(g) * u  # gpt-fast/model.py:258-259
+        got = K().sparse_gateup_silu(x, W1, W3, 0.9, 1.1)
+        diff = (got.float() - want.float()).abs()
+        ulp = torch.from_numpy(oracle.ulp16(want.float().cpu().numpy(), dtype)).to(DEV)
+        assert (diff.view(-1) <= ulp.view(-1).float() + 1e-7).all(), float(diff.max())
+        assert (diff == 0).float().mean() > 0.95
+
+
+def test_hipgraph_capture_and_replay(oracle):
+    Z, N = 4096, 4096
+    xb = oracle.hash_uniform(Z, 51, 4.0, 0)
+    W = colmajor_weight(oracle.hash_uniform_c(Z * N, 52, 0.08, 0), Z, N, 0, DEV)
+    x = torch_from_bits(xb, 0, DEV).view(1, 1, Z)
+    eager = K().splitk_sparse_gemv(x, W, 1.0, 0).clone()
+    xs = x.clone()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        K().splitk_sparse_gemv(xs, W, 1.0, 0)  # warm-up on the side stream
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        out = torch.ops.teal.sparse_gemv(xs, W, 1.0, 0)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), eager.view(torch.int16))
+    xs.copy_(x * 0.5)  # new activations, same graph: the kept set changes on-device
+    g.replay()
+    torch.cuda.synchronize()
+    want = K().splitk_sparse_gemv(x * 0.5, W, 1.0, 0)
+    assert torch.equal(out.view(torch.int16), want.view(torch.int16))
+
+
+def test_prefill_falls_back_to_dense_matmul():
+    Z, N = 256, 512
+    x = torch.randn(1, 5, Z, device=DEV, dtype=torch.float16)
+    W = (torch.randn(N, Z, device=DEV, dtype=torch.float16) * 0.05).T.contiguous().T
+    y = torch.ops.teal.sparse_gemv(x, W, 0.5, 0)  # kernels/sparse_gemv.py:271: seq_len > 1 -> matmul, no masking
+    assert torch.allclose(y, torch.matmul(x, W.T))
+
+
+def test_c_abi_error_codes():
+    from teal_amd import _lib, runtime
+    L = _lib.load()
+    x = torch.zeros(64, device=DEV, dtype=torch.float16)
+    w = torch.zeros(64 * 64, device=DEV, dtype=torch.float16)
+    y = torch.zeros(64, device=DEV, dtype=torch.float16)
+    ws = runtime.reserve_workspace(64, 64)
+    st = runtime.stream_ptr()
+    ok = L.teal_sparse_gemv(x.data_ptr(), w.data_ptr(), y.data_ptr(), 0.1, 64, 64, 0, ws.data_ptr(), ws.numel() * 4, st)
+    assert ok == 0
+    assert L.teal_sparse_gemv(None, w.data_ptr(), y.data_ptr(), 0.1, 64, 64, 0, ws.data_ptr(), ws.numel() * 4, st) == -1
+    assert L.teal_sparse_gemv(x.data_ptr(), w.data_ptr(), y.data_ptr(), 0.1, 64, 64, 7, ws.data_ptr(), ws.numel() * 4, st) == -2
+    assert L.teal_sparse_gemv(x.data_ptr(), w.data_ptr(), y.data_ptr(), 0.1, 64, 60, 0, ws.data_ptr(), ws.numel() * 4, st) == -3
+    assert L.teal_sparse_gemv(x.data_ptr(), w.data_ptr() + 2, y.data_ptr(), 0.1, 64, 64, 0, ws.data_ptr(), ws.numel() * 4, st) == -4
+    L.teal_set_tuning(8, 8, 4, 4)
+    try:
+        assert L.teal_sparse_gemv(x.data_ptr(), w.data_ptr(), y.data_ptr(), 0.1, 64, 64, 0, ws.data_ptr(), 16, st) == -5
+    finally:
+        L.teal_set_tuning(0, 0, 0, 0)
+    with pytest.raises(TypeError):
+        import teal_amd.kernels as k
+        k.splitk_sparse_gemv(torch.zeros(1, 1, 64, device=DEV), torch.zeros(64, 64, device=DEV).T.contiguous().T, 0.1, 0)
+    torch.cuda.synchronize()
