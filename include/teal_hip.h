@@ -104,6 +104,11 @@ int teal_sparse_gateup_silu(const void* x, const void* w1T, const void* w3T, voi
  * Process-global; meant for benchmark sweeps only. */
 int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll);
 
+/* Diagnostics: when set (device pointer to >= 8 * workgroups uint64), thread 0 of every GEMV
+ * workgroup stores 100 MHz wall-clock stamps of its phases (0 start, 1 ballots, 2 scatter,
+ * 3 list ready, 4 rows streamed, 5 done).  NULL (default) disables.  Process-global. */
+int teal_set_phase_buffer(void* dev_u64);
+
 /* The geometry a GEMV of this shape would use: out[0..5) = {lanes_per_row, waves, split, unroll,
  * workgroups}. */
 int teal_get_config(int Z, int N, int nseg, int* out);

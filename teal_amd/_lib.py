@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_PKG, "libteal_hip.so")
 EXPORTS = (
     "teal_version", "teal_strerror", "teal_init", "teal_workspace_bytes", "teal_compact",
     "teal_sparse_gemv", "teal_sparse_qkv_gemv", "teal_dense_gemv", "teal_sparse_gateup_silu",
-    "teal_set_tuning", "teal_get_config",
+    "teal_set_tuning", "teal_get_config", "teal_set_phase_buffer",
 )
 
 _lib = None
@@ -52,6 +52,11 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch ships its own libamdhip64 (same SONAME as /opt/rocm's).  Import torch FIRST so that
+    # our library binds to the HIP runtime torch's tensors and streams live in; loading ours first
+    # would bring in a second runtime that sees no device context.
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -70,6 +75,7 @@ def load() -> ctypes.CDLL:
     L.teal_dense_gemv.argtypes = [vp, vp, vp, ci, ci, ci, vp, sz, vp]
     L.teal_sparse_gateup_silu.argtypes = [vp, vp, vp, vp, cf, cf, ci, ci, ci, vp, sz, vp]
     L.teal_set_tuning.argtypes = [ci, ci, ci, ci]
+    L.teal_set_phase_buffer.argtypes = [vp]
     L.teal_get_config.argtypes = [ci, ci, ci, ctypes.POINTER(ci)]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError if the .so is stale

@@ -56,6 +56,7 @@ struct Params {
     int ws_ld;
     int cap;       // LDS list capacity (entries)
     int to_ws;     // 1: always write fp32 slabs (an epilogue kernel follows)
+    unsigned long long* phase;  // optional: per-workgroup phase timestamps (teal_set_phase_buffer)
     Seg seg[kMaxSeg];
 };
 
@@ -143,6 +144,24 @@ __device__ __forceinline__ void wg_ballot_prefix(const uint16_t* __restrict__ x,
     __syncthreads();
 }
 
+// wave64 inclusive scan: 4 DPP row_shr steps inside each row of 16 lanes, then the three row totals
+// are folded in through SGPRs (v_readlane) — no LDS traffic, unlike __shfl_up (ds_bpermute).
+__device__ __forceinline__ int wave_incl_scan(int v, const int lane) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    const int t0 = __builtin_amdgcn_readlane(v, 15);
+    const int t1 = __builtin_amdgcn_readlane(v, 31);
+    const int t2 = __builtin_amdgcn_readlane(v, 47);
+    return v + (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0);
+}
+
+// optional per-workgroup phase timestamps (constant 100 MHz clock, comparable across CUs)
+__device__ __forceinline__ void stamp(const Params& p, int phase) {
+    if (p.phase && threadIdx.x == 0) p.phase[(size_t)blockIdx.x * 8 + phase] = wall_clock64();
+}
+
 __device__ __forceinline__ int lane_rank(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -162,13 +181,15 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
     const int Z = p.Z;
     const int nch = (Z + 63) >> 6;
     unsigned long long* masks = reinterpret_cast<unsigned long long*>(smem);
-    int* prefix = reinterpret_cast<int*>(masks + nch);
-    uint32_t* list = reinterpret_cast<uint32_t*>(prefix + ((nch + 2) & ~1));
+    int* wavecnt = reinterpret_cast<int*>(masks + nch);
+    uint32_t* list = reinterpret_cast<uint32_t*>(wavecnt + 16);
     float* red = reinterpret_cast<float*>(list + p.cap);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Column tiles are interleaved over hardware blocks (block b runs on XCD b % 8, so every XCD
+    // walks the whole row range).  An XCD-contiguous tile range was measured 10-25 % slower.
     const int tile = blockIdx.x % p.ntiles;
     const int slice = blockIdx.x / p.ntiles;
 
@@ -179,27 +200,97 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
     const int tcol0 = (tile - sg.tile0) * BN;  // first column of the tile inside the segment
 
     const uint16_t* __restrict__ x = reinterpret_cast<const uint16_t*>(p.x);
+    stamp(p, 0);
 
-    // ---- mask + prefix over the whole activation vector ----------------------------------------
-    wg_ballot_prefix<WAVES, BF16>(x, Z, sg.tau, true, masks, prefix);
-    const int total = prefix[nch];
+    // ---- phase A: one ballot per 64 activations -> masks[]; the activations a wave ballots stay
+    //      in its registers for the scatter (chunk c is owned by wave c % WAVES) -------------------
+    constexpr int PER = 64 / WAVES;               // owned chunks per group of 64 chunks
+    constexpr int GREG = WAVES >= 16 ? 4 : (WAVES >= 8 ? 2 : 1);
+    constexpr int KR = GREG * PER;                // register-cached chunks per wave (Z <= 4096..16384)
+    const float tau = sg.tau;
+    uint32_t xr[KR];
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        const int m = (((k / PER) * 64 + wave + (k % PER) * WAVES) << 6) + lane;
+        xr[k] = (m < Z) ? (uint32_t)x[m] : 0u;
+    }
+    int mycnt = 0;
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        const int c = (k / PER) * 64 + wave + (k % PER) * WAVES;
+        if (c < nch) {
+            const float v = bits_to_float(xr[k], BF16);
+            // NaN propagates like the reference's 0 * NaN on masked rows
+            const bool kp = ((c << 6) + lane < Z) && (keep_rule(v, tau) || (v != v));
+            const unsigned long long mask = __ballot(kp);
+            if (lane == 0) masks[c] = mask;
+            mycnt += __popcll(mask);
+        }
+    }
+    for (int c = GREG * 64 + wave; c < nch; c += WAVES) {  // long vectors: beyond the register cache
+        const int m = (c << 6) + lane;
+        bool kp = false;
+        if (m < Z) {
+            const float v = bits_to_float(x[m], BF16);
+            kp = keep_rule(v, tau) || (v != v);
+        }
+        const unsigned long long mask = __ballot(kp);
+        if (lane == 0) masks[c] = mask;
+        mycnt += __popcll(mask);
+    }
+    if (lane == 0) wavecnt[wave] = mycnt;
+    stamp(p, 1);
+    __syncthreads();
+    stamp(p, 6);
+
+    // ---- phase B: every wave scans the chunk popcounts itself (DPP, no second barrier, no serial
+    //      wave) and scatters the (row, x) pairs of its own chunks into the LDS list, ascending ------
+    int total;
+    {
+        int t = (lane < WAVES) ? wavecnt[lane] : 0;
+        t += __builtin_amdgcn_update_dpp(0, t, 0x111, 0xf, 0xf, false);
+        t += __builtin_amdgcn_update_dpp(0, t, 0x112, 0xf, 0xf, false);
+        t += __builtin_amdgcn_update_dpp(0, t, 0x114, 0xf, 0xf, false);
+        t += __builtin_amdgcn_update_dpp(0, t, 0x118, 0xf, 0xf, false);
+        total = __builtin_amdgcn_readlane(t, 15);  // WAVES <= 16: one DPP row holds every count
+    }
     const int lo = (int)(((long long)total * slice) / p.split);
     const int hi = (int)(((long long)total * (slice + 1)) / p.split);
     const int nloc = hi - lo;
-
-    // ---- scatter this share's (row, x) pairs into the LDS list, ascending ------------------------
-    for (int c = wave; c < nch; c += WAVES) {
-        const int base = prefix[c];
-        const int next = prefix[c + 1];
-        if (next <= lo || base >= hi) continue;  // chunk entirely outside the share (wave-uniform)
-        const unsigned long long mask = masks[c];
-        const int m = (c << 6) + lane;
-        if ((mask >> lane) & 1ull) {
-            const int pos = base + lane_rank(mask);
-            if (pos >= lo && pos < hi) list[pos - lo] = ((uint32_t)m << 16) | (uint32_t)x[m];
-        }
+    stamp(p, 7);
+    {
+        int base = 0;
+        auto scatter_group = [&](const int g0, const uint32_t* xg) {
+            const int cg = g0 + lane;
+            const int v = (cg < nch) ? __popcll(masks[cg]) : 0;
+            const int incl = wave_incl_scan(v, lane);
+            const int excl = base + incl - v;
+            base += __builtin_amdgcn_readlane(incl, 63);
+#pragma unroll
+            for (int kk = 0; kk < PER; ++kk) {
+                const int j = wave + kk * WAVES;  // lane that holds an owned chunk's prefix (uniform)
+                const int c = g0 + j;
+                if (c >= nch) break;
+                const int pre = __builtin_amdgcn_readlane(excl, j);
+                const int cnt = __builtin_amdgcn_readlane(v, j);
+                if (pre + cnt <= lo || pre >= hi) continue;  // chunk outside this workgroup's share
+                const unsigned long long mask = masks[c];
+                if ((mask >> lane) & 1ull) {
+                    const int m = (c << 6) + lane;
+                    const int pos = pre + lane_rank(mask);
+                    const uint32_t xb = xg ? xg[kk] : (uint32_t)x[m];
+                    if (pos >= lo && pos < hi) list[pos - lo] = ((uint32_t)m << 16) | xb;
+                }
+            }
+        };
+#pragma unroll
+        for (int g = 0; g < GREG; ++g)
+            if (g * 64 < nch && base < hi) scatter_group(g * 64, &xr[g * PER]);
+        for (int g0 = GREG * 64; g0 < nch && base < hi; g0 += 64) scatter_group(g0, nullptr);
     }
+    stamp(p, 2);
     __syncthreads();
+    stamp(p, 3);
 
     // ---- stream the kept rows ----------------------------------------------------------------------
     const int g = lane / LPR;   // row group inside the wave
@@ -250,6 +341,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         }
     }
 
+    stamp(p, 4);
     // ---- reduce: row groups of the wave, then waves (fixed order) --------------------------------
 #pragma unroll
     for (int off = LPR; off < 64; off <<= 1) {
@@ -274,6 +366,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
             p.ws[(size_t)slice * p.ws_ld + sg.ws_off + c] = sum;
         }
     }
+    stamp(p, 5);
 }
 
 // y[n] = round(sum_s ws[s][n]) in slice order; one thread per column.
@@ -337,13 +430,13 @@ struct Config {
 
 int g_num_cu = 0;
 Config g_override = {0, 0, 0, 0};
+unsigned long long* g_phase = nullptr;
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 size_t lds_bytes(int Z, int cap, int waves, int lpr) {
     const int nch = (Z + 63) >> 6;
-    return (size_t)nch * 8 + (size_t)((nch + 2) & ~1) * 4 + (size_t)cap * 4 +
-           (size_t)waves * lpr * 8 * 4;
+    return (size_t)nch * 8 + 64 + (size_t)cap * 4 + (size_t)waves * lpr * 8 * 4;
 }
 
 int count_tiles(const Params& p, int bn) {
@@ -353,21 +446,39 @@ int count_tiles(const Params& p, int bn) {
 }
 
 // Launch geometry from (Z, columns, CU count).  Deterministic: no autotune at first call.
+// Measured on MI355X (profiles/, scripts/tune_gemv.py): the kernel wants ONE 16-wave workgroup per
+// CU (every workgroup repeats the compaction prologue, so more workgroups only add latency), and
+// a single launch (split == 1) whenever the column tiles alone can occupy >= ~2/3 of the CUs.
 Config pick_config(int Z, int ncols_total, int nseg_tiles_hint) {
     (void)nseg_tiles_hint;
     const int ncu = g_num_cu > 0 ? g_num_cu : 256;
     Config c;
-    c.lpr = 8;
-    c.waves = 8;
+    c.waves = 16;
     c.unroll = 4;
-    const int tiles = (ncols_total + c.lpr * 8 - 1) / (c.lpr * 8);
-    // aim at ~4 workgroups of 8 waves per CU, but keep >= 64 list entries per workgroup step
-    int split = (4 * ncu + tiles - 1) / tiles;
-    const int max_by_rows = Z / (2 * c.waves * (64 / c.lpr) * 2);  // >= 2 steps at 50 % kept
-    if (split > max_by_rows) split = max_by_rows;
-    if (split < 1) split = 1;
-    if (split > kMaxSplit) split = kMaxSplit;
-    c.split = split;
+    c.lpr = 0;
+    c.split = 1;
+    // widest tile whose tile count still covers most CUs -> no split-K, no second launch
+    for (int lpr = 64; lpr >= 8; lpr >>= 1) {
+        const int tiles = (ncols_total + lpr * 8 - 1) / (lpr * 8);
+        if (tiles <= ncu + ncu / 8 && tiles * 3 >= ncu * 2) { c.lpr = lpr; break; }
+    }
+    if (c.lpr == 0) {
+        const int t8 = (ncols_total + 63) / 64;
+        if (t8 > ncu) {  // more 64-column tiles than CUs: widest tile that keeps >= ncu workgroups
+            c.lpr = 8;
+            for (int lpr = 64; lpr > 8; lpr >>= 1)
+                if ((ncols_total + lpr * 8 - 1) / (lpr * 8) >= ncu) { c.lpr = lpr; break; }
+        } else {  // few columns: 512-byte row segments, split the kept rows to reach ~1 WG per CU
+            c.lpr = ncols_total >= 2048 ? 32 : 8;
+            const int tiles = (ncols_total + c.lpr * 8 - 1) / (c.lpr * 8);
+            int split = ncu / tiles;
+            const int max_by_rows = Z / (4 * c.waves * (64 / c.lpr));  // >= ~2 steps per workgroup at 50 %
+            if (split > max_by_rows) split = max_by_rows;
+            if (split < 1) split = 1;
+            if (split > kMaxSplit) split = kMaxSplit;
+            c.split = split;
+        }
+    }
     if (g_override.lpr) c.lpr = g_override.lpr;
     if (g_override.waves) c.waves = g_override.waves;
     if (g_override.split) c.split = g_override.split;
@@ -438,6 +549,7 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
     p.cap = (p.Z + c.split - 1) / c.split + 1;
     p.to_ws = to_ws ? 1 : 0;
     p.ws = reinterpret_cast<float*>(ws);
+    p.phase = g_phase;
     const size_t lds = lds_bytes(p.Z, p.cap, c.waves, c.lpr);
     if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
     if (c.split > 1 || to_ws) {
@@ -515,6 +627,11 @@ int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll) {
         !in(unroll, {0, 2, 4, 8}) || split < 0 || split > kMaxSplit)
         return TEAL_ERR_CONFIG;
     g_override = {lanes_per_row, waves, split, unroll};
+    return TEAL_OK;
+}
+
+int teal_set_phase_buffer(void* dev_u64) {
+    g_phase = reinterpret_cast<unsigned long long*>(dev_u64);
     return TEAL_OK;
 }
 
