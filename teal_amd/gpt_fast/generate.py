@@ -1,0 +1,319 @@
+#!/usr/bin/env python3
+"""Decode harness with the reference's CLI surface (gpt-fast/generate.py:528-558):
+
+    python -m teal_amd.gpt_fast.generate --checkpoint_path .../model.pth --hist_path models/Llama-2-7B/histograms \
+        --sparsity 0.5 --compile
+    python -m teal_amd.gpt_fast.generate --synthetic 7B --sparsity 0.5 --compile          (no checkpoint needed)
+
+Same flags (`--hist_path`, `--sparsity`, `--checkpoint_path`, `--compile`, `--num_samples`,
+`--max_new_tokens`, `--top_k`, `--temperature`, `--prompt`, `--profile`), same tokens/sec definition
+(generated tokens / wall time of one generate() call INCLUDING prefill, one warm-up sample then
+`num_samples` timed ones, generate.py:431-506), same seed (1234).  Differences, all MI355X-first:
+
+  * `--compile` means "capture the decode step into a hipGraph" (torch.cuda.CUDAGraph), not
+    torch.compile/Inductor/Triton: the sparse GEMVs are hand-written HIP behind torch.ops.teal.*,
+    launch geometry is fixed by shape, so there is nothing to trace or autotune.
+  * `--precision {fp16,bf16}` (reference hard-codes fp16, generate.py:386), `--greedy_lookup DIR`
+    (wires utils.get_layer_greedy_sparsities, which the reference imports but never calls),
+    `--synthetic NAME` (random weights of the named architecture + thresholds calibrated on the
+    synthetic activations, because there is no network for checkpoints here), `--engine`
+    (fused HIP decode step, teal_amd/gpt_fast/engine.py) and `--dense` (no monkeypatch: baseline).
+"""
+from __future__ import annotations
+
+import argparse
+import contextlib
+import itertools
+import json
+import os
+import sys
+import time
+from pathlib import Path
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+from teal_amd.gpt_fast.model import ModelArgs, Transformer  # noqa: E402
+from teal_amd.monkeypatch import monkeypatch_layer  # noqa: E402
+from teal_amd.utils import PROJS, get_layer_greedy_sparsities  # noqa: E402
+
+default_device = "cuda" if torch.cuda.is_available() else "cpu"
+
+
+# ------------------------------------------------------------------------------------------------
+# sampling (gpt-fast/generate.py:49-66: top-k, softmax, exponential-trick multinomial, no host sync)
+# ------------------------------------------------------------------------------------------------
+def multinomial_sample_one_no_sync(probs_sort: torch.Tensor) -> torch.Tensor:
+    q = torch.empty_like(probs_sort).exponential_(1)
+    return torch.argmax(probs_sort / q, dim=-1, keepdim=True).to(dtype=torch.int)
+
+
+def logits_to_probs(logits: torch.Tensor, temperature: float = 1.0, top_k: Optional[int] = None) -> torch.Tensor:
+    logits = logits / max(temperature, 1e-5)
+    if top_k is not None:
+        v, _ = torch.topk(logits, min(top_k, logits.size(-1)))
+        logits = torch.where(logits < v.select(-1, -1).unsqueeze(-1), -float("Inf"), logits)
+    return torch.nn.functional.softmax(logits, dim=-1)
+
+
+def sample(logits: torch.Tensor, temperature: float = 1.0, top_k: Optional[int] = None):
+    probs = logits_to_probs(logits[0, -1].float(), temperature, top_k)
+    return multinomial_sample_one_no_sync(probs), probs
+
+
+# ------------------------------------------------------------------------------------------------
+# model construction
+# ------------------------------------------------------------------------------------------------
+def build_synthetic_model(name: str, device: str, dtype: torch.dtype, seed: int = 1234, std: float = 0.02,
+                          n_layer: Optional[int] = None) -> Transformer:
+    """Random-init weights N(0, std^2) at the exact shapes of the named architecture."""
+    cfg = ModelArgs.from_name(name)
+    if n_layer is not None:
+        cfg.n_layer = n_layer
+    with torch.device("meta"):
+        model = Transformer(cfg)
+    g = torch.Generator(device=device).manual_seed(seed)
+    model = model.to_empty(device=device)
+    with torch.no_grad():
+        for pname, p in model.named_parameters():
+            if pname.endswith("norm.weight"):
+                p.data = torch.ones(p.shape, device=device, dtype=dtype)
+            else:
+                p.data = (torch.randn(p.shape, device=device, dtype=torch.float32, generator=g) * std).to(dtype)
+    return model.eval()
+
+
+def load_checkpoint_model(checkpoint_path: Path, device: str, dtype: torch.dtype) -> Transformer:
+    with torch.device("meta"):
+        model = Transformer.from_name(checkpoint_path.parent.name)
+    ckpt = torch.load(str(checkpoint_path), mmap=True, weights_only=True)
+    if "model" in ckpt and "stories" in str(checkpoint_path):
+        ckpt = ckpt["model"]
+    model.load_state_dict(ckpt, assign=True)
+    return model.to(device=device, dtype=dtype).eval()
+
+
+@torch.no_grad()
+def calibrate_thresholds(model: Transformer, sparsities: Dict[str, List[float]], n_tokens: int = 24,
+                         seed: int = 4321) -> List[Dict[str, float]]:
+    """Synthetic mode: per layer and projection, tau = the `s` quantile of |activation| observed on a
+    short dense run, so the kept fraction is 1 - s on the synthetic activations (the calibration
+    histograms only describe real checkpoints).  Activation sites as in the reference:
+    q/k/v <- attention input, o <- attention output, gate/up <- MLP input, down <- silu(g)*u."""
+    if all(float(v) <= 0 for vals in sparsities.values() for v in vals):
+        return [{p: -1.0 for p in PROJS} for _ in model.layers]
+    dev = model.output.weight.device
+    acts: List[Dict[str, List[torch.Tensor]]] = [dict(attn_in=[], attn_out=[], mlp_in=[], mlp_mid=[]) for _ in model.layers]
+    hooks = []
+    for i, layer in enumerate(model.layers):
+        hooks.append(layer.attention.register_forward_pre_hook(lambda m, a, i=i: acts[i]["attn_in"].append(a[0].detach().float().flatten())))
+        hooks.append(layer.attention.wo.register_forward_pre_hook(lambda m, a, i=i: acts[i]["attn_out"].append(a[0].detach().float().flatten())))
+        hooks.append(layer.feed_forward.register_forward_pre_hook(lambda m, a, i=i: acts[i]["mlp_in"].append(a[0].detach().float().flatten())))
+        hooks.append(layer.feed_forward.w2.register_forward_pre_hook(lambda m, a, i=i: acts[i]["mlp_mid"].append(a[0].detach().float().flatten())))
+    g = torch.Generator(device=dev).manual_seed(seed)
+    toks = torch.randint(0, model.config.vocab_size, (n_tokens,), device=dev, generator=g, dtype=torch.int)
+    model.setup_caches(max_batch_size=1, max_seq_length=max(n_tokens, 8))
+    model(toks.view(1, -1), torch.arange(n_tokens, device=dev))  # one dense prefill = n_tokens activation samples
+    for h in hooks:
+        h.remove()
+    site = {"q": "attn_in", "k": "attn_in", "v": "attn_in", "o": "attn_out", "gate": "mlp_in", "up": "mlp_in", "down": "mlp_mid"}
+    out = []
+    for i in range(len(model.layers)):
+        th = {}
+        for p in PROJS:
+            s = float(sparsities[p][i])
+            if s <= 0:
+                th[p] = -1.0  # keep everything (|x| > -1): the dense comparator on the same kernels
+                continue
+            a = torch.cat(acts[i][site[p]]).abs()
+            th[p] = float(torch.quantile(a[:: max(1, a.numel() // 200000)], s))
+        out.append(th)
+    # the caches were sized for calibration; let generate() size them again
+    model.max_seq_length = -1
+    model.max_batch_size = -1
+    return out
+
+
+def apply_sparsity(model: Transformer, *, sparsity: float, hist_path: Optional[str], greedy_lookup: Optional[str],
+                   synthetic: bool) -> List[Dict[str, float]]:
+    """monkeypatch every layer (gpt-fast/generate.py:328-331); returns the thresholds used."""
+    L = len(model.layers)
+    if greedy_lookup:
+        sparsities = get_layer_greedy_sparsities([sparsity] * L, greedy_lookup)
+    else:
+        sparsities = {p: [sparsity] * L for p in PROJS}
+    device = model.output.weight.device.type
+    if synthetic or hist_path is None:
+        ths = calibrate_thresholds(model, sparsities)
+        for i, layer in enumerate(model.layers):
+            monkeypatch_layer(i, layer, sparsity, None, device, thresholds=ths[i])
+    else:
+        ths = [monkeypatch_layer(i, layer, sparsity, hist_path, device, sparsities=sparsities)
+               for i, layer in enumerate(model.layers)]
+    return ths
+
+
+def _get_model_size(model) -> int:
+    size = 0
+    for _, child in model.named_children():
+        if not isinstance(child, torch.nn.Embedding):
+            size += sum(p.numel() * p.dtype.itemsize for p in itertools.chain(child.parameters(), child.buffers()))
+    return size
+
+
+# ------------------------------------------------------------------------------------------------
+# decode step + hipGraph capture
+# ------------------------------------------------------------------------------------------------
+class GraphedDecoder:
+    """decode_one_token (gpt-fast/generate.py:73-77) with static buffers, captured once into a hipGraph
+    (the reference gets the same effect from torch.compile(mode="reduce-overhead"), generate.py:420)."""
+
+    def __init__(self, model: Transformer, use_graph: bool, temperature: float, top_k: Optional[int]):
+        self.model, self.use_graph = model, use_graph
+        self.kw = dict(temperature=temperature, top_k=top_k)
+        dev = model.output.weight.device
+        self.tok = torch.zeros(1, 1, dtype=torch.int, device=dev)
+        self.pos = torch.zeros(1, dtype=torch.int, device=dev)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.out_tok = None
+
+    def _step(self):
+        logits = self.model(self.tok, self.pos)
+        return sample(logits, **self.kw)[0]
+
+    def capture(self):
+        if not self.use_graph or self.graph is not None:
+            return
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):  # warm-up outside capture: workspace + allocator pools
+            for _ in range(2):
+                self._step()
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out_tok = self._step()
+
+    def __call__(self, cur_token: torch.Tensor, input_pos: torch.Tensor) -> torch.Tensor:
+        self.tok.copy_(cur_token.view(1, 1))
+        self.pos.copy_(input_pos)
+        if self.graph is not None:
+            self.graph.replay()
+            return self.out_tok
+        return self._step()
+
+
+@torch.no_grad()
+def generate(model: Transformer, prompt: torch.Tensor, max_new_tokens: int, decoder: GraphedDecoder,
+             temperature: float = 0.8, top_k: Optional[int] = 200) -> torch.Tensor:
+    """prefill (seq > 1: ops fall back to dense matmul) then max_new_tokens-1 decode steps."""
+    T = prompt.size(0)
+    T_new = T + max_new_tokens
+    dev = prompt.device
+    model.setup_caches(max_batch_size=1, max_seq_length=min(T_new, model.config.block_size))
+    seq = torch.empty(T_new, dtype=prompt.dtype, device=dev)
+    seq[:T] = prompt
+    logits = model(prompt.view(1, -1), torch.arange(0, T, device=dev))
+    next_token = sample(logits, temperature=temperature, top_k=top_k)[0].clone()
+    seq[T] = next_token
+    decoder.capture()
+    input_pos = torch.tensor([T], device=dev, dtype=torch.int)
+    cur = next_token.view(1, -1)
+    for i in range(max_new_tokens - 1):
+        nxt = decoder(cur, input_pos)
+        input_pos += 1
+        seq[T + 1 + i] = nxt.view(())
+        cur = nxt.view(1, -1)
+    return seq
+
+
+# ------------------------------------------------------------------------------------------------
+def main(args) -> Dict:
+    device = args.device
+    assert "cuda" in device, "the sparse decode path is GPU-only (HIP kernels, no CPU fallback)"
+    dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[args.precision]
+    from teal_amd import runtime
+    runtime.init()
+    t0 = time.time()
+    if args.synthetic:
+        model = build_synthetic_model(args.synthetic, device, dtype, n_layer=args.n_layer)
+        prompt = torch.randint(0, model.config.vocab_size, (6,), device=device, dtype=torch.int,
+                               generator=torch.Generator(device=device).manual_seed(7))  # "Hello, my name is" + BOS = 6 ids
+        tokenizer = None
+    else:
+        assert args.checkpoint_path.is_file(), args.checkpoint_path
+        model = load_checkpoint_model(args.checkpoint_path, device, dtype)
+        from teal_amd.gpt_fast.tokenizer import get_tokenizer
+        tokenizer = get_tokenizer(args.checkpoint_path.parent / "tokenizer.model", args.checkpoint_path)
+        prompt = torch.tensor([tokenizer.bos_id()] + tokenizer.encode(args.prompt), dtype=torch.int, device=device)
+    thresholds = None
+    if not args.dense and (args.hist_path is not None or args.synthetic):
+        # like the reference, patching is gated on hist_path, not on sparsity (generate.py:328)
+        print("Monkeypatching with activation sparsity...")
+        thresholds = apply_sparsity(model, sparsity=args.sparsity, hist_path=args.hist_path,
+                                    greedy_lookup=args.greedy_lookup, synthetic=bool(args.synthetic))
+    torch.cuda.synchronize()
+    print(f"Time to load model: {time.time() - t0:.02f} seconds")
+    torch.manual_seed(1234)
+    model_size = _get_model_size(model)
+    decoder = GraphedDecoder(model, args.compile, args.temperature, args.top_k)
+    tps = []
+    start = -1 if args.compile else 0
+    for i in range(start, args.num_samples):
+        torch.cuda.synchronize()
+        prof = contextlib.nullcontext()
+        if args.profile and i == args.num_samples - 1:
+            prof = torch.profiler.profile()
+        t0 = time.perf_counter()
+        with prof:
+            y = generate(model, prompt, args.max_new_tokens, decoder, temperature=args.temperature, top_k=args.top_k)
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t0
+        if i == -1:
+            print(f"Graph capture + warm-up time: {t:.2f} seconds")
+            continue
+        if hasattr(prof, "export_chrome_trace"):
+            prof.export_chrome_trace(f"{args.profile}.json")
+        n_gen = y.size(0) - prompt.size(0)
+        tps.append(n_gen / t)
+        if tokenizer is not None:
+            print(tokenizer.decode(y.tolist()))
+        print(f"Time for inference {i + 1}: {t:.02f} sec total, {tps[-1]:.02f} tokens/sec")
+        print(f"Bandwidth achieved: {model_size * tps[-1] / 1e9:.02f} GB/s (dense parameter bytes x tok/s, as the reference reports)")
+    print("==========")
+    mean = sum(tps) / max(1, len(tps))
+    print(f"Average tokens/sec: {mean:.2f}")
+    print(f"Memory used: {torch.cuda.max_memory_reserved() / 1e9:.02f} GB")
+    return {"tokens_per_sec": tps, "mean_tokens_per_sec": mean, "thresholds": thresholds}
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="TEAL decode harness (MI355X / HIP)")
+    p.add_argument("--prompt", type=str, default="Hello, my name is")
+    p.add_argument("--num_samples", type=int, default=5)
+    p.add_argument("--max_new_tokens", type=int, default=200)
+    p.add_argument("--top_k", type=int, default=200)
+    p.add_argument("--temperature", type=float, default=0.8)
+    p.add_argument("--checkpoint_path", type=Path, default=Path("checkpoints/meta-llama/Llama-2-7b-chat-hf/model.pth"))
+    p.add_argument("--compile", action="store_true", help="capture the decode step into a hipGraph")
+    p.add_argument("--profile", type=Path, default=None)
+    p.add_argument("--device", type=str, default=default_device)
+    # monkeypatch (reference flags)
+    p.add_argument("--hist_path", type=str, default=None)
+    p.add_argument("--sparsity", type=float, default=0.0)
+    # extensions
+    p.add_argument("--precision", choices=["fp16", "bf16"], default="fp16")
+    p.add_argument("--greedy_lookup", type=str, default=None, help="models/<name>/lookup directory (block-wise greedy sparsities)")
+    p.add_argument("--synthetic", type=str, default=None, help="architecture name, e.g. 7B, llama-3-8b, 70B")
+    p.add_argument("--n_layer", type=int, default=None, help="override the layer count (synthetic smoke runs)")
+    p.add_argument("--dense", action="store_true", help="do not monkeypatch: dense baseline")
+    return p
+
+
+if __name__ == "__main__":
+    res = main(build_parser().parse_args())
+    print(json.dumps({"mean_tokens_per_sec": res["mean_tokens_per_sec"]}))

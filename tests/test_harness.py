@@ -1,0 +1,130 @@
+"""Decode harness: CPU checks of the model/generate plumbing (dense path only — the sparse ops are
+GPU-only) and GPU checks of the monkeypatched model under hipGraph capture."""
+import numpy as np
+import pytest
+import torch
+
+from teal_amd.gpt_fast import generate as G
+from teal_amd.gpt_fast.model import ModelArgs, Transformer, apply_rotary_emb, precompute_freqs_cis
+
+
+def tiny(device, dtype=torch.float32):
+    return G.build_synthetic_model("tiny-test", device, dtype, seed=3, std=0.05)
+
+
+def test_model_args_fuzzy_match_and_shapes():
+    a = ModelArgs.from_name("Llama-2-7b-chat-hf")
+    assert (a.n_layer, a.dim, a.intermediate_size, a.n_local_heads) == (32, 4096, 11008, 32)
+    b = ModelArgs.from_name("Meta-Llama-3-8B")
+    assert (b.intermediate_size, b.n_local_heads, b.vocab_size, b.rope_base) == (14336, 8, 128256, 500000)
+    c = ModelArgs.from_name("llama-2-70B")
+    assert (c.n_layer, c.dim, c.intermediate_size, c.n_local_heads) == (80, 8192, 28672, 8)
+    assert ModelArgs.from_name("Mistral-7B-v0.1").n_local_heads == 8  # longest match beats "7B"
+
+
+def test_rope_is_a_rotation_and_position_zero_is_identity():
+    fc = precompute_freqs_cis(16, 8, 10000, torch.float32)
+    x = torch.randn(1, 16, 2, 8)
+    y = apply_rotary_emb(x, fc)
+    assert torch.allclose(y[:, 0], x[:, 0], atol=1e-6)
+    assert torch.allclose(y.norm(dim=-1), x.norm(dim=-1), atol=1e-5)
+
+
+def test_decode_matches_prefill_cpu_dense():
+    """KV-cache decode of token t equals the t-th position of a full prefill."""
+    m = tiny("cpu")
+    m.setup_caches(1, 16)
+    toks = torch.randint(0, 512, (8,), dtype=torch.int)
+    with torch.no_grad():
+        full = m(toks.view(1, -1), torch.arange(8))
+        m2 = tiny("cpu")
+        m2.setup_caches(1, 16)
+        m2(toks[:5].view(1, -1), torch.arange(5))
+        outs = [m2(toks[i].view(1, 1), torch.tensor([i])) for i in range(5, 8)]
+    for j, o in enumerate(outs):
+        assert torch.allclose(o[0, 0], full[0, 5 + j], atol=2e-4, rtol=1e-3)
+
+
+def test_generate_cpu_dense_is_deterministic_under_seed():
+    m = tiny("cpu")
+    prompt = torch.randint(0, 512, (6,), dtype=torch.int)
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(1234)
+        dec = G.GraphedDecoder(m, False, 0.8, 50)
+        outs.append(G.generate(m, prompt, 12, dec, temperature=0.8, top_k=50))
+        m.max_seq_length = -1
+    assert torch.equal(outs[0], outs[1]) and outs[0].numel() == 18 and torch.equal(outs[0][:6], prompt)
+
+
+def test_calibration_hits_target_kept_fraction_cpu():
+    m = tiny("cpu")
+    L = len(m.layers)
+    sp = {p: [0.5] * L for p in G.PROJS}
+    ths = G.calibrate_thresholds(m, sp, n_tokens=64)
+    assert len(ths) == L and all(t["q"] == t["k"] == t["v"] > 0 and t["gate"] == t["up"] > 0 for t in ths)
+    assert G.calibrate_thresholds(m, {p: [0.0] * L for p in G.PROJS})[0]["down"] == -1.0
+    # on fresh tokens the kept fraction of the MLP input is ~50 %
+    acts = []
+    h = m.layers[1].feed_forward.register_forward_pre_hook(lambda mod, a: acts.append(a[0].flatten()))
+    m.setup_caches(1, 64)
+    with torch.no_grad():
+        m(torch.randint(0, 512, (64,), dtype=torch.int).view(1, -1), torch.arange(64))
+    h.remove()
+    kept = (torch.cat(acts).abs() > ths[1]["gate"]).float().mean()
+    assert 0.4 < float(kept) < 0.6
+
+
+def test_cli_flags_match_reference_surface():
+    p = G.build_parser()
+    a = p.parse_args(["--hist_path", "H", "--sparsity", "0.5", "--compile", "--num_samples", "2", "--max_new_tokens", "10"])
+    assert a.hist_path == "H" and a.sparsity == 0.5 and a.compile and a.max_new_tokens == 10
+    d = p.parse_args([])
+    assert d.max_new_tokens == 200 and d.num_samples == 5 and d.top_k == 200 and d.temperature == 0.8 and d.sparsity == 0.0
+
+
+# --------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_monkeypatched_model_matches_dense_when_everything_is_kept():
+    dev = "cuda"
+    m = tiny(dev, torch.float16)
+    ref = tiny(dev, torch.float16)
+    G.apply_sparsity(m, sparsity=0.0, hist_path=None, greedy_lookup=None, synthetic=True)  # tau = -1: dense on the HIP kernels
+    toks = torch.randint(0, 512, (6,), device=dev, dtype=torch.int)
+    for mod in (m, ref):
+        mod.setup_caches(1, 32)
+    with torch.no_grad():
+        a = m(toks.view(1, -1), torch.arange(6, device=dev))       # prefill: ops fall back to matmul
+        b = ref(toks.view(1, -1), torch.arange(6, device=dev))
+        assert torch.allclose(a, b, atol=2e-3, rtol=2e-2)
+        t = torch.tensor([[7]], device=dev, dtype=torch.int)
+        a1 = m(t, torch.tensor([6], device=dev))                    # decode: HIP sparse GEMV path
+        b1 = ref(t, torch.tensor([6], device=dev))
+        assert torch.allclose(a1.float(), b1.float(), atol=4e-3, rtol=3e-2)
+
+
+@pytest.mark.gpu
+def test_sparse_decode_graph_replay_equals_eager():
+    dev = "cuda"
+    prompt = torch.randint(0, 512, (6,), device=dev, dtype=torch.int)
+    seqs = []
+    for use_graph in (False, True):
+        m = tiny(dev, torch.float16)
+        G.apply_sparsity(m, sparsity=0.5, hist_path=None, greedy_lookup=None, synthetic=True)
+        torch.manual_seed(1234)
+        dec = G.GraphedDecoder(m, use_graph, 0.0, None)  # temperature ~0: argmax, no RNG dependence
+        with torch.no_grad():
+            seqs.append(G.generate(m, prompt, 10, dec, temperature=0.0, top_k=None))
+    assert torch.equal(seqs[0], seqs[1])
+
+
+@pytest.mark.gpu
+def test_sparse_thresholds_reduce_rows_read():
+    """kept fraction on the decode activations is near the calibrated target."""
+    import teal_amd.kernels as K
+    dev = "cuda"
+    m = tiny(dev, torch.float16)
+    ths = G.apply_sparsity(m, sparsity=0.5, hist_path=None, greedy_lookup=None, synthetic=True)
+    x = torch.randn(1, 1, 256, device=dev, dtype=torch.float16) * 0.05
+    _, n = K.compact(x, ths[0]["q"])
+    assert 0 <= n <= 256
