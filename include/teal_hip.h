@@ -97,6 +97,51 @@ int teal_sparse_gateup_silu(const void* x, const void* w1T, const void* w3T, voi
                             float tau_up, int Z, int N, int dtype, void* ws, size_t ws_bytes,
                             void* stream);
 
+/* ---- fused decode step: producers/consumers folded into the GEMV launch - */
+
+#define TEAL_IN_PLAIN 0      /* x given as is */
+#define TEAL_IN_RESID_NORM 1 /* x = RMSNorm(resid + round(sum slabs)) * w   (model.py:158-161, 289-291) */
+#define TEAL_IN_SILU_MUL 2   /* x = silu(gate) * up, gate|up contiguous [2Z] (model.py:258-259) */
+#define TEAL_OUT_ROUNDED 0   /* y rounded to dtype (runs the ordered slab reduce when split-K is used) */
+#define TEAL_OUT_SLABS 1     /* leave the fp32 split-K slabs for the next launch's RESID_NORM producer */
+
+typedef struct teal_gemv_in {
+    int mode;                 /* TEAL_IN_* */
+    const void* x;            /* PLAIN: [Z];  SILU_MUL: gate[Z] followed by up[Z] */
+    const void* resid_in;     /* RESID_NORM: residual stream [Z] (or a [rows][Z] table with row_index) */
+    const int32_t* row_index; /* RESID_NORM, optional: device int32; row = row_index[0] (embedding lookup) */
+    const float* slabs;       /* RESID_NORM, optional: fp32 [nslabs][Z] partial sums folded into the residual */
+    int nslabs;
+    const void* norm_weight;  /* RESID_NORM: RMSNorm weight [Z] */
+    float eps;
+    void* resid_out;          /* RESID_NORM, optional: updated residual [Z]; must not alias resid_in */
+} teal_gemv_in_t;
+
+typedef struct teal_gemv_out {
+    int nseg;            /* 1..3 column segments, each with its own threshold (q|k|v, gate|up, ...) */
+    const void* w[3];    /* weight image of the segment: row-major [Z][ld] */
+    int ld[3];           /* row stride (elements) */
+    int col0[3];         /* first column of the segment inside a row */
+    int ncols[3];        /* columns in the segment */
+    float tau[3];        /* keep threshold of the segment */
+    void* y[3];          /* ROUNDED: output of the segment [ncols] */
+    int mode;            /* TEAL_OUT_* */
+    float* slabs;        /* SLABS: destination, fp32 [nslabs][sum ncols] */
+    size_t slabs_bytes;
+} teal_gemv_out_t;
+
+/* One launch: [fused producer] -> mask + compaction -> gathered GEMV over every segment.
+ * *nslabs_out receives the split-K factor used (the number of slabs written in SLABS mode). */
+int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z, int dtype, void* ws,
+                    size_t ws_bytes, int* nslabs_out, void* stream);
+
+/* Single-token attention between gemv1 and gemv2 (gpt-fast/model.py:170-186): RoPE(q, k_new) with the
+ * (cos, sin) table rope[max_pos][head_dim/2][2], KV-cache append at *pos, softmax(q K^T / sqrt(d)) V.
+ * qkv = [q | k | v] as produced by the fused wqkv GEMV; caches are [n_kv_head][max_seq][head_dim];
+ * y = [n_head * head_dim].  head_dim 64 or 128. */
+int teal_decode_attention(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,
+                          void* y, int n_head, int n_kv_head, int head_dim, int max_seq, int dtype, void* stream);
+
 /* ---- tuning / introspection ------------------------------------------------------------------ */
 
 /* Override the launch geometry picked from (Z, N, CU count): lanes per row segment (8/16/32/64),

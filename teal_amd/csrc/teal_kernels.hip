@@ -25,6 +25,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "teal_hip.h"
 
 namespace {
@@ -46,7 +48,20 @@ struct Seg {
     int ws_off;  // column offset of the segment inside a workspace slab
 };
 
+// fused activation producers: what the workgroup computes before the mask
+struct InSpec {
+    int mode;                  // 0 plain x; 1 residual + slabs -> RMSNorm; 2 silu(gate) * up
+    int nslabs;                // mode 1: fp32 slabs to fold into the residual
+    const void* resid_in;      // mode 1: residual stream [Z] (or a table when row_index is set)
+    const int* row_index;      // mode 1: optional device int: resid_in += row_index[0] * Z
+    const float* slabs;        // mode 1: [nslabs][Z]
+    const void* norm_w;        // mode 1: RMSNorm weight [Z]
+    void* resid_out;           // mode 1: updated residual, written by workgroup 0
+    float eps;
+};
+
 struct Params {
+    InSpec in;
     const void* x;
     float* ws;  // [split][ws_ld] fp32 partial slabs
     int Z;
@@ -157,6 +172,22 @@ __device__ __forceinline__ int wave_incl_scan(int v, const int lane) {
     return v + (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0);
 }
 
+// sum of a float over the 64 lanes of a wave (result valid in every lane)
+__device__ __forceinline__ float wave_sum_f(float v) {
+    auto shr = [](float a, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    v += shr(v, std::integral_constant<int, 0x111>{});
+    v += shr(v, std::integral_constant<int, 0x112>{});
+    v += shr(v, std::integral_constant<int, 0x114>{});
+    v += shr(v, std::integral_constant<int, 0x118>{});
+    const int iv = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 15)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 31)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 47)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 63));
+}
+
 // optional per-workgroup phase timestamps (constant 100 MHz clock, comparable across CUs)
 __device__ __forceinline__ void stamp(const Params& p, int phase) {
     if (p.phase && threadIdx.x == 0) p.phase[(size_t)blockIdx.x * 8 + phase] = wall_clock64();
@@ -170,7 +201,7 @@ __device__ __forceinline__ int lane_rank(unsigned long long mask) {
 // ------------------------------------------------------------------------------------------------
 // The sparse GEMV.  grid = ntiles * split workgroups of WAVES*64 threads.
 // ------------------------------------------------------------------------------------------------
-template <int LPR, int WAVES, int U, bool BF16>
+template <int LPR, int WAVES, int U, bool BF16, int MODE>
 __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p) {
     constexpr int RPW = 64 / LPR;  // rows a wave touches per load instruction
     constexpr int BN = LPR * 8;    // columns per tile (16 B per lane)
@@ -182,7 +213,8 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
     const int nch = (Z + 63) >> 6;
     unsigned long long* masks = reinterpret_cast<unsigned long long*>(smem);
     int* wavecnt = reinterpret_cast<int*>(masks + nch);
-    uint32_t* list = reinterpret_cast<uint32_t*>(wavecnt + 16);
+    float* sumsq = reinterpret_cast<float*>(wavecnt + 16);
+    uint32_t* list = reinterpret_cast<uint32_t*>(sumsq + 16);
     float* red = reinterpret_cast<float*>(list + p.cap);
 
     const int tid = threadIdx.x;
@@ -209,10 +241,67 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
     constexpr int KR = GREG * PER;                // register-cached chunks per wave (Z <= 4096..16384)
     const float tau = sg.tau;
     uint32_t xr[KR];
+    // activation of element m after the fused producer (modes 0 and 2 are element-wise)
+    auto load_act = [&](const int m) -> uint32_t {
+        if constexpr (MODE == 2) {
+            // silu(gate) * up with the roundings of the unfused fp16/bf16 sequence (model.py:258-259)
+            const float gt = bits_to_float(x[m], BF16);
+            const float up = bits_to_float(x[Z + m], BF16);
+            const float sl = bits_to_float(float_to_bits<BF16>(gt / (1.0f + expf(-gt))), BF16);
+            return float_to_bits<BF16>(sl * up);
+        } else {
+            return (uint32_t)x[m];
+        }
+    };
+    if constexpr (MODE == 1) {
+        // h = resid + round(sum of split-K slabs);  x = round(round(h * rsqrt(mean(h^2) + eps)) * w)
+        // (gpt-fast/model.py:158-161 residual adds, :289-291 RMSNorm) — every workgroup recomputes
+        // it from L2-resident inputs; workgroup 0 stores the new residual stream.
+        const uint16_t* resid = reinterpret_cast<const uint16_t*>(p.in.resid_in);
+        if (p.in.row_index) resid += (size_t)p.in.row_index[0] * Z;
+        const uint16_t* nw = reinterpret_cast<const uint16_t*>(p.in.norm_w);
+        float rv[KR];
+        float ss = 0.0f;
 #pragma unroll
-    for (int k = 0; k < KR; ++k) {
-        const int m = (((k / PER) * 64 + wave + (k % PER) * WAVES) << 6) + lane;
-        xr[k] = (m < Z) ? (uint32_t)x[m] : 0u;
+        for (int k = 0; k < KR; ++k) {
+            const int m = (((k / PER) * 64 + wave + (k % PER) * WAVES) << 6) + lane;
+            float r = 0.0f;
+            if (m < Z) {
+                r = bits_to_float(resid[m], BF16);
+                if (p.in.nslabs > 0) {
+                    float sacc = 0.0f;
+                    for (int q = 0; q < p.in.nslabs; ++q) sacc += p.in.slabs[(size_t)q * Z + m];
+                    const float yv = bits_to_float(float_to_bits<BF16>(sacc), BF16);
+                    r = bits_to_float(float_to_bits<BF16>(r + yv), BF16);
+                }
+            }
+            rv[k] = r;
+            ss += r * r;
+        }
+        ss = wave_sum_f(ss);
+        if (lane == 0) sumsq[wave] = ss;
+        __syncthreads();
+        float tot = (lane < WAVES) ? sumsq[lane] : 0.0f;
+        tot = wave_sum_f(tot);
+        const float rstd = rsqrtf(tot / (float)Z + p.in.eps);
+        uint16_t* rout = reinterpret_cast<uint16_t*>(p.in.resid_out);
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const int m = (((k / PER) * 64 + wave + (k % PER) * WAVES) << 6) + lane;
+            uint32_t xb = 0u;
+            if (m < Z) {
+                const float xn = bits_to_float(float_to_bits<BF16>(rv[k] * rstd), BF16);
+                xb = float_to_bits<BF16>(xn * bits_to_float(nw[m], BF16));
+                if (rout && blockIdx.x == 0) rout[m] = float_to_bits<BF16>(rv[k]);
+            }
+            xr[k] = xb;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const int m = (((k / PER) * 64 + wave + (k % PER) * WAVES) << 6) + lane;
+            xr[k] = (m < Z) ? load_act(m) : 0u;
+        }
     }
     int mycnt = 0;
 #pragma unroll
@@ -231,7 +320,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         const int m = (c << 6) + lane;
         bool kp = false;
         if (m < Z) {
-            const float v = bits_to_float(x[m], BF16);
+            const float v = bits_to_float(load_act(m), BF16);
             kp = keep_rule(v, tau) || (v != v);
         }
         const unsigned long long mask = __ballot(kp);
@@ -278,7 +367,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
                 if ((mask >> lane) & 1ull) {
                     const int m = (c << 6) + lane;
                     const int pos = pre + lane_rank(mask);
-                    const uint32_t xb = xg ? xg[kk] : (uint32_t)x[m];
+                    const uint32_t xb = xg ? xg[kk] : load_act(m);
                     if (pos >= lo && pos < hi) list[pos - lo] = ((uint32_t)m << 16) | xb;
                 }
             }
@@ -422,6 +511,109 @@ __global__ __launch_bounds__(1024) void compact_kernel(const uint16_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// Single-token attention over a static KV cache (the step between gemv1 and gemv2 of
+// gpt-fast/model.py:163-190): RoPE on q and the new k, KV-cache append, softmax(q K^T / sqrt(d)) V.
+// One workgroup (256 threads) per query head; GQA by head group.  Rounding points follow the
+// reference's fp16/bf16 tensors: rotated q/k, scores, probabilities and the output are rounded to
+// dtype; accumulation is fp32.
+// ------------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(256) void decode_attention_kernel(
+    const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ rope, const int* __restrict__ pos_ptr,
+    uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache, uint16_t* __restrict__ y,
+    const int n_head, const int n_kv, const int hd, const int max_seq, const float scale) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* qs = reinterpret_cast<float*>(smem);  // [hd] rotated q
+    float* kn = qs + hd;                         // [hd] rotated new k
+    float* vn = kn + hd;                         // [hd] new v
+    float* red = vn + hd;                        // [8] block reductions
+    float* part = red + 8;                       // [4][hd] partial outputs
+    float* sc = part + 4 * hd;                   // [max_seq] scores / probabilities
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x;
+    const int rep = n_head / n_kv;
+    const int kvh = h / rep;
+    const int pos = pos_ptr[0];
+    const int dim = n_head * hd, kvs = n_kv * hd;
+    const uint16_t* qh = qkv + (size_t)h * hd;
+    const uint16_t* kh = qkv + dim + (size_t)kvh * hd;
+    const uint16_t* vh = qkv + dim + kvs + (size_t)kvh * hd;
+    uint16_t* kc = k_cache + (size_t)kvh * max_seq * hd;
+    uint16_t* vc = v_cache + (size_t)kvh * max_seq * hd;
+
+    // RoPE on interleaved pairs (model.py apply_rotary_emb), table rows are (cos, sin) in dtype
+    if (tid < hd / 2) {
+        const float c = bits_to_float(rope[((size_t)pos * (hd / 2) + tid) * 2], BF16);
+        const float sn = bits_to_float(rope[((size_t)pos * (hd / 2) + tid) * 2 + 1], BF16);
+        const float q0 = bits_to_float(qh[2 * tid], BF16), q1 = bits_to_float(qh[2 * tid + 1], BF16);
+        const float k0 = bits_to_float(kh[2 * tid], BF16), k1 = bits_to_float(kh[2 * tid + 1], BF16);
+        const uint16_t qa = float_to_bits<BF16>(q0 * c - q1 * sn), qb = float_to_bits<BF16>(q1 * c + q0 * sn);
+        const uint16_t ka = float_to_bits<BF16>(k0 * c - k1 * sn), kb = float_to_bits<BF16>(k1 * c + k0 * sn);
+        qs[2 * tid] = bits_to_float(qa, BF16);
+        qs[2 * tid + 1] = bits_to_float(qb, BF16);
+        kn[2 * tid] = bits_to_float(ka, BF16);
+        kn[2 * tid + 1] = bits_to_float(kb, BF16);
+        if (h % rep == 0) {  // one writer per KV head
+            kc[(size_t)pos * hd + 2 * tid] = ka;
+            kc[(size_t)pos * hd + 2 * tid + 1] = kb;
+        }
+    } else if (tid >= 128 && tid < 128 + hd) {
+        const int d = tid - 128;
+        const uint16_t vb = vh[d];
+        vn[d] = bits_to_float(vb, BF16);
+        if (h % rep == 0) vc[(size_t)pos * hd + d] = vb;
+    }
+    __syncthreads();
+
+    // scores: one wave per cached position, lanes across the head dimension
+    const int epl = hd / 64;  // elements per lane (hd = 64 or 128)
+    float lmax = -INFINITY;
+    for (int t = wave; t <= pos; t += 4) {
+        float a = 0.0f;
+        if (t == pos) {
+            for (int e = 0; e < epl; ++e) a += qs[lane * epl + e] * kn[lane * epl + e];
+        } else {
+            const uint16_t* kr = kc + (size_t)t * hd + lane * epl;
+            for (int e = 0; e < epl; ++e) a += qs[lane * epl + e] * bits_to_float(kr[e], BF16);
+        }
+        a = wave_sum_f(a);
+        const float sv = bits_to_float(float_to_bits<BF16>(a * scale), BF16);
+        if (lane == 0) sc[t] = sv;
+        lmax = fmaxf(lmax, sv);
+    }
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float lsum = 0.0f;
+    for (int t = tid; t <= pos; t += 256) {
+        const float e = expf(sc[t] - mx);
+        sc[t] = e;
+        lsum += e;
+    }
+    lsum = wave_sum_f(lsum);
+    if (lane == 0) red[4 + wave] = lsum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+
+    // output: thread (grp, d) sums positions t = grp, grp + G, ... ; G = 256 / hd groups
+    const int G = 256 / hd;
+    const int d = tid % hd, grp = tid / hd;
+    float o = 0.0f;
+    for (int t = grp; t <= pos; t += G) {
+        const float pr = bits_to_float(float_to_bits<BF16>(sc[t] * inv), BF16);
+        const float vv = (t == pos) ? vn[d] : bits_to_float(vc[(size_t)t * hd + d], BF16);
+        o += pr * vv;
+    }
+    part[grp * hd + d] = o;
+    __syncthreads();
+    if (tid < hd) {
+        float acc = 0.0f;
+        for (int gq = 0; gq < G; ++gq) acc += part[gq * hd + tid];
+        y[(size_t)h * hd + tid] = float_to_bits<BF16>(acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 struct Config {
@@ -436,7 +628,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 size_t lds_bytes(int Z, int cap, int waves, int lpr) {
     const int nch = (Z + 63) >> 6;
-    return (size_t)nch * 8 + 64 + (size_t)cap * 4 + (size_t)waves * lpr * 8 * 4;
+    return (size_t)nch * 8 + 128 + (size_t)cap * 4 + (size_t)waves * lpr * 8 * 4;
 }
 
 int count_tiles(const Params& p, int bn) {
@@ -488,14 +680,24 @@ Config pick_config(int Z, int ncols_total, int nseg_tiles_hint) {
     return c;
 }
 
-template <int LPR, int WAVES, int U>
-hipError_t launch_gemv_t(const Params& p, int dtype, size_t lds, hipStream_t st) {
+template <int LPR, int WAVES, int U, int MODE>
+hipError_t launch_gemv_m(const Params& p, int dtype, size_t lds, hipStream_t st) {
     const dim3 grid(p.ntiles * p.split), block(WAVES * 64);
     if (dtype == TEAL_BF16)
-        hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, true>), grid, block, lds, st, p);
+        hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, true, MODE>), grid, block, lds, st, p);
     else
-        hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, false>), grid, block, lds, st, p);
+        hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, false, MODE>), grid, block, lds, st, p);
     return hipGetLastError();
+}
+
+template <int LPR, int WAVES, int U>
+hipError_t launch_gemv_t(const Params& p, int dtype, size_t lds, hipStream_t st) {
+    if (p.in.mode == 0) return launch_gemv_m<LPR, WAVES, U, 0>(p, dtype, lds, st);
+    if constexpr (WAVES == 16 && U != 2) {  // fused producers are built for the production geometry only
+        if (p.in.mode == 1) return launch_gemv_m<LPR, WAVES, U, 1>(p, dtype, lds, st);
+        if (p.in.mode == 2) return launch_gemv_m<LPR, WAVES, U, 2>(p, dtype, lds, st);
+    }
+    return hipErrorInvalidValue;
 }
 
 template <int LPR, int WAVES>
@@ -531,10 +733,27 @@ hipError_t launch_gemv(const Params& p, int dtype, size_t lds, const Config& c, 
 // Common driver: fills geometry fields of `p` (segments' w/y/tau/ld/col0/ncols are set by the
 // caller), launches the GEMV and, if needed, the ordered slab reduce.
 int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStream_t st,
-             Config* used) {
+             Config* used, bool few_slabs = false) {
     int total_cols = 0;
     for (int i = 0; i < p.nseg; ++i) total_cols += p.seg[i].ncols;
     Config c = pick_config(p.Z, total_cols, p.nseg);
+    if (few_slabs && c.split > 1 && !g_override.split && !g_override.lpr) {
+        // the consumer re-reads every slab in each of its workgroups: prefer narrow tiles and a
+        // shallow split (64-column tiles, <= 8 slabs) over 512-byte row segments
+        const int ncu = g_num_cu > 0 ? g_num_cu : 256;
+        c.lpr = 8;
+        const int tiles = (total_cols + 63) / 64;
+        int split = ncu / tiles;
+        if (split > 8) split = 8;
+        if (split < 1) split = 1;
+        c.split = split;
+        while ((size_t)((p.Z + c.split - 1) / c.split) * 4 > 40 * 1024 && c.split < kMaxSplit) ++c.split;
+    }
+    if (p.in.mode != 0) {  // fused producers exist for 16-wave workgroups, unroll 4/8
+        c.waves = 16;
+        if (c.unroll == 2) c.unroll = 4;
+        if (p.in.mode == 1 && p.Z > 16 * 64 * 16) return TEAL_ERR_SHAPE;  // register-resident norm
+    }
     const int bn = c.lpr * 8;
     int t = 0, off = 0;
     for (int i = 0; i < p.nseg; ++i) {
@@ -722,6 +941,85 @@ int teal_sparse_gateup_silu(const void* x, const void* w1T, const void* w3T, voi
         hipLaunchKernelGGL((gateup_silu_epilogue_kernel<true>), grid, block, 0, st, p, h);
     else
         hipLaunchKernelGGL((gateup_silu_epilogue_kernel<false>), grid, block, 0, st, p, h);
+    return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
+}
+
+int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z, int dtype, void* ws,
+                    size_t ws_bytes, int* nslabs_out, void* stream) {
+    if (!in || !out || Z <= 0 || out->nseg < 1 || out->nseg > kMaxSeg) return TEAL_ERR_ARG;
+    if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
+    if (Z > 65536) return TEAL_ERR_SHAPE;
+    if (g_num_cu <= 0 && teal_init() <= 0) return TEAL_ERR_NO_DEVICE;
+    Params p = {};
+    p.Z = Z;
+    p.in.mode = in->mode;
+    switch (in->mode) {
+        case TEAL_IN_PLAIN:
+        case TEAL_IN_SILU_MUL:
+            if (!in->x) return TEAL_ERR_ARG;
+            p.x = in->x;
+            break;
+        case TEAL_IN_RESID_NORM:
+            if (!in->resid_in || !in->norm_weight || in->nslabs < 0 || (in->nslabs > 0 && !in->slabs)) return TEAL_ERR_ARG;
+            if (in->resid_out == in->resid_in && !in->row_index) return TEAL_ERR_ARG;  // must ping-pong
+            p.x = in->resid_in;
+            p.in.resid_in = in->resid_in;
+            p.in.row_index = in->row_index;
+            p.in.slabs = in->slabs;
+            p.in.nslabs = in->nslabs;
+            p.in.norm_w = in->norm_weight;
+            p.in.resid_out = in->resid_out;
+            p.in.eps = in->eps;
+            break;
+        default: return TEAL_ERR_ARG;
+    }
+    p.nseg = out->nseg;
+    for (int i = 0; i < out->nseg; ++i) {
+        if (!out->w[i] || out->ncols[i] <= 0 || (out->ncols[i] & 7) || (out->col0[i] & 7) || (out->ld[i] & 7)) return TEAL_ERR_SHAPE;
+        if (!aligned16(out->w[i])) return TEAL_ERR_ALIGN;
+        if (out->mode == TEAL_OUT_ROUNDED && !out->y[i]) return TEAL_ERR_ARG;
+        p.seg[i].w = out->w[i];
+        p.seg[i].y = out->y[i];
+        p.seg[i].tau = out->tau[i];
+        p.seg[i].ld = out->ld[i];
+        p.seg[i].col0 = out->col0[i];
+        p.seg[i].ncols = out->ncols[i];
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    Config used = {};
+    int rc;
+    if (out->mode == TEAL_OUT_SLABS) {
+        if (!out->slabs) return TEAL_ERR_ARG;
+        rc = run_gemv(p, dtype, out->slabs, out->slabs_bytes, true, st, &used, true);
+    } else if (out->mode == TEAL_OUT_ROUNDED) {
+        rc = run_gemv(p, dtype, ws, ws_bytes, false, st, &used, false);
+    } else {
+        return TEAL_ERR_ARG;
+    }
+    if (rc == TEAL_OK && nslabs_out) *nslabs_out = used.split;
+    return rc;
+}
+
+int teal_decode_attention(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,
+                          void* y, int n_head, int n_kv_head, int head_dim, int max_seq, int dtype, void* stream) {
+    if (!qkv || !rope || !pos || !k_cache || !v_cache || !y) return TEAL_ERR_ARG;
+    if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
+    if ((head_dim != 64 && head_dim != 128) || n_head <= 0 || n_kv_head <= 0 || n_head % n_kv_head || max_seq <= 0)
+        return TEAL_ERR_SHAPE;
+    const size_t lds = (size_t)(3 * head_dim + 8 + 4 * head_dim + max_seq) * sizeof(float);
+    if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    const dim3 grid(n_head), block(256);
+    auto* q = reinterpret_cast<const uint16_t*>(qkv);
+    auto* r = reinterpret_cast<const uint16_t*>(rope);
+    auto* kc = reinterpret_cast<uint16_t*>(k_cache);
+    auto* vc = reinterpret_cast<uint16_t*>(v_cache);
+    auto* yo = reinterpret_cast<uint16_t*>(y);
+    if (dtype == TEAL_BF16)
+        hipLaunchKernelGGL((decode_attention_kernel<true>), grid, block, lds, st, q, r, pos, kc, vc, yo, n_head, n_kv_head, head_dim, max_seq, scale);
+    else
+        hipLaunchKernelGGL((decode_attention_kernel<false>), grid, block, lds, st, q, r, pos, kc, vc, yo, n_head, n_kv_head, head_dim, max_seq, scale);
     return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
 }
 

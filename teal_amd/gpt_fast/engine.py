@@ -1,0 +1,199 @@
+"""Fused HIP decode step for a gpt-fast-shaped Llama.
+
+The reference runs one token through ~13 framework ops per layer around its 5 sparse GEMVs
+(gpt-fast/model.py:158-190, 258-259, 289-291) and relies on Inductor to fuse them.  Here the whole
+layer is 5 hand-written HIP launches, with everything between two GEMVs folded into the consumer's
+prologue (every workgroup recomputes the tiny vector work from L2; nothing round-trips through a
+separate kernel):
+
+  1. qkv     [h = resid + round(sum down-slabs); x = RMSNorm(h) * w] -> mask(tau_q|k|v) -> GEMV -> q|k|v
+  2. attn    RoPE(q, k), KV-cache append, softmax(q K^T / sqrt(d)) V                         -> y
+  3. wo      mask(tau_o) -> GEMV                                                            -> fp32 slabs
+  4. gate|up [h = resid + round(sum wo-slabs); x = RMSNorm(h) * w] -> mask(tau_gate|up)      -> gate|up
+  5. down    [x = silu(gate) * up] -> mask(tau_down) -> GEMV                                -> fp32 slabs
+  lm_head    [h = resid + round(sum down-slabs); x = RMSNorm(h) * w] -> dense GEMV           -> logits
+
+All through the C ABI (teal_fused_gemv / teal_decode_attention); PyTorch only owns the buffers and
+the stream.  The rounding points are those of the reference's fp16/bf16 tensors, so logits agree
+with the unfused module path to fp16 rounding (tests/test_engine.py).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional
+
+import torch
+
+from .. import _lib, runtime
+from ..monkeypatch import to_column_major
+from .model import Transformer
+
+TEAL_IN_PLAIN, TEAL_IN_RESID_NORM, TEAL_IN_SILU_MUL = 0, 1, 2
+TEAL_OUT_ROUNDED, TEAL_OUT_SLABS = 0, 1
+MAX_SLABS = 32
+
+
+class GemvIn(ctypes.Structure):  # teal_gemv_in_t
+    _fields_ = [("mode", ctypes.c_int), ("x", ctypes.c_void_p), ("resid_in", ctypes.c_void_p),
+                ("row_index", ctypes.c_void_p), ("slabs", ctypes.c_void_p), ("nslabs", ctypes.c_int),
+                ("norm_weight", ctypes.c_void_p), ("eps", ctypes.c_float), ("resid_out", ctypes.c_void_p)]
+
+
+class GemvOut(ctypes.Structure):  # teal_gemv_out_t
+    _fields_ = [("nseg", ctypes.c_int), ("w", ctypes.c_void_p * 3), ("ld", ctypes.c_int * 3),
+                ("col0", ctypes.c_int * 3), ("ncols", ctypes.c_int * 3), ("tau", ctypes.c_float * 3),
+                ("y", ctypes.c_void_p * 3), ("mode", ctypes.c_int), ("slabs", ctypes.c_void_p),
+                ("slabs_bytes", ctypes.c_size_t)]
+
+
+def _out(segs, mode, slabs: Optional[torch.Tensor] = None) -> GemvOut:
+    """segs: list of (weight_ptr, ld, col0, ncols, tau, y_ptr)."""
+    o = GemvOut()
+    o.nseg = len(segs)
+    for i, (w, ld, col0, ncols, tau, y) in enumerate(segs):
+        o.w[i], o.ld[i], o.col0[i], o.ncols[i], o.tau[i], o.y[i] = w, ld, col0, ncols, tau, y
+    o.mode = mode
+    if slabs is not None:
+        o.slabs = slabs.data_ptr()
+        o.slabs_bytes = slabs.numel() * 4
+    return o
+
+
+class DecodeEngine:
+    """One-token decode of `model` at batch 1 through the fused HIP kernels.
+
+    `thresholds[i]` = {"q","k","v","o","gate","up","down": tau} for layer i (what monkeypatch_layer
+    derives from the histograms, or the synthetic calibration).  The model's KV caches
+    (`setup_caches`) are shared: prefill runs through the module path, decode through the engine.
+    """
+
+    def __init__(self, model: Transformer, thresholds: List[Dict[str, float]]):
+        self.L = _lib.load()
+        runtime.init()
+        cfg = model.config
+        self.cfg, self.model = cfg, model
+        dev = model.output.weight.device
+        dt = model.output.weight.dtype
+        self.dtype, self.code = dt, runtime.dtype_code(dt)
+        assert model.freqs_cis is not None, "call model.setup_caches() first"
+        dim, inter, hd = cfg.dim, cfg.intermediate_size, cfg.head_dim
+        kv = cfg.n_local_heads * hd
+        self.dim, self.inter, self.kv, self.nqkv = dim, inter, kv, dim + 2 * kv
+        for layer in model.layers:
+            for lin in (layer.attention.wqkv, layer.attention.wo, layer.feed_forward.w1, layer.feed_forward.w3,
+                        layer.feed_forward.w2):
+                to_column_major(lin)
+        to_column_major(model.output)
+        e = lambda *shape, dtype=dt: torch.zeros(*shape, device=dev, dtype=dtype)  # noqa: E731
+        self.resid = [e(dim), e(dim)]
+        self.qkv, self.y_attn, self.gu = e(self.nqkv), e(dim), e(2 * inter)
+        self.s_wo, self.s_down = e(MAX_SLABS, dim, dtype=torch.float32), e(MAX_SLABS, dim, dtype=torch.float32)
+        self.logits = e(1, 1, cfg.vocab_size)
+        self.ws = runtime.reserve_workspace(max(dim, inter), max(self.nqkv, inter, cfg.vocab_size))
+        self.rope = model.freqs_cis.contiguous()
+        assert self.rope.dtype == dt and self.rope.shape[1:] == (hd // 2, 2)
+        self.max_seq = model.max_seq_length
+        self.eps = float(cfg.norm_eps)
+        self.n_wo = ctypes.c_int(0)
+        self.n_down = ctypes.c_int(0)
+        self._build(thresholds)
+
+    # ---- static launch descriptors (pointers never change: hipGraph-capture friendly) -------------
+    def _build(self, ths):
+        m, dim, inter, kv, nq = self.model, self.dim, self.inter, self.kv, self.nqkv
+        A, B = self.resid
+        self.stages = []
+        for i, layer in enumerate(m.layers):
+            at, ff, th = layer.attention, layer.feed_forward, ths[i]
+            k1_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=(m.tok_embeddings.weight.data_ptr() if i == 0 else A.data_ptr()),
+                           slabs=(None if i == 0 else self.s_down.data_ptr()), nslabs=0,
+                           norm_weight=layer.attention_norm.weight.data_ptr(), eps=self.eps, resid_out=B.data_ptr())
+            wq = at.wqkv.weight.data_ptr()
+            k1_out = _out([(wq, nq, 0, dim, th["q"], self.qkv.data_ptr()),
+                           (wq, nq, dim, kv, th["k"], self.qkv.data_ptr() + 2 * dim),
+                           (wq, nq, dim + kv, kv, th["v"], self.qkv.data_ptr() + 2 * (dim + kv))], TEAL_OUT_ROUNDED)
+            k3_in = GemvIn(mode=TEAL_IN_PLAIN, x=self.y_attn.data_ptr())
+            k3_out = _out([(at.wo.weight.data_ptr(), dim, 0, dim, th["o"], None)], TEAL_OUT_SLABS, self.s_wo)
+            k4_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=B.data_ptr(), slabs=self.s_wo.data_ptr(), nslabs=0,
+                           norm_weight=layer.ffn_norm.weight.data_ptr(), eps=self.eps, resid_out=A.data_ptr())
+            k4_out = _out([(ff.w1.weight.data_ptr(), inter, 0, inter, th["gate"], self.gu.data_ptr()),
+                           (ff.w3.weight.data_ptr(), inter, 0, inter, th["up"], self.gu.data_ptr() + 2 * inter)], TEAL_OUT_ROUNDED)
+            k5_in = GemvIn(mode=TEAL_IN_SILU_MUL, x=self.gu.data_ptr())
+            k5_out = _out([(ff.w2.weight.data_ptr(), dim, 0, dim, th["down"], None)], TEAL_OUT_SLABS, self.s_down)
+            kc, vc = at.kv_cache.k_cache, at.kv_cache.v_cache
+            assert kc.is_contiguous() and kc.shape[0] == 1 and kc.shape[2] == self.max_seq
+            self.stages.append((k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out))
+        self.head_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=A.data_ptr(), slabs=self.s_down.data_ptr(), nslabs=0,
+                              norm_weight=m.norm.weight.data_ptr(), eps=self.eps, resid_out=None)
+        self.head_out = _out([(m.output.weight.data_ptr(), self.cfg.vocab_size, 0, self.cfg.vocab_size, float("-inf"),
+                               self.logits.data_ptr())], TEAL_OUT_ROUNDED)
+
+    def _gemv(self, gin: GemvIn, gout: GemvOut, Z: int, nslabs_out=None):
+        rc = self.L.teal_fused_gemv(ctypes.byref(gin), ctypes.byref(gout), Z, self.code, self.ws.data_ptr(),
+                                    self.ws.numel() * 4, ctypes.byref(nslabs_out) if nslabs_out is not None else None,
+                                    self._stream)
+        if rc != 0:
+            _lib.check(rc, "teal_fused_gemv")
+
+    def __call__(self, idx: torch.Tensor, input_pos: torch.Tensor) -> torch.Tensor:
+        """idx: int32 [1, 1] token id, input_pos: int32 [1] position -> logits [1, 1, vocab]."""
+        assert idx.dtype == torch.int32 and input_pos.dtype == torch.int32 and idx.numel() == 1
+        cfg = self.cfg
+        self._stream = runtime.stream_ptr()
+        tok_ptr, pos_ptr = idx.data_ptr(), input_pos.data_ptr()
+        for i, (k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out) in enumerate(self.stages):
+            if i == 0:
+                k1_in.row_index = tok_ptr
+            else:
+                k1_in.nslabs = self.n_down.value
+            self._gemv(k1_in, k1_out, self.dim)
+            rc = self.L.teal_decode_attention(self.qkv.data_ptr(), self.rope.data_ptr(), pos_ptr, kc.data_ptr(), vc.data_ptr(),
+                                              self.y_attn.data_ptr(), cfg.n_head, cfg.n_local_heads, cfg.head_dim,
+                                              self.max_seq, self.code, self._stream)
+            if rc != 0:
+                _lib.check(rc, "teal_decode_attention")
+            self._gemv(k3_in, k3_out, self.dim, self.n_wo)
+            k4_in.nslabs = self.n_wo.value
+            self._gemv(k4_in, k4_out, self.dim)
+            self._gemv(k5_in, k5_out, self.inter, self.n_down)
+        self.head_in.nslabs = self.n_down.value
+        self._gemv(self.head_in, self.head_out, self.dim)
+        return self.logits
+
+    # nn.Module-ish surface so GraphedDecoder can drive either a Transformer or an engine
+    @property
+    def config(self):
+        return self.cfg
+
+    @property
+    def device(self):
+        return self.logits.device
+
+
+def make_engine_stepper(model: Transformer, a):
+    """bench.py helper: thresholds (synthetic calibration) + prefill through the module path + a
+    hipGraph of [engine decode step + sampling]; returns (step_fn, info)."""
+    from . import generate as G
+    dev = "cuda"
+    ths = G.apply_sparsity(model, sparsity=a.sparsity, hist_path=None, greedy_lookup=None, synthetic=True)
+    prompt = torch.randint(0, model.config.vocab_size, (6,), device=dev, dtype=torch.int,
+                           generator=torch.Generator(device=dev).manual_seed(7))
+    total = 6 + a.warmup + a.steps + 8
+    model.max_seq_length = -1
+    model.setup_caches(max_batch_size=1, max_seq_length=min(total, model.config.block_size))
+    with torch.no_grad():
+        logits = model(prompt.view(1, -1), torch.arange(0, 6, device=dev))  # prefill fills the shared KV caches
+        tok = G.sample(logits, temperature=0.8, top_k=200)[0]
+        eng = DecodeEngine(model, ths)
+        dec = G.GraphedDecoder(eng, True, 0.8, 200)
+        dec.tok.copy_(tok.view(1, 1))
+        dec.pos.fill_(6)
+        dec.capture()
+    one = torch.ones(1, dtype=torch.int, device=dev)
+
+    def step():
+        dec.graph.replay()
+        dec.tok.copy_(dec.out_tok.view(1, 1))
+        dec.pos.add_(one)
+
+    return step, {"thresholds": ths, "engine": eng}

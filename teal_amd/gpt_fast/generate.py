@@ -175,7 +175,7 @@ class GraphedDecoder:
     def __init__(self, model: Transformer, use_graph: bool, temperature: float, top_k: Optional[int]):
         self.model, self.use_graph = model, use_graph
         self.kw = dict(temperature=temperature, top_k=top_k)
-        dev = model.output.weight.device
+        dev = model.device if hasattr(model, "device") else model.output.weight.device
         self.tok = torch.zeros(1, 1, dtype=torch.int, device=dev)
         self.pos = torch.zeros(1, dtype=torch.int, device=dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None

@@ -1,0 +1,166 @@
+"""GPU: the fused HIP decode step (engine.py: RMSNorm/residual/silu producers folded into the GEMV
+launches + the decode-attention kernel) against the unfused module path it replaces."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _models(dtype, sparsity, seed=3):
+    from teal_amd.gpt_fast import generate as G
+    ref = G.build_synthetic_model("tiny-test", DEV, dtype, seed=seed, std=0.05)
+    eng_m = G.build_synthetic_model("tiny-test", DEV, dtype, seed=seed, std=0.05)
+    ths = G.apply_sparsity(ref, sparsity=sparsity, hist_path=None, greedy_lookup=None, synthetic=True)
+    G.apply_sparsity(eng_m, sparsity=sparsity, hist_path=None, greedy_lookup=None, synthetic=True)
+    for m in (ref, eng_m):
+        m.max_seq_length = -1
+        m.setup_caches(1, 64)
+    return ref, eng_m, ths
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_decode_attention_kernel_vs_torch(dtype):
+    from teal_amd import _lib, runtime
+    from teal_amd.gpt_fast.model import apply_rotary_emb, precompute_freqs_cis
+    L = _lib.load()
+    runtime.init()
+    for n_head, n_kv, hd, pos in ((4, 2, 64, 0), (4, 2, 64, 17), (8, 8, 128, 40), (8, 2, 128, 63)):
+        S = 64
+        g = torch.Generator(device=DEV).manual_seed(pos + hd)
+        qkv = (torch.randn((n_head + 2 * n_kv) * hd, device=DEV, generator=g) * 0.5).to(dtype)
+        kc = (torch.randn(n_kv, S, hd, device=DEV, generator=g) * 0.5).to(dtype)
+        vc = (torch.randn(n_kv, S, hd, device=DEV, generator=g) * 0.5).to(dtype)
+        rope = precompute_freqs_cis(S, hd, 10000, dtype).to(DEV).contiguous()
+        y = torch.empty(n_head * hd, device=DEV, dtype=dtype)
+        p = torch.tensor([pos], device=DEV, dtype=torch.int32)
+        kc0, vc0 = kc.clone(), vc.clone()
+        rc = L.teal_decode_attention(qkv.data_ptr(), rope.data_ptr(), p.data_ptr(), kc.data_ptr(), vc.data_ptr(), y.data_ptr(),
+                                     n_head, n_kv, hd, S, runtime.dtype_code(dtype), runtime.stream_ptr())
+        assert rc == 0
+        # torch reference (the module path's maths)
+        q, k, v = qkv.split([n_head * hd, n_kv * hd, n_kv * hd])
+        fc = rope[pos:pos + 1]
+        qr = apply_rotary_emb(q.view(1, 1, n_head, hd), fc).view(n_head, hd)
+        kr = apply_rotary_emb(k.view(1, 1, n_kv, hd), fc).view(n_kv, hd)
+        kc0[:, pos] = kr
+        vc0[:, pos] = v.view(n_kv, hd)
+        assert torch.equal(kc, kc0) and torch.equal(vc, vc0), "KV-cache append differs"
+        rep = n_head // n_kv
+        K = kc0[:, :pos + 1].repeat_interleave(rep, dim=0).float()
+        V = vc0[:, :pos + 1].repeat_interleave(rep, dim=0).float()
+        sc = torch.einsum("hd,htd->ht", qr.float(), K) / hd ** 0.5
+        want = torch.einsum("ht,htd->hd", torch.softmax(sc, dim=-1), V).reshape(-1)
+        tol = 4e-3 if dtype == torch.float16 else 3e-2
+        assert torch.allclose(y.float(), want, atol=tol, rtol=tol), float((y.float() - want).abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_engine_matches_module_path_dense_thresholds(dtype):
+    """tau = -1 (everything kept): no threshold flips, so the fused step must track the unfused
+    module path to rounding for several tokens, including the KV caches it appends to."""
+    from teal_amd.gpt_fast.engine import DecodeEngine
+    ref, eng_m, ths = _models(dtype, 0.0)
+    prompt = torch.randint(0, 512, (6,), device=DEV, dtype=torch.int)
+    with torch.no_grad():
+        for m in (ref, eng_m):
+            m(prompt.view(1, -1), torch.arange(6, device=DEV))
+        eng = DecodeEngine(eng_m, ths)
+        tok = torch.tensor([[11]], device=DEV, dtype=torch.int)
+        for step in range(5):
+            pos = torch.tensor([6 + step], device=DEV, dtype=torch.int)
+            a = ref(tok, pos).float().view(-1)
+            b = eng(tok, pos).float().view(-1)
+            tol = 6e-3 if dtype == torch.float16 else 6e-2
+            assert torch.allclose(a, b, atol=tol, rtol=tol), (step, float((a - b).abs().max()))
+            assert int(a.argmax()) == int(b.argmax()) or (a - b).abs().max() < tol
+            tok = a.argmax().view(1, 1).to(torch.int)
+        for lr, le in zip(ref.layers, eng_m.layers):
+            kr, ke = lr.attention.kv_cache.k_cache[:, :, :11].float(), le.attention.kv_cache.k_cache[:, :, :11].float()
+            assert torch.allclose(kr, ke, atol=tol, rtol=tol)
+
+
+def test_engine_sparse_tracks_module_path():
+    """50 % thresholds: a handful of activations sit within rounding of tau and may flip, so compare
+    by direction of the logits rather than element-wise."""
+    from teal_amd.gpt_fast.engine import DecodeEngine
+    ref, eng_m, ths = _models(torch.float16, 0.5)
+    prompt = torch.randint(0, 512, (6,), device=DEV, dtype=torch.int)
+    with torch.no_grad():
+        for m in (ref, eng_m):
+            m(prompt.view(1, -1), torch.arange(6, device=DEV))
+        eng = DecodeEngine(eng_m, ths)
+        tok = torch.tensor([[5]], device=DEV, dtype=torch.int)
+        for step in range(4):
+            pos = torch.tensor([6 + step], device=DEV, dtype=torch.int)
+            a = ref(tok, pos).float().view(-1)
+            b = eng(tok, pos).float().view(-1)
+            cos = torch.nn.functional.cosine_similarity(a, b, dim=0)
+            assert cos > 0.995, (step, float(cos))
+            tok = a.argmax().view(1, 1).to(torch.int)
+
+
+def test_engine_under_hipgraph_equals_eager():
+    from teal_amd.gpt_fast import generate as G
+    from teal_amd.gpt_fast.engine import DecodeEngine
+    _, eng_m, ths = _models(torch.float16, 0.5)
+    prompt = torch.randint(0, 512, (6,), device=DEV, dtype=torch.int)
+    with torch.no_grad():
+        eng_m(prompt.view(1, -1), torch.arange(6, device=DEV))
+        eng = DecodeEngine(eng_m, ths)
+        tok = torch.tensor([[9]], device=DEV, dtype=torch.int)
+        pos = torch.tensor([6], device=DEV, dtype=torch.int)
+        eager = eng(tok, pos).clone()
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            eng(tok, pos)
+        torch.cuda.current_stream().wait_stream(s)
+        with torch.cuda.graph(g):
+            out = eng(tok, pos)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int16), eager.view(torch.int16))
+        # a different token/position through the same graph
+        tok.fill_(3)
+        pos.fill_(7)
+        g.replay()
+        torch.cuda.synchronize()
+        replayed = out.clone()
+        want = eng(tok, pos)
+        assert torch.equal(replayed.view(torch.int16), want.view(torch.int16))
+
+
+def test_fused_gemv_resid_norm_matches_torch():
+    """RESID_NORM producer alone: x = RMSNorm(resid + round(sum slabs)) * w, then a dense GEMV."""
+    from teal_amd import _lib, runtime
+    from teal_amd.gpt_fast.engine import GemvIn, GemvOut, _out, TEAL_IN_RESID_NORM, TEAL_OUT_ROUNDED
+    from teal_amd.gpt_fast.model import RMSNorm
+    L = _lib.load()
+    runtime.init()
+    Z, N, ns = 1024, 768, 3
+    dt = torch.float16
+    g = torch.Generator(device=DEV).manual_seed(0)
+    resid = (torch.randn(Z, device=DEV, generator=g)).to(dt)
+    slabs = torch.randn(ns, Z, device=DEV, generator=g) * 0.3
+    nw = (1 + 0.1 * torch.randn(Z, device=DEV, generator=g)).to(dt)
+    W = (torch.randn(N, Z, device=DEV, generator=g) * 0.05).to(dt).T.contiguous().T
+    rout = torch.zeros(Z, device=DEV, dtype=dt)
+    y = torch.zeros(N, device=DEV, dtype=dt)
+    ws = runtime.reserve_workspace(Z, N)
+    gin = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=resid.data_ptr(), slabs=slabs.data_ptr(), nslabs=ns,
+                 norm_weight=nw.data_ptr(), eps=1e-5, resid_out=rout.data_ptr())
+    gout = _out([(W.data_ptr(), N, 0, N, -1.0, y.data_ptr())], TEAL_OUT_ROUNDED)
+    rc = L.teal_fused_gemv(ctypes.byref(gin), ctypes.byref(gout), Z, 0, ws.data_ptr(), ws.numel() * 4, None, runtime.stream_ptr())
+    assert rc == 0
+    h = resid + slabs.sum(0).to(dt)
+    assert torch.equal(rout, h) or (rout.float() - h.float()).abs().max() <= 2e-3
+    norm = RMSNorm(Z, 1e-5).to(DEV)
+    norm.weight.data = nw
+    x = norm(rout.view(1, 1, Z))
+    want = torch.matmul(x.float(), W.float().T).view(-1)
+    assert torch.allclose(y.float(), want, atol=3e-3, rtol=3e-3), float((y.float() - want).abs().max())

@@ -105,17 +105,28 @@ def test_monkeypatched_model_matches_dense_when_everything_is_kept():
 
 @pytest.mark.gpu
 def test_sparse_decode_graph_replay_equals_eager():
+    """the monkeypatched model's decode step, replayed from a hipGraph, is bit-identical to eager."""
     dev = "cuda"
+    m = tiny(dev, torch.float16)
+    G.apply_sparsity(m, sparsity=0.5, hist_path=None, greedy_lookup=None, synthetic=True)
+    m.setup_caches(1, 32)
     prompt = torch.randint(0, 512, (6,), device=dev, dtype=torch.int)
-    seqs = []
-    for use_graph in (False, True):
-        m = tiny(dev, torch.float16)
-        G.apply_sparsity(m, sparsity=0.5, hist_path=None, greedy_lookup=None, synthetic=True)
-        torch.manual_seed(1234)
-        dec = G.GraphedDecoder(m, use_graph, 0.0, None)  # temperature ~0: argmax, no RNG dependence
-        with torch.no_grad():
-            seqs.append(G.generate(m, prompt, 10, dec, temperature=0.0, top_k=None))
-    assert torch.equal(seqs[0], seqs[1])
+    with torch.no_grad():
+        m(prompt.view(1, -1), torch.arange(6, device=dev))
+        tok = torch.tensor([[9]], device=dev, dtype=torch.int)
+        pos = torch.tensor([6], device=dev, dtype=torch.int)
+        eager = m(tok, pos).clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            m(tok, pos)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = m(tok, pos)
+        g.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), eager.view(torch.int16))
 
 
 @pytest.mark.gpu
