@@ -142,6 +142,13 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
 int teal_decode_attention(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,
                           void* y, int n_head, int n_kv_head, int head_dim, int max_seq, int dtype, void* stream);
 
+/* Sampling step of the decode loop (gpt-fast/generate.py:49-66): logits / temperature, top-k filter
+ * (ties at the pivot kept), softmax, exponential-race multinomial.  rng_state = device uint64[2]
+ * {seed, draw counter}; the kernel bumps the counter so hipGraph replays draw fresh numbers.
+ * top_k <= 0 or >= vocab disables the filter.  token_out = device int32[1]. */
+int teal_sample_topk(const void* logits, int vocab, int dtype, int top_k, float temperature, void* rng_state,
+                     int32_t* token_out, void* stream);
+
 /* ---- tuning / introspection ------------------------------------------------------------------ */
 
 /* Override the launch geometry picked from (Z, N, CU count): lanes per row segment (8/16/32/64),

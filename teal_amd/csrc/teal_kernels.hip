@@ -261,17 +261,49 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         if (p.in.row_index) resid += (size_t)p.in.row_index[0] * Z;
         const uint16_t* nw = reinterpret_cast<const uint16_t*>(p.in.norm_w);
         float rv[KR];
+        float sacc[KR];
+        // issue every load before the first use (wave-uniform guards keep them asynchronous)
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const int c = (k / PER) * 64 + wave + (k % PER) * WAVES;
+            rv[k] = 0.0f;
+            sacc[k] = 0.0f;
+            if (c < nch) {
+                const int mc = min((c << 6) + lane, Z - 1);
+                rv[k] = bits_to_float(resid[mc], BF16);
+            }
+        }
+        for (int q = 0; q < p.in.nslabs; q += 2) {  // slabs two at a time, summed in slab order
+            const bool two = q + 1 < p.in.nslabs;
+            const float* s0 = p.in.slabs + (size_t)q * Z;
+            const float* s1 = p.in.slabs + (size_t)(two ? q + 1 : q) * Z;
+            float a0[KR], a1[KR];
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                const int c = (k / PER) * 64 + wave + (k % PER) * WAVES;
+                a0[k] = 0.0f;
+                a1[k] = 0.0f;
+                if (c < nch) {
+                    const int mc = min((c << 6) + lane, Z - 1);
+                    a0[k] = s0[mc];
+                    a1[k] = s1[mc];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                sacc[k] += a0[k];
+                if (two) sacc[k] += a1[k];
+            }
+        }
         float ss = 0.0f;
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
             const int m = (((k / PER) * 64 + wave + (k % PER) * WAVES) << 6) + lane;
             float r = 0.0f;
             if (m < Z) {
-                r = bits_to_float(resid[m], BF16);
+                r = rv[k];
                 if (p.in.nslabs > 0) {
-                    float sacc = 0.0f;
-                    for (int q = 0; q < p.in.nslabs; ++q) sacc += p.in.slabs[(size_t)q * Z + m];
-                    const float yv = bits_to_float(float_to_bits<BF16>(sacc), BF16);
+                    const float yv = bits_to_float(float_to_bits<BF16>(sacc[k]), BF16);
                     r = bits_to_float(float_to_bits<BF16>(r + yv), BF16);
                 }
             }
@@ -295,6 +327,29 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
                 if (rout && blockIdx.x == 0) rout[m] = float_to_bits<BF16>(rv[k]);
             }
             xr[k] = xb;
+        }
+    } else if constexpr (MODE == 2) {
+        uint32_t gb[KR], ub[KR];
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {  // all gate/up loads first, then the activation maths
+            const int c = (k / PER) * 64 + wave + (k % PER) * WAVES;
+            gb[k] = 0u;
+            ub[k] = 0u;
+            if (c < nch) {
+                const int mc = min((c << 6) + lane, Z - 1);
+                gb[k] = x[mc];
+                ub[k] = x[Z + mc];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const int c = (k / PER) * 64 + wave + (k % PER) * WAVES;
+            xr[k] = 0u;
+            if (c < nch) {
+                const float gt = bits_to_float(gb[k], BF16);
+                const float sl = bits_to_float(float_to_bits<BF16>(gt / (1.0f + expf(-gt))), BF16);
+                xr[k] = ((c << 6) + lane < Z) ? (uint32_t)float_to_bits<BF16>(sl * bits_to_float(ub[k], BF16)) : 0u;
+            }
         }
     } else {
 #pragma unroll
@@ -527,8 +582,8 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(
     float* kn = qs + hd;                         // [hd] rotated new k
     float* vn = kn + hd;                         // [hd] new v
     float* red = vn + hd;                        // [8] block reductions
-    float* part = red + 8;                       // [4][hd] partial outputs
-    float* sc = part + 4 * hd;                   // [max_seq] scores / probabilities
+    float* part = red + 8;                       // [16][hd] partial outputs
+    float* sc = part + 16 * hd;                  // [max_seq] scores / probabilities
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x;
     const int rep = n_head / n_kv;
@@ -565,22 +620,34 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(
     }
     __syncthreads();
 
-    // scores: one wave per cached position, lanes across the head dimension
-    const int epl = hd / 64;  // elements per lane (hd = 64 or 128)
+    // scores: one THREAD per cached position (all rows' 16-byte loads are in flight together);
+    // the new token's own key comes from LDS, not from the cache line being written
     float lmax = -INFINITY;
-    for (int t = wave; t <= pos; t += 4) {
-        float a = 0.0f;
-        if (t == pos) {
-            for (int e = 0; e < epl; ++e) a += qs[lane * epl + e] * kn[lane * epl + e];
-        } else {
-            const uint16_t* kr = kc + (size_t)t * hd + lane * epl;
-            for (int e = 0; e < epl; ++e) a += qs[lane * epl + e] * bits_to_float(kr[e], BF16);
+    for (int t0 = 0; t0 <= pos; t0 += 256) {
+        const int t = t0 + tid;
+        if (t <= pos) {
+            float a = 0.0f;
+            if (t == pos) {
+                for (int e = 0; e < hd; ++e) a += qs[e] * kn[e];
+            } else {
+                const u32x4* kr = reinterpret_cast<const u32x4*>(kc + (size_t)t * hd);
+#pragma unroll 4
+                for (int v8 = 0; v8 < hd / 8; ++v8) {
+                    const u32x4 w = kr[v8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        a += qs[v8 * 8 + 2 * j] * bits_to_float(w[j] & 0xFFFFu, BF16);
+                        a += qs[v8 * 8 + 2 * j + 1] * bits_to_float(w[j] >> 16, BF16);
+                    }
+                }
+            }
+            const float sv = bits_to_float(float_to_bits<BF16>(a * scale), BF16);
+            sc[t] = sv;
+            lmax = fmaxf(lmax, sv);
         }
-        a = wave_sum_f(a);
-        const float sv = bits_to_float(float_to_bits<BF16>(a * scale), BF16);
-        if (lane == 0) sc[t] = sv;
-        lmax = fmaxf(lmax, sv);
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, d));
     if (lane == 0) red[wave] = lmax;
     __syncthreads();
     const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
@@ -595,21 +662,154 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(
     __syncthreads();
     const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
 
-    // output: thread (grp, d) sums positions t = grp, grp + G, ... ; G = 256 / hd groups
-    const int G = 256 / hd;
-    const int d = tid % hd, grp = tid / hd;
-    float o = 0.0f;
-    for (int t = grp; t <= pos; t += G) {
+    // output: 16-byte slices of V rows; thread = (row group rg, 8-dim slice ds), R = 256/(hd/8) row groups
+    const int SL = hd / 8;            // slices per row (16 for hd=128, 8 for hd=64)
+    const int R = 256 / SL;           // rows in flight per step (16 or 32)
+    const int ds = tid % SL, rg = tid / SL;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.0f;
+#pragma unroll 4
+    for (int t = rg; t <= pos; t += R) {
         const float pr = bits_to_float(float_to_bits<BF16>(sc[t] * inv), BF16);
-        const float vv = (t == pos) ? vn[d] : bits_to_float(vc[(size_t)t * hd + d], BF16);
-        o += pr * vv;
+        if (t == pos) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += pr * vn[ds * 8 + j];
+        } else {
+            const u32x4 w = *reinterpret_cast<const u32x4*>(vc + (size_t)t * hd + ds * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[2 * j] += pr * bits_to_float(w[j] & 0xFFFFu, BF16);
+                o[2 * j + 1] += pr * bits_to_float(w[j] >> 16, BF16);
+            }
+        }
     }
-    part[grp * hd + d] = o;
+    // fold the R row groups: 16 partial rows through LDS (R = 32 is folded pairwise first)
+    float* prow = part + (size_t)(rg % 16) * hd + ds * 8;
+    if (rg < 16) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) prow[j] = o[j];
+    }
+    __syncthreads();
+    if (rg >= 16) {  // hd = 64: row groups 16..31 add onto 0..15
+#pragma unroll
+        for (int j = 0; j < 8; ++j) prow[j] += o[j];
+    }
     __syncthreads();
     if (tid < hd) {
         float acc = 0.0f;
-        for (int gq = 0; gq < G; ++gq) acc += part[gq * hd + tid];
+#pragma unroll
+        for (int gq = 0; gq < 16; ++gq) acc += part[gq * hd + tid];
         y[(size_t)h * hd + tid] = float_to_bits<BF16>(acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused sampler (gpt-fast/generate.py:49-66): logits / T -> keep the top-k -> softmax -> exponential-
+// race multinomial (argmax p_i / q_i, q_i ~ Exp(1)), no host sync.  One workgroup; the k-th largest
+// logit is found EXACTLY by a two-pass radix select on the 16-bit keys (ties at the pivot are all
+// kept, as `logits < pivot -> -inf` does).  Randomness: counter-based hash of (seed, draw counter,
+// index); the draw counter lives on the device and is bumped by the kernel, so hipGraph replays
+// draw fresh numbers.  Token streams are not pinned by the reference (they depend on torch's RNG).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t order_key16(uint32_t b, bool bf16) {
+    (void)bf16;  // fp16 and bf16 share sign-magnitude ordering
+    return (b & 0x8000u) ? (~b & 0xFFFFu) : (b | 0x8000u);
+}
+
+__device__ __forceinline__ uint32_t hash3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ (c + 0x165667B1u) * 0xC2B2AE3Du;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(1024) void sample_topk_kernel(const uint16_t* __restrict__ logits, const int V,
+                                                            const int top_k, const float inv_temp,
+                                                            unsigned long long* __restrict__ rng_state,
+                                                            int* __restrict__ token_out) {
+    __shared__ unsigned int hist[256];
+    __shared__ float fred[16];
+    __shared__ int ired[16];
+    __shared__ unsigned int sel[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool filter = top_k > 0 && top_k < V;
+    uint32_t pivot_key = 0;  // keep keys >= pivot_key
+    if (filter) {
+        // pass 1: high byte histogram
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < V; i += 1024) atomicAdd(&hist[order_key16(logits[i], BF16) >> 8], 1u);
+        __syncthreads();
+        if (tid == 0) {
+            unsigned int need = (unsigned int)top_k, acc = 0;
+            int bsel = 0;
+            for (int b = 255; b >= 0; --b) {
+                if (acc + hist[b] >= need) { bsel = b; break; }
+                acc += hist[b];
+            }
+            sel[0] = (unsigned int)bsel;
+            sel[1] = need - acc;  // rank wanted inside the selected bin
+        }
+        __syncthreads();
+        const unsigned int hb = sel[0], need2 = sel[1];
+        __syncthreads();
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < V; i += 1024) {
+            const uint32_t k = order_key16(logits[i], BF16);
+            if ((k >> 8) == hb) atomicAdd(&hist[k & 0xFFu], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned int acc = 0;
+            int bsel = 0;
+            for (int b = 255; b >= 0; --b) {
+                if (acc + hist[b] >= need2) { bsel = b; break; }
+                acc += hist[b];
+            }
+            sel[0] = (hb << 8) | (unsigned int)bsel;
+        }
+        __syncthreads();
+        pivot_key = sel[0];
+    }
+    // global max (always among the kept)
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, bits_to_float(logits[i], BF16));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    if (lane == 0) fred[wave] = mx;
+    __syncthreads();
+    mx = fred[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, fred[w]);
+    // exponential race: argmax_i exp((x_i - max)/T) / q_i  over the kept set (the softmax
+    // normaliser is common to all i and cannot change the argmax)
+    const uint32_t seed = (uint32_t)rng_state[0], ctr = (uint32_t)rng_state[1];
+    float best = -1.0f;
+    int besti = 0x7FFFFFFF;
+    for (int i = tid; i < V; i += 1024) {
+        const uint32_t b = logits[i];
+        if (filter && order_key16(b, BF16) < pivot_key) continue;
+        const float pnum = expf((bits_to_float(b, BF16) - mx) * inv_temp);
+        const float u = ((float)(hash3(seed, ctr, (uint32_t)i) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float sc = pnum / (-logf(u));
+        if (sc > best || (sc == best && i < besti)) { best = sc; besti = i; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float ob = __shfl_xor(best, d);
+        const int oi = __shfl_xor(besti, d);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    __syncthreads();
+    if (lane == 0) { fred[wave] = best; ired[wave] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (fred[w] > best || (fred[w] == best && ired[w] < besti)) { best = fred[w]; besti = ired[w]; }
+        token_out[0] = besti;
+        rng_state[1] = rng_state[1] + 1ull;
     }
 }
 
@@ -1006,7 +1206,7 @@ int teal_decode_attention(const void* qkv, const void* rope, const int32_t* pos,
     if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
     if ((head_dim != 64 && head_dim != 128) || n_head <= 0 || n_kv_head <= 0 || n_head % n_kv_head || max_seq <= 0)
         return TEAL_ERR_SHAPE;
-    const size_t lds = (size_t)(3 * head_dim + 8 + 4 * head_dim + max_seq) * sizeof(float);
+    const size_t lds = (size_t)(3 * head_dim + 8 + 16 * head_dim + max_seq) * sizeof(float);
     if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const float scale = 1.0f / sqrtf((float)head_dim);
@@ -1020,6 +1220,21 @@ int teal_decode_attention(const void* qkv, const void* rope, const int32_t* pos,
         hipLaunchKernelGGL((decode_attention_kernel<true>), grid, block, lds, st, q, r, pos, kc, vc, yo, n_head, n_kv_head, head_dim, max_seq, scale);
     else
         hipLaunchKernelGGL((decode_attention_kernel<false>), grid, block, lds, st, q, r, pos, kc, vc, yo, n_head, n_kv_head, head_dim, max_seq, scale);
+    return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
+}
+
+int teal_sample_topk(const void* logits, int vocab, int dtype, int top_k, float temperature, void* rng_state,
+                     int32_t* token_out, void* stream) {
+    if (!logits || !rng_state || !token_out || vocab <= 0) return TEAL_ERR_ARG;
+    if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
+    const float inv_temp = 1.0f / fmaxf(temperature, 1e-5f);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    auto* lg = reinterpret_cast<const uint16_t*>(logits);
+    auto* rs = reinterpret_cast<unsigned long long*>(rng_state);
+    if (dtype == TEAL_BF16)
+        hipLaunchKernelGGL((sample_topk_kernel<true>), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out);
+    else
+        hipLaunchKernelGGL((sample_topk_kernel<false>), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out);
     return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
 }
 

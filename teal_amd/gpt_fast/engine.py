@@ -96,6 +96,8 @@ class DecodeEngine:
         self.eps = float(cfg.norm_eps)
         self.n_wo = ctypes.c_int(0)
         self.n_down = ctypes.c_int(0)
+        self.rng_state = torch.tensor([1234, 0], dtype=torch.int64, device=dev)  # {seed, draw counter}
+        self.token = torch.zeros(1, dtype=torch.int32, device=dev)
         self._build(thresholds)
 
     # ---- static launch descriptors (pointers never change: hipGraph-capture friendly) -------------
@@ -159,6 +161,17 @@ class DecodeEngine:
         self.head_in.nslabs = self.n_down.value
         self._gemv(self.head_in, self.head_out, self.dim)
         return self.logits
+
+    def sample_fused(self, logits: torch.Tensor, temperature: float = 1.0, top_k: Optional[int] = None) -> torch.Tensor:
+        """One launch: top-k filter + softmax + exponential-race multinomial (generate.py:49-66)."""
+        rc = self.L.teal_sample_topk(logits.data_ptr(), self.cfg.vocab_size, self.code, int(top_k or 0), float(temperature),
+                                     self.rng_state.data_ptr(), self.token.data_ptr(), runtime.stream_ptr())
+        if rc != 0:
+            _lib.check(rc, "teal_sample_topk")
+        return self.token
+
+    def manual_seed(self, seed: int):
+        self.rng_state.copy_(torch.tensor([seed, 0], dtype=torch.int64))
 
     # nn.Module-ish surface so GraphedDecoder can drive either a Transformer or an engine
     @property

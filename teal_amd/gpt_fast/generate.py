@@ -183,6 +183,8 @@ class GraphedDecoder:
 
     def _step(self):
         logits = self.model(self.tok, self.pos)
+        if hasattr(self.model, "sample_fused"):  # HIP engine: one-launch sampler
+            return self.model.sample_fused(logits, **self.kw)
         return sample(logits, **self.kw)[0]
 
     def capture(self):

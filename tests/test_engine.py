@@ -164,3 +164,36 @@ def test_fused_gemv_resid_norm_matches_torch():
     x = norm(rout.view(1, 1, Z))
     want = torch.matmul(x.float(), W.float().T).view(-1)
     assert torch.allclose(y.float(), want, atol=3e-3, rtol=3e-3), float((y.float() - want).abs().max())
+
+
+def test_fused_sampler_topk_and_distribution():
+    """top-k pivot is exact (ties kept), temperature -> 0 is argmax, and draws follow softmax(top-k)."""
+    from teal_amd import _lib, runtime
+    L = _lib.load()
+    runtime.init()
+    V = 4096
+    g = torch.Generator(device=DEV).manual_seed(5)
+    logits = (torch.randn(V, device=DEV, generator=g) * 2).to(torch.float16)
+    state = torch.tensor([77, 0], dtype=torch.int64, device=DEV)
+    tok = torch.zeros(1, dtype=torch.int32, device=DEV)
+
+    def draw(n, top_k, temp):
+        out = []
+        for _ in range(n):
+            rc = L.teal_sample_topk(logits.data_ptr(), V, 0, top_k, temp, state.data_ptr(), tok.data_ptr(), runtime.stream_ptr())
+            assert rc == 0
+            out.append(int(tok.item()))
+        return out
+
+    assert draw(3, 50, 1e-6) == [int(logits.float().argmax())] * 3      # T -> 0: argmax
+    assert int(state[1]) == 3                                            # counter bumped per draw
+    k = 8
+    top = set(torch.topk(logits.float(), k).indices.tolist())
+    draws = draw(400, k, 1.0)
+    assert set(draws) <= top and len(set(draws)) >= 4                    # only top-k, and it does vary
+    # empirical frequencies ~ softmax over the top-k
+    idx = torch.topk(logits.float(), k).indices
+    p = torch.softmax(logits.float()[idx], dim=0).cpu().numpy()
+    freq = np.array([draws.count(int(i)) for i in idx]) / len(draws)
+    assert np.abs(freq - p).max() < 0.08
+    assert len(set(draw(200, 0, 1.0))) > 20                              # no filter: wide support
