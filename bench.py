@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--n_layer", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense comparator run")
+    ap.add_argument("--swizzle", type=int, default=1, help="XCD-decorrelating tile swizzle (A/B switch)")
     return ap.parse_args()
 
 
@@ -237,6 +238,8 @@ def main():
     from teal_amd import runtime
     from teal_amd.gpt_fast import generate as G
     runtime.init()
+    from teal_amd import _lib
+    _lib.load().teal_set_swizzle(a.swizzle)
     dt = {"fp16": torch.float16, "bf16": torch.bfloat16}[a.precision]
     torch.manual_seed(1234)
     mode = a.mode

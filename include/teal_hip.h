@@ -145,16 +145,21 @@ int teal_decode_attention(const void* qkv, const void* rope, const int32_t* pos,
 /* Sampling step of the decode loop (gpt-fast/generate.py:49-66): logits / temperature, top-k filter
  * (ties at the pivot kept), softmax, exponential-race multinomial.  rng_state = device uint64[2]
  * {seed, draw counter}; the kernel bumps the counter so hipGraph replays draw fresh numbers.
- * top_k <= 0 or >= vocab disables the filter.  token_out = device int32[1]. */
+ * top_k <= 0 or >= vocab disables the filter.  token_out = device int32[1] (may be the buffer the next
+ * decode step reads its token from).  Optional in-graph loop-carried state, so that one graph replay
+ * IS one decode step with no host-side glue: pos_inout[0] += 1; history[draw counter] = token. */
 int teal_sample_topk(const void* logits, int vocab, int dtype, int top_k, float temperature, void* rng_state,
-                     int32_t* token_out, void* stream);
+                     int32_t* token_out, int32_t* pos_inout, int32_t* history, int history_len, void* stream);
 
 /* ---- tuning / introspection ------------------------------------------------------------------ */
 
 /* Override the launch geometry picked from (Z, N, CU count): lanes per row segment (8/16/32/64),
- * waves per workgroup (4/8/16), split-K factor (>= 1) and unroll depth (4/8).  0 = automatic.
+ * waves per workgroup (8/16), split-K factor (>= 1) and unroll depth (4/8).  0 = automatic.
  * Process-global; meant for benchmark sweeps only. */
 int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll);
+
+/* Column-tile XOR swizzle that spreads every XCD over all DRAM channel residues (default on). */
+int teal_set_swizzle(int on);
 
 /* Diagnostics: when set (device pointer to >= 8 * workgroups uint64), thread 0 of every GEMV
  * workgroup stores 100 MHz wall-clock stamps of its phases (0 start, 1 ballots, 2 scatter,

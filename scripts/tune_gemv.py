@@ -96,7 +96,7 @@ def main():
     ]
     if a.shapes:
         cases = [c for c in cases if c[0] in a.shapes.split(",")]
-    lprs, waves, unrolls = (8, 16, 32, 64), (4, 8, 16), (2, 4, 8)
+    lprs, waves, unrolls = (8, 16, 32, 64), (8, 16), (4, 8)
     if a.quick:
         lprs, waves, unrolls = (8, 32), (8, 16), (4, 8)
 

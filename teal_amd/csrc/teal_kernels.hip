@@ -71,6 +71,7 @@ struct Params {
     int ws_ld;
     int cap;       // LDS list capacity (entries)
     int to_ws;     // 1: always write fp32 slabs (an epilogue kernel follows)
+    int swizzle;   // 1: XOR-swizzle tiles inside aligned groups of 8 (XCD decorrelation)
     unsigned long long* phase;  // optional: per-workgroup phase timestamps (teal_set_phase_buffer)
     Seg seg[kMaxSeg];
 };
@@ -201,7 +202,7 @@ __device__ __forceinline__ int lane_rank(unsigned long long mask) {
 // ------------------------------------------------------------------------------------------------
 // The sparse GEMV.  grid = ntiles * split workgroups of WAVES*64 threads.
 // ------------------------------------------------------------------------------------------------
-template <int LPR, int WAVES, int U, bool BF16, int MODE>
+template <int LPR, int WAVES, int U, bool BF16, int MODE, int KRT>
 __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p) {
     constexpr int RPW = 64 / LPR;  // rows a wave touches per load instruction
     constexpr int BN = LPR * 8;    // columns per tile (16 B per lane)
@@ -222,8 +223,12 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // Column tiles are interleaved over hardware blocks (block b runs on XCD b % 8, so every XCD
     // walks the whole row range).  An XCD-contiguous tile range was measured 10-25 % slower.
-    const int tile = blockIdx.x % p.ntiles;
+    int tile = blockIdx.x % p.ntiles;
     const int slice = blockIdx.x / p.ntiles;
+    // Block b runs on XCD b % 8, so with tile = b % ntiles every XCD would only ever touch one
+    // residue class (mod 8) of column tiles, i.e. of DRAM channels; XOR-ing the low 3 tile bits with
+    // the next 3 keeps the set of tiles in flight identical but spreads each XCD over all residues.
+    if (p.swizzle && tile < (p.ntiles & ~7)) tile = (tile & ~7) | ((tile ^ (tile >> 3)) & 7);
 
     int s = 0;
     if (p.nseg > 1 && tile >= p.seg[1].tile0) s = 1;
@@ -235,12 +240,18 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
     stamp(p, 0);
 
     // ---- phase A: one ballot per 64 activations -> masks[]; the activations a wave ballots stay
-    //      in its registers for the scatter (chunk c is owned by wave c % WAVES) -------------------
-    constexpr int PER = 64 / WAVES;               // owned chunks per group of 64 chunks
-    constexpr int GREG = WAVES >= 16 ? 4 : (WAVES >= 8 ? 2 : 1);
-    constexpr int KR = GREG * PER;                // register-cached chunks per wave (Z <= 4096..16384)
+    //      in its registers for the scatter (chunk c is owned by wave c % WAVES).  KRT (template) is
+    //      the number of register-cached chunks per wave, sized to Z by the host, so every load below
+    //      is unconditional (clamped address) and ALL of them are in flight before the first use. ----
+    constexpr int PER = 64 / WAVES;  // owned chunks per group of 64 chunks
+    constexpr int KR = KRT;
+    constexpr int GREG = KR / PER;   // groups of 64 chunks covered by the register cache
     const float tau = sg.tau;
     uint32_t xr[KR];
+    int mcl[KR];  // clamped element index of (k, lane)
+#pragma unroll
+    for (int k = 0; k < KR; ++k)
+        mcl[k] = min((((k / PER) * 64 + wave + (k % PER) * WAVES) << 6) + lane, Z - 1);
     // activation of element m after the fused producer (modes 0 and 2 are element-wise)
     auto load_act = [&](const int m) -> uint32_t {
         if constexpr (MODE == 2) {
@@ -260,53 +271,42 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         const uint16_t* resid = reinterpret_cast<const uint16_t*>(p.in.resid_in);
         if (p.in.row_index) resid += (size_t)p.in.row_index[0] * Z;
         const uint16_t* nw = reinterpret_cast<const uint16_t*>(p.in.norm_w);
-        float rv[KR];
-        float sacc[KR];
-        // issue every load before the first use (wave-uniform guards keep them asynchronous)
+        uint32_t rb[KR], wb[KR];
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
-            const int c = (k / PER) * 64 + wave + (k % PER) * WAVES;
-            rv[k] = 0.0f;
-            sacc[k] = 0.0f;
-            if (c < nch) {
-                const int mc = min((c << 6) + lane, Z - 1);
-                rv[k] = bits_to_float(resid[mc], BF16);
-            }
+            rb[k] = resid[mcl[k]];
+            wb[k] = nw[mcl[k]];
         }
-        for (int q = 0; q < p.in.nslabs; q += 2) {  // slabs two at a time, summed in slab order
+        float sacc[KR];
+#pragma unroll
+        for (int k = 0; k < KR; ++k) sacc[k] = 0.0f;
+        for (int q = 0; q < p.in.nslabs; q += 2) {  // two slabs per round trip, summed in slab order
             const bool two = q + 1 < p.in.nslabs;
             const float* s0 = p.in.slabs + (size_t)q * Z;
             const float* s1 = p.in.slabs + (size_t)(two ? q + 1 : q) * Z;
             float a0[KR], a1[KR];
 #pragma unroll
             for (int k = 0; k < KR; ++k) {
-                const int c = (k / PER) * 64 + wave + (k % PER) * WAVES;
-                a0[k] = 0.0f;
-                a1[k] = 0.0f;
-                if (c < nch) {
-                    const int mc = min((c << 6) + lane, Z - 1);
-                    a0[k] = s0[mc];
-                    a1[k] = s1[mc];
-                }
+                a0[k] = s0[mcl[k]];
+                a1[k] = s1[mcl[k]];
             }
 #pragma unroll
             for (int k = 0; k < KR; ++k) {
                 sacc[k] += a0[k];
-                if (two) sacc[k] += a1[k];
+                sacc[k] += two ? a1[k] : 0.0f;
             }
         }
+        float rv[KR];
         float ss = 0.0f;
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
             const int m = (((k / PER) * 64 + wave + (k % PER) * WAVES) << 6) + lane;
-            float r = 0.0f;
-            if (m < Z) {
-                r = rv[k];
-                if (p.in.nslabs > 0) {
-                    const float yv = bits_to_float(float_to_bits<BF16>(sacc[k]), BF16);
-                    r = bits_to_float(float_to_bits<BF16>(r + yv), BF16);
-                }
+            float r = bits_to_float(rb[k], BF16);
+            if (p.in.nslabs > 0) {
+                const float yv = bits_to_float(float_to_bits<BF16>(sacc[k]), BF16);
+                r = bits_to_float(float_to_bits<BF16>(r + yv), BF16);
             }
+            r = (m < Z) ? r : 0.0f;
             rv[k] = r;
             ss += r * r;
         }
@@ -320,43 +320,27 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
             const int m = (((k / PER) * 64 + wave + (k % PER) * WAVES) << 6) + lane;
-            uint32_t xb = 0u;
-            if (m < Z) {
-                const float xn = bits_to_float(float_to_bits<BF16>(rv[k] * rstd), BF16);
-                xb = float_to_bits<BF16>(xn * bits_to_float(nw[m], BF16));
-                if (rout && blockIdx.x == 0) rout[m] = float_to_bits<BF16>(rv[k]);
-            }
-            xr[k] = xb;
+            const float xn = bits_to_float(float_to_bits<BF16>(rv[k] * rstd), BF16);
+            xr[k] = (m < Z) ? (uint32_t)float_to_bits<BF16>(xn * bits_to_float(wb[k], BF16)) : 0u;
+            if (rout && blockIdx.x == 0 && m < Z) rout[m] = float_to_bits<BF16>(rv[k]);
         }
     } else if constexpr (MODE == 2) {
         uint32_t gb[KR], ub[KR];
 #pragma unroll
         for (int k = 0; k < KR; ++k) {  // all gate/up loads first, then the activation maths
-            const int c = (k / PER) * 64 + wave + (k % PER) * WAVES;
-            gb[k] = 0u;
-            ub[k] = 0u;
-            if (c < nch) {
-                const int mc = min((c << 6) + lane, Z - 1);
-                gb[k] = x[mc];
-                ub[k] = x[Z + mc];
-            }
+            gb[k] = x[mcl[k]];
+            ub[k] = x[Z + mcl[k]];
         }
-#pragma unroll
-        for (int k = 0; k < KR; ++k) {
-            const int c = (k / PER) * 64 + wave + (k % PER) * WAVES;
-            xr[k] = 0u;
-            if (c < nch) {
-                const float gt = bits_to_float(gb[k], BF16);
-                const float sl = bits_to_float(float_to_bits<BF16>(gt / (1.0f + expf(-gt))), BF16);
-                xr[k] = ((c << 6) + lane < Z) ? (uint32_t)float_to_bits<BF16>(sl * bits_to_float(ub[k], BF16)) : 0u;
-            }
-        }
-    } else {
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
             const int m = (((k / PER) * 64 + wave + (k % PER) * WAVES) << 6) + lane;
-            xr[k] = (m < Z) ? load_act(m) : 0u;
+            const float gt = bits_to_float(gb[k], BF16);
+            const float sl = bits_to_float(float_to_bits<BF16>(gt / (1.0f + expf(-gt))), BF16);
+            xr[k] = (m < Z) ? (uint32_t)float_to_bits<BF16>(sl * bits_to_float(ub[k], BF16)) : 0u;
         }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KR; ++k) xr[k] = x[mcl[k]];
     }
     int mycnt = 0;
 #pragma unroll
@@ -572,18 +556,19 @@ __global__ __launch_bounds__(1024) void compact_kernel(const uint16_t* __restric
 // reference's fp16/bf16 tensors: rotated q/k, scores, probabilities and the output are rounded to
 // dtype; accumulation is fp32.
 // ------------------------------------------------------------------------------------------------
-template <bool BF16>
-__global__ __launch_bounds__(256) void decode_attention_kernel(
+template <bool BF16, int NT>
+__global__ __launch_bounds__(NT) void decode_attention_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ rope, const int* __restrict__ pos_ptr,
     uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache, uint16_t* __restrict__ y,
     const int n_head, const int n_kv, const int hd, const int max_seq, const float scale) {
+    constexpr int NW = NT / 64;
     extern __shared__ __align__(16) unsigned char smem[];
     float* qs = reinterpret_cast<float*>(smem);  // [hd] rotated q
     float* kn = qs + hd;                         // [hd] rotated new k
     float* vn = kn + hd;                         // [hd] new v
-    float* red = vn + hd;                        // [8] block reductions
-    float* part = red + 8;                       // [16][hd] partial outputs
-    float* sc = part + 16 * hd;                  // [max_seq] scores / probabilities
+    float* red = vn + hd;                        // [2 * NW] block reductions
+    float* part = red + 2 * NW;                  // [NW][hd] per-wave partial outputs
+    float* sc = part + NW * hd;                  // [max_seq] scores / probabilities
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x;
     const int rep = n_head / n_kv;
@@ -623,7 +608,7 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(
     // scores: one THREAD per cached position (all rows' 16-byte loads are in flight together);
     // the new token's own key comes from LDS, not from the cache line being written
     float lmax = -INFINITY;
-    for (int t0 = 0; t0 <= pos; t0 += 256) {
+    for (int t0 = 0; t0 <= pos; t0 += NT) {
         const int t = t0 + tid;
         if (t <= pos) {
             float a = 0.0f;
@@ -631,7 +616,7 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(
                 for (int e = 0; e < hd; ++e) a += qs[e] * kn[e];
             } else {
                 const u32x4* kr = reinterpret_cast<const u32x4*>(kc + (size_t)t * hd);
-#pragma unroll 4
+#pragma unroll 8
                 for (int v8 = 0; v8 < hd / 8; ++v8) {
                     const u32x4 w = kr[v8];
 #pragma unroll
@@ -650,27 +635,33 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(
     for (int d = 32; d >= 1; d >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, d));
     if (lane == 0) red[wave] = lmax;
     __syncthreads();
-    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float mx = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w]);
     float lsum = 0.0f;
-    for (int t = tid; t <= pos; t += 256) {
+    for (int t = tid; t <= pos; t += NT) {
         const float e = expf(sc[t] - mx);
         sc[t] = e;
         lsum += e;
     }
     lsum = wave_sum_f(lsum);
-    if (lane == 0) red[4 + wave] = lsum;
+    if (lane == 0) red[NW + wave] = lsum;
     __syncthreads();
-    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    float tot = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += red[NW + w];
+    const float inv = 1.0f / tot;
 
-    // output: 16-byte slices of V rows; thread = (row group rg, 8-dim slice ds), R = 256/(hd/8) row groups
-    const int SL = hd / 8;            // slices per row (16 for hd=128, 8 for hd=64)
-    const int R = 256 / SL;           // rows in flight per step (16 or 32)
-    const int ds = tid % SL, rg = tid / SL;
+    // output: 16-byte slices of V rows; lane = (row-in-wave rw, 8-dim slice ds); a wave covers
+    // RW = 64/SL rows per step, the workgroup NW*RW rows
+    const int SL = hd / 8;   // slices per row (16 for hd=128, 8 for hd=64)
+    const int RW = 64 / SL;  // rows per wave step (4 or 8)
+    const int ds = lane % SL, rw = lane / SL;
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = 0.0f;
 #pragma unroll 4
-    for (int t = rg; t <= pos; t += R) {
+    for (int t = wave * RW + rw; t <= pos; t += NW * RW) {
         const float pr = bits_to_float(float_to_bits<BF16>(sc[t] * inv), BF16);
         if (t == pos) {
 #pragma unroll
@@ -684,22 +675,19 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(
             }
         }
     }
-    // fold the R row groups: 16 partial rows through LDS (R = 32 is folded pairwise first)
-    float* prow = part + (size_t)(rg % 16) * hd + ds * 8;
-    if (rg < 16) {
+    for (int off = SL; off < 64; off <<= 1) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) prow[j] = o[j];
+        for (int j = 0; j < 8; ++j) o[j] += __shfl_xor(o[j], off);
     }
-    __syncthreads();
-    if (rg >= 16) {  // hd = 64: row groups 16..31 add onto 0..15
+    if (lane < SL) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) prow[j] += o[j];
+        for (int j = 0; j < 8; ++j) part[wave * hd + lane * 8 + j] = o[j];
     }
     __syncthreads();
     if (tid < hd) {
         float acc = 0.0f;
 #pragma unroll
-        for (int gq = 0; gq < 16; ++gq) acc += part[gq * hd + tid];
+        for (int w = 0; w < NW; ++w) acc += part[w * hd + tid];
         y[(size_t)h * hd + tid] = float_to_bits<BF16>(acc);
     }
 }
@@ -727,20 +715,45 @@ template <bool BF16>
 __global__ __launch_bounds__(1024) void sample_topk_kernel(const uint16_t* __restrict__ logits, const int V,
                                                             const int top_k, const float inv_temp,
                                                             unsigned long long* __restrict__ rng_state,
-                                                            int* __restrict__ token_out) {
+                                                            int* __restrict__ token_out, int* __restrict__ pos_inout,
+                                                            int* __restrict__ history, const int history_len) {
     __shared__ unsigned int hist[256];
     __shared__ float fred[16];
     __shared__ int ired[16];
     __shared__ unsigned int sel[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool filter = top_k > 0 && top_k < V;
+    const int V8 = V >> 3;  // 16-byte vectors (vocab sizes are multiples of 8; the tail is handled scalar)
+    const u32x4* lv = reinterpret_cast<const u32x4*>(logits);
     uint32_t pivot_key = 0;  // keep keys >= pivot_key
+    float mx = -INFINITY;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    // pass 1: high-byte histogram of the order-preserving 16-bit keys + global max
+    for (int i = tid; i < V8; i += 1024) {
+        const u32x4 w = lv[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t lo = w[j] & 0xFFFFu, hi = w[j] >> 16;
+            mx = fmaxf(mx, fmaxf(bits_to_float(lo, BF16), bits_to_float(hi, BF16)));
+            if (filter) {
+                atomicAdd(&hist[order_key16(lo, BF16) >> 8], 1u);
+                atomicAdd(&hist[order_key16(hi, BF16) >> 8], 1u);
+            }
+        }
+    }
+    for (int i = (V8 << 3) + tid; i < V; i += 1024) {
+        mx = fmaxf(mx, bits_to_float(logits[i], BF16));
+        if (filter) atomicAdd(&hist[order_key16(logits[i], BF16) >> 8], 1u);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    if (lane == 0) fred[wave] = mx;
+    __syncthreads();
+    mx = fred[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, fred[w]);
     if (filter) {
-        // pass 1: high byte histogram
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
-        for (int i = tid; i < V; i += 1024) atomicAdd(&hist[order_key16(logits[i], BF16) >> 8], 1u);
-        __syncthreads();
         if (tid == 0) {
             unsigned int need = (unsigned int)top_k, acc = 0;
             int bsel = 0;
@@ -756,7 +769,17 @@ __global__ __launch_bounds__(1024) void sample_topk_kernel(const uint16_t* __res
         __syncthreads();
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        for (int i = tid; i < V; i += 1024) {
+        // pass 2: low-byte histogram inside the selected high-byte bin
+        for (int i = tid; i < V8; i += 1024) {
+            const u32x4 w = lv[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t k0 = order_key16(w[j] & 0xFFFFu, BF16), k1 = order_key16(w[j] >> 16, BF16);
+                if ((k0 >> 8) == hb) atomicAdd(&hist[k0 & 0xFFu], 1u);
+                if ((k1 >> 8) == hb) atomicAdd(&hist[k1 & 0xFFu], 1u);
+            }
+        }
+        for (int i = (V8 << 3) + tid; i < V; i += 1024) {
             const uint32_t k = order_key16(logits[i], BF16);
             if ((k >> 8) == hb) atomicAdd(&hist[k & 0xFFu], 1u);
         }
@@ -773,29 +796,27 @@ __global__ __launch_bounds__(1024) void sample_topk_kernel(const uint16_t* __res
         __syncthreads();
         pivot_key = sel[0];
     }
-    // global max (always among the kept)
-    float mx = -INFINITY;
-    for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, bits_to_float(logits[i], BF16));
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
-    if (lane == 0) fred[wave] = mx;
-    __syncthreads();
-    mx = fred[0];
-#pragma unroll
-    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, fred[w]);
     // exponential race: argmax_i exp((x_i - max)/T) / q_i  over the kept set (the softmax
     // normaliser is common to all i and cannot change the argmax)
     const uint32_t seed = (uint32_t)rng_state[0], ctr = (uint32_t)rng_state[1];
     float best = -1.0f;
     int besti = 0x7FFFFFFF;
-    for (int i = tid; i < V; i += 1024) {
-        const uint32_t b = logits[i];
-        if (filter && order_key16(b, BF16) < pivot_key) continue;
+    auto consider = [&](const uint32_t b, const int i) {
+        if (filter && order_key16(b, BF16) < pivot_key) return;
         const float pnum = expf((bits_to_float(b, BF16) - mx) * inv_temp);
         const float u = ((float)(hash3(seed, ctr, (uint32_t)i) >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        const float sc = pnum / (-logf(u));
-        if (sc > best || (sc == best && i < besti)) { best = sc; besti = i; }
+        const float scv = pnum / (-logf(u));
+        if (scv > best || (scv == best && i < besti)) { best = scv; besti = i; }
+    };
+    for (int i = tid; i < V8; i += 1024) {
+        const u32x4 w = lv[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            consider(w[j] & 0xFFFFu, i * 8 + 2 * j);
+            consider(w[j] >> 16, i * 8 + 2 * j + 1);
+        }
     }
+    for (int i = (V8 << 3) + tid; i < V; i += 1024) consider(logits[i], i);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         const float ob = __shfl_xor(best, d);
@@ -809,7 +830,10 @@ __global__ __launch_bounds__(1024) void sample_topk_kernel(const uint16_t* __res
         for (int w = 1; w < 16; ++w)
             if (fred[w] > best || (fred[w] == best && ired[w] < besti)) { best = fred[w]; besti = ired[w]; }
         token_out[0] = besti;
-        rng_state[1] = rng_state[1] + 1ull;
+        const unsigned long long c = rng_state[1];
+        if (history && (long long)c < (long long)history_len) history[c] = besti;
+        rng_state[1] = c + 1ull;
+        if (pos_inout) pos_inout[0] = pos_inout[0] + 1;
     }
 }
 
@@ -823,6 +847,7 @@ struct Config {
 int g_num_cu = 0;
 Config g_override = {0, 0, 0, 0};
 unsigned long long* g_phase = nullptr;
+int g_swizzle = 1;
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -880,20 +905,34 @@ Config pick_config(int Z, int ncols_total, int nseg_tiles_hint) {
     return c;
 }
 
-template <int LPR, int WAVES, int U, int MODE>
-hipError_t launch_gemv_m(const Params& p, int dtype, size_t lds, hipStream_t st) {
+template <int LPR, int WAVES, int U, int MODE, int KRT>
+hipError_t launch_gemv_k(const Params& p, int dtype, size_t lds, hipStream_t st) {
     const dim3 grid(p.ntiles * p.split), block(WAVES * 64);
     if (dtype == TEAL_BF16)
-        hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, true, MODE>), grid, block, lds, st, p);
+        hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, true, MODE, KRT>), grid, block, lds, st, p);
     else
-        hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, false, MODE>), grid, block, lds, st, p);
+        hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, false, MODE, KRT>), grid, block, lds, st, p);
     return hipGetLastError();
+}
+
+// register-cache depth: smallest KRT with KRT * WAVES * 64 >= Z (16-wave production geometry);
+// longer vectors use KRT = 16 plus the reload path (plain / silu-mul producers only)
+template <int LPR, int WAVES, int U, int MODE>
+hipError_t launch_gemv_m(const Params& p, int dtype, size_t lds, hipStream_t st) {
+    if constexpr (WAVES == 16) {
+        const int owned = (((p.Z + 63) >> 6) + WAVES - 1) / WAVES;
+        if (owned <= 4) return launch_gemv_k<LPR, WAVES, U, MODE, 4>(p, dtype, lds, st);
+        if (owned <= 8) return launch_gemv_k<LPR, WAVES, U, MODE, 8>(p, dtype, lds, st);
+        return launch_gemv_k<LPR, WAVES, U, MODE, 16>(p, dtype, lds, st);
+    } else {
+        return launch_gemv_k<LPR, WAVES, U, MODE, 16>(p, dtype, lds, st);
+    }
 }
 
 template <int LPR, int WAVES, int U>
 hipError_t launch_gemv_t(const Params& p, int dtype, size_t lds, hipStream_t st) {
     if (p.in.mode == 0) return launch_gemv_m<LPR, WAVES, U, 0>(p, dtype, lds, st);
-    if constexpr (WAVES == 16 && U != 2) {  // fused producers are built for the production geometry only
+    if constexpr (WAVES == 16) {  // fused producers are built for the production geometry only
         if (p.in.mode == 1) return launch_gemv_m<LPR, WAVES, U, 1>(p, dtype, lds, st);
         if (p.in.mode == 2) return launch_gemv_m<LPR, WAVES, U, 2>(p, dtype, lds, st);
     }
@@ -903,7 +942,6 @@ hipError_t launch_gemv_t(const Params& p, int dtype, size_t lds, hipStream_t st)
 template <int LPR, int WAVES>
 hipError_t launch_gemv_u(const Params& p, int dtype, size_t lds, int unroll, hipStream_t st) {
     switch (unroll) {
-        case 2: return launch_gemv_t<LPR, WAVES, 2>(p, dtype, lds, st);
         case 4: return launch_gemv_t<LPR, WAVES, 4>(p, dtype, lds, st);
         case 8: return launch_gemv_t<LPR, WAVES, 8>(p, dtype, lds, st);
         default: return hipErrorInvalidValue;
@@ -913,7 +951,6 @@ hipError_t launch_gemv_u(const Params& p, int dtype, size_t lds, int unroll, hip
 template <int LPR>
 hipError_t launch_gemv_w(const Params& p, int dtype, size_t lds, const Config& c, hipStream_t st) {
     switch (c.waves) {
-        case 4: return launch_gemv_u<LPR, 4>(p, dtype, lds, c.unroll, st);
         case 8: return launch_gemv_u<LPR, 8>(p, dtype, lds, c.unroll, st);
         case 16: return launch_gemv_u<LPR, 16>(p, dtype, lds, c.unroll, st);
         default: return hipErrorInvalidValue;
@@ -949,9 +986,8 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
         c.split = split;
         while ((size_t)((p.Z + c.split - 1) / c.split) * 4 > 40 * 1024 && c.split < kMaxSplit) ++c.split;
     }
-    if (p.in.mode != 0) {  // fused producers exist for 16-wave workgroups, unroll 4/8
+    if (p.in.mode != 0) {  // fused producers exist for 16-wave workgroups
         c.waves = 16;
-        if (c.unroll == 2) c.unroll = 4;
         if (p.in.mode == 1 && p.Z > 16 * 64 * 16) return TEAL_ERR_SHAPE;  // register-resident norm
     }
     const int bn = c.lpr * 8;
@@ -969,6 +1005,7 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
     p.to_ws = to_ws ? 1 : 0;
     p.ws = reinterpret_cast<float*>(ws);
     p.phase = g_phase;
+    p.swizzle = g_swizzle;
     const size_t lds = lds_bytes(p.Z, p.cap, c.waves, c.lpr);
     if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
     if (c.split > 1 || to_ws) {
@@ -1042,10 +1079,15 @@ int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll) {
         for (int o : ok) if (v == o) return true;
         return false;
     };
-    if (!in(lanes_per_row, {0, 8, 16, 32, 64}) || !in(waves, {0, 4, 8, 16}) ||
-        !in(unroll, {0, 2, 4, 8}) || split < 0 || split > kMaxSplit)
+    if (!in(lanes_per_row, {0, 8, 16, 32, 64}) || !in(waves, {0, 8, 16}) ||
+        !in(unroll, {0, 4, 8}) || split < 0 || split > kMaxSplit)
         return TEAL_ERR_CONFIG;
     g_override = {lanes_per_row, waves, split, unroll};
+    return TEAL_OK;
+}
+
+int teal_set_swizzle(int on) {
+    g_swizzle = on ? 1 : 0;
     return TEAL_OK;
 }
 
@@ -1206,35 +1248,37 @@ int teal_decode_attention(const void* qkv, const void* rope, const int32_t* pos,
     if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
     if ((head_dim != 64 && head_dim != 128) || n_head <= 0 || n_kv_head <= 0 || n_head % n_kv_head || max_seq <= 0)
         return TEAL_ERR_SHAPE;
-    const size_t lds = (size_t)(3 * head_dim + 8 + 16 * head_dim + max_seq) * sizeof(float);
+    constexpr int NT = 1024;
+    const size_t lds = (size_t)(3 * head_dim + 2 * (NT / 64) + (NT / 64) * head_dim + max_seq) * sizeof(float);
     if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const float scale = 1.0f / sqrtf((float)head_dim);
-    const dim3 grid(n_head), block(256);
+    const dim3 grid(n_head), block(NT);
     auto* q = reinterpret_cast<const uint16_t*>(qkv);
     auto* r = reinterpret_cast<const uint16_t*>(rope);
     auto* kc = reinterpret_cast<uint16_t*>(k_cache);
     auto* vc = reinterpret_cast<uint16_t*>(v_cache);
     auto* yo = reinterpret_cast<uint16_t*>(y);
     if (dtype == TEAL_BF16)
-        hipLaunchKernelGGL((decode_attention_kernel<true>), grid, block, lds, st, q, r, pos, kc, vc, yo, n_head, n_kv_head, head_dim, max_seq, scale);
+        hipLaunchKernelGGL((decode_attention_kernel<true, NT>), grid, block, lds, st, q, r, pos, kc, vc, yo, n_head, n_kv_head, head_dim, max_seq, scale);
     else
-        hipLaunchKernelGGL((decode_attention_kernel<false>), grid, block, lds, st, q, r, pos, kc, vc, yo, n_head, n_kv_head, head_dim, max_seq, scale);
+        hipLaunchKernelGGL((decode_attention_kernel<false, NT>), grid, block, lds, st, q, r, pos, kc, vc, yo, n_head, n_kv_head, head_dim, max_seq, scale);
     return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
 }
 
 int teal_sample_topk(const void* logits, int vocab, int dtype, int top_k, float temperature, void* rng_state,
-                     int32_t* token_out, void* stream) {
+                     int32_t* token_out, int32_t* pos_inout, int32_t* history, int history_len, void* stream) {
     if (!logits || !rng_state || !token_out || vocab <= 0) return TEAL_ERR_ARG;
     if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
+    if (!aligned16(logits)) return TEAL_ERR_ALIGN;
     const float inv_temp = 1.0f / fmaxf(temperature, 1e-5f);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     auto* lg = reinterpret_cast<const uint16_t*>(logits);
     auto* rs = reinterpret_cast<unsigned long long*>(rng_state);
     if (dtype == TEAL_BF16)
-        hipLaunchKernelGGL((sample_topk_kernel<true>), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out);
+        hipLaunchKernelGGL((sample_topk_kernel<true>), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len);
     else
-        hipLaunchKernelGGL((sample_topk_kernel<false>), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out);
+        hipLaunchKernelGGL((sample_topk_kernel<false>), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len);
     return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
 }
 

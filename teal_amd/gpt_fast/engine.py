@@ -97,7 +97,12 @@ class DecodeEngine:
         self.n_wo = ctypes.c_int(0)
         self.n_down = ctypes.c_int(0)
         self.rng_state = torch.tensor([1234, 0], dtype=torch.int64, device=dev)  # {seed, draw counter}
+        self._seed, self._calls = 1234, 0
         self.token = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.tok_buf = torch.zeros(1, 1, dtype=torch.int32, device=dev)   # loop-carried token
+        self.pos_buf = torch.zeros(1, dtype=torch.int32, device=dev)      # loop-carried position
+        self.history = torch.zeros(max(8, model.max_seq_length), dtype=torch.int32, device=dev)
+        self._graph, self._graph_key = None, None
         self._build(thresholds)
 
     # ---- static launch descriptors (pointers never change: hipGraph-capture friendly) -------------
@@ -162,16 +167,63 @@ class DecodeEngine:
         self._gemv(self.head_in, self.head_out, self.dim)
         return self.logits
 
-    def sample_fused(self, logits: torch.Tensor, temperature: float = 1.0, top_k: Optional[int] = None) -> torch.Tensor:
-        """One launch: top-k filter + softmax + exponential-race multinomial (generate.py:49-66)."""
+    def sample_fused(self, logits: torch.Tensor, temperature: float = 1.0, top_k: Optional[int] = None,
+                     feed: bool = False) -> torch.Tensor:
+        """One launch: top-k filter + softmax + exponential-race multinomial (generate.py:49-66).
+        feed=True also carries the loop state on the device: the token goes into the buffer the next
+        step reads, the position is advanced and the token is appended to `history`."""
+        tok_out = self.tok_buf if feed else self.token
         rc = self.L.teal_sample_topk(logits.data_ptr(), self.cfg.vocab_size, self.code, int(top_k or 0), float(temperature),
-                                     self.rng_state.data_ptr(), self.token.data_ptr(), runtime.stream_ptr())
+                                     self.rng_state.data_ptr(), tok_out.data_ptr(),
+                                     self.pos_buf.data_ptr() if feed else None,
+                                     self.history.data_ptr() if feed else None, self.history.numel(), runtime.stream_ptr())
         if rc != 0:
             _lib.check(rc, "teal_sample_topk")
-        return self.token
+        return tok_out
 
     def manual_seed(self, seed: int):
+        self._seed, self._calls = int(seed), 0
         self.rng_state.copy_(torch.tensor([seed, 0], dtype=torch.int64))
+
+    # ---- device-resident decode loop: one hipGraph replay == one token, no host-side glue ---------
+    def _self_step(self, temperature, top_k):
+        logits = self(self.tok_buf, self.pos_buf)
+        self.sample_fused(logits, temperature, top_k, feed=True)
+
+    def capture_loop(self, temperature: float, top_k: Optional[int]):
+        key = (float(temperature), int(top_k or 0))
+        if self._graph is not None and self._graph_key == key:
+            return self._graph
+        state = (self.tok_buf.clone(), self.pos_buf.clone(), self.rng_state.clone())
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):  # warm-up outside capture (KV rows it writes are rewritten by the real run)
+            self._self_step(temperature, top_k)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._self_step(temperature, top_k)
+        self.tok_buf.copy_(state[0]); self.pos_buf.copy_(state[1]); self.rng_state.copy_(state[2])
+        self._graph, self._graph_key = g, key
+        return g
+
+    @torch.no_grad()
+    def decode_n(self, first_token: torch.Tensor, pos: int, n: int, temperature: float = 0.8,
+                 top_k: Optional[int] = 200, use_graph: bool = True) -> torch.Tensor:
+        """n decode steps starting from `first_token` at position `pos`; returns the n sampled tokens."""
+        assert n <= self.history.numel() and pos + n <= self.max_seq
+        self.tok_buf.copy_(first_token.view(1, 1))
+        self.pos_buf.fill_(pos)
+        self._calls += 1
+        self.rng_state.copy_(torch.tensor([self._seed + self._calls, 0], dtype=torch.int64))
+        if use_graph:
+            g = self.capture_loop(temperature, top_k)
+            for _ in range(n):
+                g.replay()
+        else:
+            for _ in range(n):
+                self._self_step(temperature, top_k)
+        return self.history[:n].clone()
 
     # nn.Module-ish surface so GraphedDecoder can drive either a Transformer or an engine
     @property
@@ -184,29 +236,25 @@ class DecodeEngine:
 
 
 def make_engine_stepper(model: Transformer, a):
-    """bench.py helper: thresholds (synthetic calibration) + prefill through the module path + a
-    hipGraph of [engine decode step + sampling]; returns (step_fn, info)."""
+    """bench.py helper: thresholds (synthetic calibration) + prefill through the module path + the
+    device-resident decode loop (one hipGraph replay per token); returns (step_fn, info)."""
     from . import generate as G
     dev = "cuda"
     ths = G.apply_sparsity(model, sparsity=a.sparsity, hist_path=None, greedy_lookup=None, synthetic=True)
     prompt = torch.randint(0, model.config.vocab_size, (6,), device=dev, dtype=torch.int,
                            generator=torch.Generator(device=dev).manual_seed(7))
-    total = 6 + a.warmup + a.steps + 8
+    total = 6 + 2 * (a.warmup + a.steps) + 16
     model.max_seq_length = -1
     model.setup_caches(max_batch_size=1, max_seq_length=min(total, model.config.block_size))
     with torch.no_grad():
         logits = model(prompt.view(1, -1), torch.arange(0, 6, device=dev))  # prefill fills the shared KV caches
         tok = G.sample(logits, temperature=0.8, top_k=200)[0]
         eng = DecodeEngine(model, ths)
-        dec = G.GraphedDecoder(eng, True, 0.8, 200)
-        dec.tok.copy_(tok.view(1, 1))
-        dec.pos.fill_(6)
-        dec.capture()
-    one = torch.ones(1, dtype=torch.int, device=dev)
+        eng.tok_buf.copy_(tok.view(1, 1))
+        eng.pos_buf.fill_(6)
+        graph = eng.capture_loop(0.8, 200)
 
     def step():
-        dec.graph.replay()
-        dec.tok.copy_(dec.out_tok.view(1, 1))
-        dec.pos.add_(one)
+        graph.replay()
 
     return step, {"thresholds": ths, "engine": eng}

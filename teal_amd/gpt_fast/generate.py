@@ -209,6 +209,22 @@ class GraphedDecoder:
         return self._step()
 
 
+class EngineDecoder:
+    """GraphedDecoder's role for the fused HIP engine: built lazily once the KV caches exist."""
+
+    def __init__(self, torch_model: Transformer, thresholds, use_graph: bool, temperature: float, top_k: Optional[int]):
+        self.torch_model, self.thresholds, self.use_graph = torch_model, thresholds, use_graph
+        self.kw = dict(temperature=temperature, top_k=top_k)
+        self._engine = None
+
+    @property
+    def model(self):
+        if self._engine is None or self._engine.max_seq != self.torch_model.max_seq_length:
+            from teal_amd.gpt_fast.engine import DecodeEngine
+            self._engine = DecodeEngine(self.torch_model, self.thresholds)
+        return self._engine
+
+
 @torch.no_grad()
 def generate(model: Transformer, prompt: torch.Tensor, max_new_tokens: int, decoder: GraphedDecoder,
              temperature: float = 0.8, top_k: Optional[int] = 200) -> torch.Tensor:
@@ -222,6 +238,11 @@ def generate(model: Transformer, prompt: torch.Tensor, max_new_tokens: int, deco
     logits = model(prompt.view(1, -1), torch.arange(0, T, device=dev))
     next_token = sample(logits, temperature=temperature, top_k=top_k)[0].clone()
     seq[T] = next_token
+    if hasattr(decoder.model, "decode_n"):  # HIP engine: the whole loop stays on the device
+        toks = decoder.model.decode_n(next_token, T, max_new_tokens - 1, temperature=decoder.kw["temperature"],
+                                      top_k=decoder.kw["top_k"], use_graph=decoder.use_graph)
+        seq[T + 1:] = toks.to(seq.dtype)
+        return seq
     decoder.capture()
     input_pos = torch.tensor([T], device=dev, dtype=torch.int)
     cur = next_token.view(1, -1)
@@ -263,6 +284,9 @@ def main(args) -> Dict:
     torch.manual_seed(1234)
     model_size = _get_model_size(model)
     decoder = GraphedDecoder(model, args.compile, args.temperature, args.top_k)
+    if args.engine:
+        assert thresholds is not None, "--engine needs thresholds (--hist_path or --synthetic)"
+        decoder = EngineDecoder(model, thresholds, args.compile, args.temperature, args.top_k)
     tps = []
     start = -1 if args.compile else 0
     for i in range(start, args.num_samples):
@@ -313,6 +337,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--synthetic", type=str, default=None, help="architecture name, e.g. 7B, llama-3-8b, 70B")
     p.add_argument("--n_layer", type=int, default=None, help="override the layer count (synthetic smoke runs)")
     p.add_argument("--dense", action="store_true", help="do not monkeypatch: dense baseline")
+    p.add_argument("--engine", action="store_true", help="fused HIP decode step (teal_amd/gpt_fast/engine.py)")
     return p
 
 

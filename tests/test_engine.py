@@ -180,7 +180,7 @@ def test_fused_sampler_topk_and_distribution():
     def draw(n, top_k, temp):
         out = []
         for _ in range(n):
-            rc = L.teal_sample_topk(logits.data_ptr(), V, 0, top_k, temp, state.data_ptr(), tok.data_ptr(), runtime.stream_ptr())
+            rc = L.teal_sample_topk(logits.data_ptr(), V, 0, top_k, temp, state.data_ptr(), tok.data_ptr(), None, None, 0, runtime.stream_ptr())
             assert rc == 0
             out.append(int(tok.item()))
         return out
@@ -197,3 +197,40 @@ def test_fused_sampler_topk_and_distribution():
     freq = np.array([draws.count(int(i)) for i in idx]) / len(draws)
     assert np.abs(freq - p).max() < 0.08
     assert len(set(draw(200, 0, 1.0))) > 20                              # no filter: wide support
+
+
+def test_engine_device_resident_loop_matches_stepwise():
+    """decode_n (one graph replay per token, token/position/history carried on the device) produces
+    the same tokens as stepping the engine and the sampler by hand with the same RNG state."""
+    from teal_amd.gpt_fast.engine import DecodeEngine
+    _, eng_m, ths = _models(torch.float16, 0.5)
+    prompt = torch.randint(0, 512, (6,), device=DEV, dtype=torch.int)
+    with torch.no_grad():
+        eng_m(prompt.view(1, -1), torch.arange(6, device=DEV))
+        eng = DecodeEngine(eng_m, ths)
+        first = torch.tensor([[9]], device=DEV, dtype=torch.int)
+        toks = eng.decode_n(first, 6, 10, temperature=0.8, top_k=50, use_graph=True)
+        assert toks.shape == (10,) and int(eng.pos_buf) == 16
+        # by hand, eager, same seed/counter sequence
+        eng.rng_state.copy_(torch.tensor([eng._seed + eng._calls, 0], dtype=torch.int64))
+        cur = first.clone()
+        hand = []
+        for i in range(10):
+            pos = torch.tensor([6 + i], device=DEV, dtype=torch.int)
+            lg = eng(cur, pos)
+            t = eng.sample_fused(lg, 0.8, 50)
+            hand.append(int(t))
+            cur = t.view(1, 1).clone()
+        assert toks.tolist() == hand
+        toks2 = eng.decode_n(first, 6, 10, temperature=0.8, top_k=50, use_graph=False)
+        assert toks2.shape == (10,)
+
+
+def test_generate_with_engine_decoder():
+    from teal_amd.gpt_fast import generate as G
+    m = G.build_synthetic_model("tiny-test", DEV, torch.float16, seed=3, std=0.05)
+    ths = G.apply_sparsity(m, sparsity=0.5, hist_path=None, greedy_lookup=None, synthetic=True)
+    dec = G.EngineDecoder(m, ths, True, 0.8, 50)
+    prompt = torch.randint(0, 512, (6,), device=DEV, dtype=torch.int)
+    y = G.generate(m, prompt, 12, dec, temperature=0.8, top_k=50)
+    assert y.numel() == 18 and torch.equal(y[:6], prompt) and int(y.max()) < 512 and int(y.min()) >= 0

@@ -176,9 +176,9 @@ def test_every_launch_geometry_agrees(oracle):
     truth = oracle.truth64(xb, wb, Z, N, 1.0, 0.5, 1.5, N - 2 * 256, 256, dtype)  # qkv_gemv: N_q = N - 2*kv_size
     try:
         for lpr in (8, 16, 32, 64):
-            for waves in (4, 8, 16):
+            for waves in (8, 16):
                 for split in (1, 2, 5, 32):
-                    for unroll in (2, 4, 8):
+                    for unroll in (4, 8):
                         assert L.teal_set_tuning(lpr, waves, split, unroll) == 0
                         y = K().qkv_gemv(x, W, 1.0, 0.5, 1.5, 0, 256)
                         check_gemv(oracle, bits_from_torch(y.view(-1)), truth, dtype, None, f"cfg {lpr},{waves},{split},{unroll}")
