@@ -179,6 +179,73 @@ def roofline_dominant_kernel(model, a):
             "timing": "HIP events around a hipGraph of one launch per layer (distinct weights); includes the same-stream launch boundary"}
 
 
+def roofline_engine_gateup(eng, a):
+    """Dominant kernel of the fused decode step: the MLP gate|up launch (RESID_NORM producer + two
+    weight matrices, ~92 MB at 50 %).  One launch per layer inside a hipGraph, each layer's own
+    w1/w3 and thresholds (2.9 GB of distinct weights >> 256 MB Infinity Cache), timed with HIP events
+    on the launch stream.  Algorithmic bytes: kept rows of both matrices + the producer's inputs
+    (residual, slabs, norm weight) + the gate|up output."""
+    import torch.nn.functional as F
+    from teal_amd import runtime
+    from teal_amd.gpt_fast.engine import GemvIn, TEAL_IN_RESID_NORM
+    m, cfg = eng.model, eng.cfg
+    Z, N = cfg.dim, cfg.intermediate_size
+    ns = eng.n_wo.value
+    B = eng.resid[1]
+    # the producer's output, recomputed in torch to count kept rows per layer
+    h = (B.float() + eng.s_wo[:ns].sum(0).to(B.dtype).float()).to(B.dtype)
+    hf = h.float()
+    xn = (hf * torch.rsqrt(hf.pow(2).mean() + eng.eps)).to(B.dtype)
+    total_bytes, launches = 0, []
+    for i, st in enumerate(eng.stages):
+        k4_in, k4_out = st[6], st[7]
+        x = (xn * m.layers[i].ffn_norm.weight).float().abs()
+        nnz_g = int((x > k4_out.tau[0]).sum())
+        nnz_u = int((x > k4_out.tau[1]).sum())
+        total_bytes += (nnz_g + nnz_u) * N * 2 + Z * 2 + ns * Z * 4 + Z * 2 + 2 * N * 2
+        gin = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=B.data_ptr(), slabs=eng.s_wo.data_ptr(), nslabs=ns,
+                     norm_weight=m.layers[i].ffn_norm.weight.data_ptr(), eps=eng.eps, resid_out=None)
+        launches.append((gin, k4_out))
+
+    def run_all():
+        eng._stream = runtime.stream_ptr()
+        for gin, gout in launches:
+            eng._gemv(gin, gout, Z)
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        run_all()
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run_all()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(20):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        graph.replay()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3)
+    t = float(np.median(ts))
+    n = len(launches)
+    cfgv = (ctypes.c_int * 5)()
+    eng.L.teal_get_config(Z, 2 * N, 2, cfgv)
+    owned = ((Z + 63) // 64 + 15) // 16
+    krt = 4 if owned <= 4 else (8 if owned <= 8 else 16)
+    return {"bound": "hbm", "achieved": total_bytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": total_bytes / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "kernel": f"sparse_gemv_kernel<{cfgv[0]}, 16, {cfgv[3]}, {'true' if eng.code else 'false'}, 1, {krt}> "
+                      f"(fused RMSNorm -> mask -> gate|up GEMV, Z={Z}, N=2x{N})",
+            "algorithmic_bytes": total_bytes / n, "us_per_launch": t / n * 1e6, "launches_timed": n,
+            "timing": "HIP events (launch stream) around a hipGraph of one launch per layer with that layer's weights; "
+                      "per-launch time includes the same-stream launch boundary, like rocprofv3's per-dispatch duration"}
+
+
 def cpu_baseline(model, a, budget_s=12.0):
     """Oracle port (fp32 accumulate, OpenMP) on ONE layer's five sparse projections + the dense lm_head,
     inputs U(-.5,.5) with tau = s/2 (kept fraction 1-s), scaled to a whole token."""
@@ -270,7 +337,7 @@ def main():
                       "prompt_tokens": 6}}
     out.update(info.get("report", {}))
     if rank == 0 and world == 1:
-        out["roofline"] = roofline_dominant_kernel(model, a)
+        out["roofline"] = roofline_engine_gateup(info["engine"], a) if mode == "engine" else roofline_dominant_kernel(model, a)
         if not a.no_dense:
             # dense comparator on the same harness: same kernels with every row kept (threshold < 0)
             a_d = argparse.Namespace(**vars(a))

@@ -35,9 +35,9 @@ def main():
     k1_in.nslabs = eng.n_down.value
     k4_in.nslabs = eng.n_wo.value
     print("slabs: wo", eng.n_wo.value, "down", eng.n_down.value)
-    names = ["load+norm+ballots (0->1)", "barrier wait (1->6)", "total (6->7)", "scan/scatter (7->2)", "barrier (2->3)", "rows streamed (3->4)",
+    names = ["load+norm+ballots (0->1)", "barrier wait (1->6)", "scan/scatter (6->2)", "-", "barrier (2->3)", "rows streamed (3->4)",
              "reduce+store (4->5)"]
-    order = [(0, 1), (1, 6), (6, 7), (7, 2), (2, 3), (3, 4), (4, 5)]
+    order = [(0, 1), (1, 6), (6, 2), (2, 2), (2, 3), (3, 4), (4, 5)]
     for tag, gin, gout, Z in (("qkv  [RESID_NORM]", k1_in, k1_out, eng.dim), ("wo   [PLAIN]", k3_in, k3_out, eng.dim),
                               ("g|u  [RESID_NORM]", k4_in, k4_out, eng.dim), ("down [SILU_MUL]", k5_in, k5_out, eng.inter)):
         spans, rows = [], []
@@ -53,6 +53,9 @@ def main():
             L.teal_set_phase_buffer(None)
             p = phase.view(-1, 8)
             n = int((p[:, 5] > 0).sum())
+            if it == 7:
+                import numpy as np
+                np.save(os.path.join(ROOT, "gpurun_out", f"ephase_{tag.split()[0].replace('|', '')}.npy"), p[:n].cpu().numpy())
             p = p[:n].cpu().double() * 10.0
             t0 = p[:, 0].min()
             spans.append(float(p[:, 5].max() - t0) / 1e3)

@@ -52,8 +52,8 @@ def main():
             t0 = p[:, 0].min()
             spans.append(float(p[:, 5].max() - t0) / 1e3)
             rows.append([float((p[:, 0] - t0).max()) / 1e3] + [float((p[:, i + 1] - p[:, i]).mean()) / 1e3 for i in range(5)] +
-                        [float((p[:, 5] - t0).min()) / 1e3, float((p[:, 6] - p[:, 1]).mean()) / 1e3, float((p[:, 7] - p[:, 6]).mean()) / 1e3,
-                         float((p[:, 2] - p[:, 7]).mean()) / 1e3])
+                        [float((p[:, 5] - t0).min()) / 1e3, float((p[:, 6] - p[:, 1]).mean()) / 1e3, 0.0,
+                         float((p[:, 2] - p[:, 6]).mean()) / 1e3])
         import numpy as np
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         np.save(os.path.join(ROOT, "gpurun_out", f"phase_{tag}.npy"), (phase.view(wgs, 8).cpu().numpy() - int(phase.view(wgs, 8)[:, 0].min())))

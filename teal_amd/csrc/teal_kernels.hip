@@ -495,6 +495,12 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         }
     }
     stamp(p, 5);
+    if (p.phase && threadIdx.x == 0) {
+        unsigned xcc = 0, hwid = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        p.phase[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)hwid << 32) | xcc;
+    }
 }
 
 // y[n] = round(sum_s ws[s][n]) in slice order; one thread per column.
@@ -847,7 +853,7 @@ struct Config {
 int g_num_cu = 0;
 Config g_override = {0, 0, 0, 0};
 unsigned long long* g_phase = nullptr;
-int g_swizzle = 1;
+int g_swizzle = 0;
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
