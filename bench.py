@@ -237,13 +237,31 @@ def roofline_engine_gateup(eng, a):
     eng.L.teal_get_config(Z, 2 * N, 2, cfgv)
     owned = ((Z + 63) // 64 + 15) // 16
     krt = 4 if owned <= 4 else (8 if owned <= 8 else 16)
+    kname = f"sparse_gemv_kernel<{cfgv[0]},16,{cfgv[3]},{'true' if eng.code else 'false'},1,{krt}>"
+    traffic, tsrc = pmc_traffic(kname)
     return {"bound": "hbm", "achieved": total_bytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": total_bytes / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "frac": total_bytes / t / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
             "kernel": f"sparse_gemv_kernel<{cfgv[0]}, 16, {cfgv[3]}, {'true' if eng.code else 'false'}, 1, {krt}> "
                       f"(fused RMSNorm -> mask -> gate|up GEMV, Z={Z}, N=2x{N})",
             "algorithmic_bytes": total_bytes / n, "us_per_launch": t / n * 1e6, "launches_timed": n,
             "timing": "HIP events (launch stream) around a hipGraph of one launch per layer with that layer's weights; "
                       "per-launch time includes the same-stream launch boundary, like rocprofv3's per-dispatch duration"}
+
+
+def pmc_traffic(kernel_short_name):
+    """HBM read bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc FETCH_SIZE
+    pass of this same command (profiles/*pmc_fetch_by_kernel.csv; counters cannot be sampled from
+    inside the process).  FETCH_SIZE is reported in KiB and, on gfx950, counts 128-byte requests as 64
+    bytes for wide coalesced reads: doubled as MI355X_MICROARCH.md (HBM section) prescribes."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_fetch_by_kernel.csv")))
+    if not files:
+        return None, None
+    for r in csv.DictReader(open(files[-1])):
+        if r["kernel"].replace(" ", "") == kernel_short_name.replace(" ", "") and r["counter"] == "FETCH_SIZE":
+            return float(r["avg_value"]) * 1024 * 2, os.path.relpath(files[-1], ROOT) + " (FETCH_SIZE KiB x 2, per dispatch)"
+    return None, None
 
 
 def cpu_baseline(model, a, budget_s=12.0):
