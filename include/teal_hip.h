@@ -83,6 +83,14 @@ int teal_sparse_qkv_gemv(const void* x, const void* wT, void* y, float tau_q, fl
                          float tau_v, int Z, int N, int N_q, int N_kv, int dtype, void* ws,
                          size_t ws_bytes, void* stream);
 
+/* Same with an explicit row stride `ld >= N` (elements, multiple of 8) of the W^T image, i.e. weight[N, Z]
+ * with strides (1, ld).  A stride that is NOT a multiple of 1024 bytes (ld = N + 64) makes consecutive
+ * rows start in different 128-byte DRAM-channel residues, so a workgroup's column tile rotates over all
+ * channels instead of hammering one. */
+int teal_sparse_qkv_gemv_ld(const void* x, const void* wT, int ld, void* y, float tau_q, float tau_k,
+                            float tau_v, int Z, int N, int N_q, int N_kv, int dtype, void* ws,
+                            size_t ws_bytes, void* stream);
+
 /* y = x @ W^T with every row kept (prefill-free decode of un-sparsified layers, e.g. lm_head).
  * (kernels/sparse_gemv.py:301-307) */
 int teal_dense_gemv(const void* x, const void* wT, void* y, int Z, int N, int dtype, void* ws,

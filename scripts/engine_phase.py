@@ -17,6 +17,7 @@ from teal_amd.gpt_fast.engine import DecodeEngine  # noqa: E402
 def main():
     L = _lib.load()
     runtime.init()
+    L.teal_set_swizzle(int(os.environ.get("TEAL_SWIZZLE", "0")))
     model = G.build_synthetic_model("7B", "cuda", torch.float16, n_layer=6)
     ths = G.apply_sparsity(model, sparsity=0.5, hist_path=None, greedy_lookup=None, synthetic=True)
     model.max_seq_length = -1

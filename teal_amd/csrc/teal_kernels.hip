@@ -228,7 +228,8 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
     // Block b runs on XCD b % 8, so with tile = b % ntiles every XCD would only ever touch one
     // residue class (mod 8) of column tiles, i.e. of DRAM channels; XOR-ing the low 3 tile bits with
     // the next 3 keeps the set of tiles in flight identical but spreads each XCD over all residues.
-    if (p.swizzle && tile < (p.ntiles & ~7)) tile = (tile & ~7) | ((tile ^ (tile >> 3)) & 7);
+    if (p.swizzle == 1 && tile < (p.ntiles & ~7)) tile = (tile & ~7) | ((tile ^ (tile >> 3)) & 7);
+    if (p.swizzle >= 8 && tile < (p.ntiles & ~7)) tile = (tile & ~7) | ((tile + (p.swizzle - 8)) & 7);  // diagnostic rotation
 
     int s = 0;
     if (p.nseg > 1 && tile >= p.seg[1].tile0) s = 1;
@@ -1093,7 +1094,7 @@ int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll) {
 }
 
 int teal_set_swizzle(int on) {
-    g_swizzle = on ? 1 : 0;
+    g_swizzle = on;
     return TEAL_OK;
 }
 
@@ -1132,8 +1133,15 @@ int teal_compact(const void* x, float tau, int Z, int dtype, int32_t* idx_out, i
 int teal_sparse_qkv_gemv(const void* x, const void* wT, void* y, float tau_q, float tau_k,
                          float tau_v, int Z, int N, int N_q, int N_kv, int dtype, void* ws,
                          size_t ws_bytes, void* stream) {
+    return teal_sparse_qkv_gemv_ld(x, wT, N, y, tau_q, tau_k, tau_v, Z, N, N_q, N_kv, dtype, ws, ws_bytes, stream);
+}
+
+int teal_sparse_qkv_gemv_ld(const void* x, const void* wT, int ld, void* y, float tau_q, float tau_k,
+                            float tau_v, int Z, int N, int N_q, int N_kv, int dtype, void* ws,
+                            size_t ws_bytes, void* stream) {
     int rc = check_common(x, wT, y, Z, N, dtype);
     if (rc != TEAL_OK) return rc;
+    if (ld < N || (ld & 7)) return TEAL_ERR_SHAPE;
     if (N_q < 0 || N_kv < 0 || N_q + N_kv > N || (N_q & 7) || (N_kv & 7)) return TEAL_ERR_SHAPE;
     Params p = {};
     p.x = x;
@@ -1147,7 +1155,7 @@ int teal_sparse_qkv_gemv(const void* x, const void* wT, void* y, float tau_q, fl
             sgm.w = wT;
             sgm.y = reinterpret_cast<uint16_t*>(y) + col;
             sgm.tau = taus[i];
-            sgm.ld = N;
+            sgm.ld = ld;
             sgm.col0 = col;
             sgm.ncols = widths[i];
         }

@@ -115,24 +115,24 @@ class DecodeEngine:
             k1_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=(m.tok_embeddings.weight.data_ptr() if i == 0 else A.data_ptr()),
                            slabs=(None if i == 0 else self.s_down.data_ptr()), nslabs=0,
                            norm_weight=layer.attention_norm.weight.data_ptr(), eps=self.eps, resid_out=B.data_ptr())
-            wq = at.wqkv.weight.data_ptr()
-            k1_out = _out([(wq, nq, 0, dim, th["q"], self.qkv.data_ptr()),
-                           (wq, nq, dim, kv, th["k"], self.qkv.data_ptr() + 2 * dim),
-                           (wq, nq, dim + kv, kv, th["v"], self.qkv.data_ptr() + 2 * (dim + kv))], TEAL_OUT_ROUNDED)
+            wq, ldq = at.wqkv.weight.data_ptr(), at.wqkv.weight.stride(1)
+            k1_out = _out([(wq, ldq, 0, dim, th["q"], self.qkv.data_ptr()),
+                           (wq, ldq, dim, kv, th["k"], self.qkv.data_ptr() + 2 * dim),
+                           (wq, ldq, dim + kv, kv, th["v"], self.qkv.data_ptr() + 2 * (dim + kv))], TEAL_OUT_ROUNDED)
             k3_in = GemvIn(mode=TEAL_IN_PLAIN, x=self.y_attn.data_ptr())
-            k3_out = _out([(at.wo.weight.data_ptr(), dim, 0, dim, th["o"], None)], TEAL_OUT_SLABS, self.s_wo)
+            k3_out = _out([(at.wo.weight.data_ptr(), at.wo.weight.stride(1), 0, dim, th["o"], None)], TEAL_OUT_SLABS, self.s_wo)
             k4_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=B.data_ptr(), slabs=self.s_wo.data_ptr(), nslabs=0,
                            norm_weight=layer.ffn_norm.weight.data_ptr(), eps=self.eps, resid_out=A.data_ptr())
-            k4_out = _out([(ff.w1.weight.data_ptr(), inter, 0, inter, th["gate"], self.gu.data_ptr()),
-                           (ff.w3.weight.data_ptr(), inter, 0, inter, th["up"], self.gu.data_ptr() + 2 * inter)], TEAL_OUT_ROUNDED)
+            k4_out = _out([(ff.w1.weight.data_ptr(), ff.w1.weight.stride(1), 0, inter, th["gate"], self.gu.data_ptr()),
+                           (ff.w3.weight.data_ptr(), ff.w3.weight.stride(1), 0, inter, th["up"], self.gu.data_ptr() + 2 * inter)], TEAL_OUT_ROUNDED)
             k5_in = GemvIn(mode=TEAL_IN_SILU_MUL, x=self.gu.data_ptr())
-            k5_out = _out([(ff.w2.weight.data_ptr(), dim, 0, dim, th["down"], None)], TEAL_OUT_SLABS, self.s_down)
+            k5_out = _out([(ff.w2.weight.data_ptr(), ff.w2.weight.stride(1), 0, dim, th["down"], None)], TEAL_OUT_SLABS, self.s_down)
             kc, vc = at.kv_cache.k_cache, at.kv_cache.v_cache
             assert kc.is_contiguous() and kc.shape[0] == 1 and kc.shape[2] == self.max_seq
             self.stages.append((k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out))
         self.head_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=A.data_ptr(), slabs=self.s_down.data_ptr(), nslabs=0,
                               norm_weight=m.norm.weight.data_ptr(), eps=self.eps, resid_out=None)
-        self.head_out = _out([(m.output.weight.data_ptr(), self.cfg.vocab_size, 0, self.cfg.vocab_size, float("-inf"),
+        self.head_out = _out([(m.output.weight.data_ptr(), m.output.weight.stride(1), 0, self.cfg.vocab_size, float("-inf"),
                                self.logits.data_ptr())], TEAL_OUT_ROUNDED)
 
     def _gemv(self, gin: GemvIn, gout: GemvOut, Z: int, nslabs_out=None):

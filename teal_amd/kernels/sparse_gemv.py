@@ -30,8 +30,9 @@ def _prep(x: torch.Tensor, weight: torch.Tensor):
     assert weight.stride(1) > 1, "weight should be column major"
     if not x.is_cuda or not weight.is_cuda:
         raise RuntimeError("teal_amd sparse GEMV runs on the GPU only (HIP kernels; there is no CPU fallback)")
-    if weight.stride(0) != 1 or weight.stride(1) != N:
-        raise RuntimeError("weight must be the reference's column-major layout: weight.T.contiguous().T, strides (1, N)")
+    if weight.stride(0) != 1 or weight.stride(1) < N or weight.stride(1) % 8:
+        raise RuntimeError("weight must be the reference's column-major layout: weight.T.contiguous().T "
+                           "(strides (1, ld) with ld >= N, ld % 8 == 0)")
     if weight.dtype != x.dtype:
         raise TypeError(f"x ({x.dtype}) and weight ({weight.dtype}) must share a dtype")
     x = x.contiguous()
@@ -50,8 +51,9 @@ def splitk_sparse_gemv(x: torch.Tensor, weight: torch.Tensor, threshold: float, 
         raise RuntimeError("splitk_sparse_gemv is the single-token path: x must be [1, 1, Z] "
                            "(the reference kernel only implements BATCHSIZE == 1)")
     y = torch.empty(B, S, N, device=x.device, dtype=x.dtype)
-    rc = L.teal_sparse_gemv(x.data_ptr(), weight.data_ptr(), y.data_ptr(), float(threshold), Z, N, code,
-                            ws.data_ptr(), ws.numel() * 4, runtime.stream_ptr())
+    t = float(threshold)
+    rc = L.teal_sparse_qkv_gemv_ld(x.data_ptr(), weight.data_ptr(), weight.stride(1), y.data_ptr(), t, t, t, Z, N, N, 0,
+                                   code, ws.data_ptr(), ws.numel() * 4, runtime.stream_ptr())
     _lib.check(rc, "teal_sparse_gemv")
     return y
 
@@ -65,9 +67,9 @@ def qkv_gemv(x: torch.Tensor, weight: torch.Tensor, threshold_q: float, threshol
         raise RuntimeError("qkv_gemv is the single-token path: x must be [1, 1, Z]")
     N_q = N - 2 * kv_size
     y = torch.empty(B, S, N, device=x.device, dtype=x.dtype)
-    rc = L.teal_sparse_qkv_gemv(x.data_ptr(), weight.data_ptr(), y.data_ptr(), float(threshold_q),
-                                float(threshold_k), float(threshold_v), Z, N, N_q, kv_size, code,
-                                ws.data_ptr(), ws.numel() * 4, runtime.stream_ptr())
+    rc = L.teal_sparse_qkv_gemv_ld(x.data_ptr(), weight.data_ptr(), weight.stride(1), y.data_ptr(), float(threshold_q),
+                                   float(threshold_k), float(threshold_v), Z, N, N_q, kv_size, code,
+                                   ws.data_ptr(), ws.numel() * 4, runtime.stream_ptr())
     _lib.check(rc, "teal_sparse_qkv_gemv")
     return y
 
@@ -79,8 +81,9 @@ def dense_gemv(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     if B * S != 1:
         return torch.matmul(x, weight.T)
     y = torch.empty(B, S, N, device=x.device, dtype=x.dtype)
-    rc = L.teal_dense_gemv(x.data_ptr(), weight.data_ptr(), y.data_ptr(), Z, N, code, ws.data_ptr(),
-                           ws.numel() * 4, runtime.stream_ptr())
+    ninf = float("-inf")
+    rc = L.teal_sparse_qkv_gemv_ld(x.data_ptr(), weight.data_ptr(), weight.stride(1), y.data_ptr(), ninf, ninf, ninf, Z, N, N, 0,
+                                   code, ws.data_ptr(), ws.numel() * 4, runtime.stream_ptr())
     _lib.check(rc, "teal_dense_gemv")
     return y
 
@@ -92,6 +95,8 @@ def sparse_gateup_silu(x: torch.Tensor, w1: torch.Tensor, w3: torch.Tensor, thre
     L, x, N, Z, code, ws = _prep(x, w1)
     if w3.shape != w1.shape or w3.stride() != w1.stride() or w3.dtype != w1.dtype:
         raise RuntimeError("w1 and w3 must have identical shape, layout and dtype")
+    if w1.stride(1) != N:
+        raise RuntimeError("sparse_gateup_silu takes unpadded weights (strides (1, N)); the engine handles padded rows")
     B, S, _ = x.shape
     if B * S != 1:
         raise RuntimeError("sparse_gateup_silu is the single-token path: x must be [1, 1, Z]")

@@ -38,13 +38,27 @@ def layer_thresholds(layer_idx: int, hist_path: str, sparsities: Dict[str, Seque
     return out
 
 
-def to_column_major(linear: torch.nn.Linear) -> None:
-    """weight.data = weight.data.T.contiguous().T : shape stays [N, Z], memory becomes W^T [Z][N]
-    (gpt-fast/generate.py:296-317)."""
+ROW_PAD = 64  # elements (128 B): see to_column_major
+
+
+def to_column_major(linear: torch.nn.Linear, pad: int = ROW_PAD) -> None:
+    """weight.data = weight.data.T.contiguous().T : shape stays [N, Z], memory becomes W^T [Z][ld]
+    (gpt-fast/generate.py:296-317), here with a row stride ld = N + pad.
+
+    Why pad: with ld = N every row of W^T starts at a multiple of 1024 B for all Llama shapes, so a
+    workgroup's 128-byte column tile always lands in the same 128-B address residue = the same DRAM
+    channel group for every row; on MI355X one such group is ~25 % slower and the workgroups bound to it
+    finish last.  ld = N + 64 rotates the residue row by row (measured: qkv 15.8 -> 13.7 us, gate 14.7 ->
+    13.0 us per launch, profiles/r01_ld_padding.txt).  The reference's own contract only asks for
+    `weight.stride(1) > 1` (kernels/sparse_gemv.py:106), which a padded view satisfies."""
     w = linear.weight.data
-    if w.stride(0) == 1 and w.stride(1) == w.shape[0]:
+    N, Z = w.shape
+    ld = N + pad
+    if w.stride(0) == 1 and w.stride(1) == ld:
         return
-    linear.weight.data = w.T.contiguous().T
+    buf = torch.zeros(Z, ld, dtype=w.dtype, device=w.device)
+    buf[:, :N] = w.T
+    linear.weight.data = buf[:, :N].T
 
 
 def monkeypatch_layer(layer_idx: int, layer, sparsity, hist_path: Optional[str], device: str = "cuda", *,

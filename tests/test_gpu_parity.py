@@ -261,6 +261,27 @@ def test_hipgraph_capture_and_replay(oracle):
     assert torch.equal(out.view(torch.int16), want.view(torch.int16))
 
 
+def test_padded_row_stride_equals_unpadded(oracle):
+    """weights with strides (1, N + 64) (what monkeypatch_layer installs) give the same bits as (1, N)."""
+    Z, N = 4096, 4096
+    xb = oracle.hash_uniform(Z, 61, 4.0, 0)
+    wb = oracle.hash_uniform_c(Z * N, 62, 0.08, 0)
+    x = torch_from_bits(xb, 0, DEV).view(1, 1, Z)
+    W = colmajor_weight(wb, Z, N, 0, DEV)
+    buf = torch.zeros(Z, N + 64, device=DEV, dtype=torch.float16)
+    buf[:, :N] = W.T
+    Wp = buf[:, :N].T
+    assert Wp.stride() == (1, N + 64)
+    for tau in (1.0, -1.0):
+        a = K().splitk_sparse_gemv(x, W, tau, 0)
+        b = K().splitk_sparse_gemv(x, Wp, tau, 0)
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    q1 = K().qkv_gemv(x, W, 0.5, 1.0, 1.5, 0, 1024)
+    q2 = K().qkv_gemv(x, Wp, 0.5, 1.0, 1.5, 0, 1024)
+    assert torch.equal(q1.view(torch.int16), q2.view(torch.int16))
+    assert torch.equal(K().dense_gemv(x, W).view(torch.int16), K().dense_gemv(x, Wp).view(torch.int16))
+
+
 def test_prefill_falls_back_to_dense_matmul():
     Z, N = 256, 512
     x = torch.randn(1, 5, Z, device=DEV, dtype=torch.float16)

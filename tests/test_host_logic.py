@@ -202,9 +202,10 @@ def test_monkeypatch_layer_installs_reference_attribute_bundle():
     l0 = g["models"]["Llama-2-7B"][0]
     assert (at.thresh_q, at.thresh_o, ff.thresh_up, ff.thresh_down) == (l0["attn_h1"][i5], l0["attn_h2"][i5], l0["mlp_h1"][i5], l0["mlp_h2"][i5])
     # weights re-laid column-major, values unchanged
+    from teal_amd.monkeypatch import ROW_PAD
     for lin in (ff.w1, ff.w3, ff.w2, at.wqkv, at.wo):
         N, Z = lin.weight.shape
-        assert lin.weight.stride() == (1, N)
+        assert lin.weight.stride() == (1, N + ROW_PAD) and lin.weight.stride(1) > 1  # reference: stride(1) > 1
     assert torch.equal(ff.w1.weight, w1_before)
     # forwards swapped; old ones kept (model.py:222-224,270-272)
     assert hasattr(ff, "old_forward") and hasattr(at, "old_forward")
