@@ -202,7 +202,8 @@ def roofline_engine_gateup(eng, a):
         x = (xn * m.layers[i].ffn_norm.weight).float().abs()
         nnz_g = int((x > k4_out.tau[0]).sum())
         nnz_u = int((x > k4_out.tau[1]).sum())
-        total_bytes += (nnz_g + nnz_u) * N * 2 + Z * 2 + ns * Z * 4 + Z * 2 + 2 * N * 2
+        out_bytes = (N * 2 + N // 8) if eng.pair else 2 * N * 2  # h (+ keep masks) vs gate|up
+        total_bytes += (nnz_g + nnz_u) * N * 2 + Z * 2 + ns * Z * 4 + Z * 2 + out_bytes
         gin = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=B.data_ptr(), slabs=eng.s_wo.data_ptr(), nslabs=ns,
                      norm_weight=m.layers[i].ffn_norm.weight.data_ptr(), eps=eng.eps, resid_out=None)
         launches.append((gin, k4_out))
@@ -235,14 +236,17 @@ def roofline_engine_gateup(eng, a):
     n = len(launches)
     cfgv = (ctypes.c_int * 5)()
     eng.L.teal_get_config(Z, 2 * N, 2, cfgv)
+    if eng.pair:  # PAIR geometry (run_gemv): widest tile that still gives >= 2/3 of the CUs a tile, else 64 columns
+        ncu = runtime.init()
+        cfgv[0] = next((l for l in (64, 32, 16) if ((N + l * 8 - 1) // (l * 8)) * 3 >= ncu * 2), 8)
+        cfgv[3] = 4
     owned = ((Z + 63) // 64 + 15) // 16
     krt = 4 if owned <= 4 else (8 if owned <= 8 else 16)
-    kname = f"sparse_gemv_kernel<{cfgv[0]},16,{cfgv[3]},{'true' if eng.code else 'false'},1,{krt}>"
+    kname = f"sparse_gemv_kernel<{cfgv[0]},16,{cfgv[3]},{'true' if eng.code else 'false'},1,{krt},{'true' if eng.pair else 'false'}>"
     traffic, tsrc = pmc_traffic(kname)
     return {"bound": "hbm", "achieved": total_bytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": total_bytes / t / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
-            "kernel": f"sparse_gemv_kernel<{cfgv[0]}, 16, {cfgv[3]}, {'true' if eng.code else 'false'}, 1, {krt}> "
-                      f"(fused RMSNorm -> mask -> gate|up GEMV, Z={Z}, N=2x{N})",
+            "kernel": kname + f" (fused RMSNorm -> mask -> gate|up GEMV{' -> silu*mul' if eng.pair else ''}, Z={Z}, N=2x{N})",
             "algorithmic_bytes": total_bytes / n, "us_per_launch": t / n * 1e6, "launches_timed": n,
             "timing": "HIP events (launch stream) around a hipGraph of one launch per layer with that layer's weights; "
                       "per-launch time includes the same-stream launch boundary, like rocprofv3's per-dispatch duration"}

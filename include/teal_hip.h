@@ -110,8 +110,14 @@ int teal_sparse_gateup_silu(const void* x, const void* w1T, const void* w3T, voi
 #define TEAL_IN_PLAIN 0      /* x given as is */
 #define TEAL_IN_RESID_NORM 1 /* x = RMSNorm(resid + round(sum slabs)) * w   (model.py:158-161, 289-291) */
 #define TEAL_IN_SILU_MUL 2   /* x = silu(gate) * up, gate|up contiguous [2Z] (model.py:258-259) */
+#define TEAL_IN_MASKED 3     /* x given together with its keep masks (one uint64 per 64 elements, bit i =
+                              * element 64*c+i kept) as emitted by the producing launch: the consumer skips
+                              * the compare/ballot phase.  The masks must be those of tau[0]. */
 #define TEAL_OUT_ROUNDED 0   /* y rounded to dtype (runs the ordered slab reduce when split-K is used) */
 #define TEAL_OUT_SLABS 1     /* leave the fp32 split-K slabs for the next launch's RESID_NORM producer */
+#define TEAL_OUT_PAIR_SILU 2 /* nseg == 2 (gate, up of equal shape): every workgroup streams the same column tile
+                              * of both matrices and stores h = silu(gate) * up to y[0] (model.py:258-259); optional
+                              * mask_out[ncols/64] = keep masks of h against mask_tau for a TEAL_IN_MASKED consumer */
 
 typedef struct teal_gemv_in {
     int mode;                 /* TEAL_IN_* */
@@ -123,6 +129,7 @@ typedef struct teal_gemv_in {
     const void* norm_weight;  /* RESID_NORM: RMSNorm weight [Z] */
     float eps;
     void* resid_out;          /* RESID_NORM, optional: updated residual [Z]; must not alias resid_in */
+    const void* masks;        /* MASKED: uint64 [ceil(Z/64)] keep masks of x */
 } teal_gemv_in_t;
 
 typedef struct teal_gemv_out {
@@ -136,6 +143,8 @@ typedef struct teal_gemv_out {
     int mode;            /* TEAL_OUT_* */
     float* slabs;        /* SLABS: destination, fp32 [nslabs][sum ncols] */
     size_t slabs_bytes;
+    void* mask_out;      /* PAIR_SILU, optional: uint64 [ceil(ncols/64)] keep masks of h */
+    float mask_tau;      /* PAIR_SILU: threshold of the consumer (the down projection) */
 } teal_gemv_out_t;
 
 /* One launch: [fused producer] -> mask + compaction -> gathered GEMV over every segment.
@@ -149,6 +158,12 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
  * y = [n_head * head_dim].  head_dim 64 or 128. */
 int teal_decode_attention(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,
                           void* y, int n_head, int n_kv_head, int head_dim, int max_seq, int dtype, void* stream);
+
+/* Same, also emitting the keep masks of y against mask_tau (uint64 [n_head*head_dim/64]) for a
+ * TEAL_IN_MASKED wo projection. */
+int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,
+                                 void* y, void* mask_out, float mask_tau, int n_head, int n_kv_head, int head_dim,
+                                 int max_seq, int dtype, void* stream);
 
 /* Sampling step of the decode loop (gpt-fast/generate.py:49-66): logits / temperature, top-k filter
  * (ties at the pivot kept), softmax, exponential-race multinomial.  rng_state = device uint64[2]

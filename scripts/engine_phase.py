@@ -32,15 +32,15 @@ def main():
         eng(tok, pos)
     torch.cuda.synchronize()
     phase = torch.zeros(2048 * 8, dtype=torch.int64, device="cuda")
-    k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out = eng.stages[3]
+    k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out, _tau_o = eng.stages[3]
     k1_in.nslabs = eng.n_down.value
     k4_in.nslabs = eng.n_wo.value
     print("slabs: wo", eng.n_wo.value, "down", eng.n_down.value)
     names = ["load+norm+ballots (0->1)", "barrier wait (1->6)", "scan/scatter (6->2)", "-", "barrier (2->3)", "rows streamed (3->4)",
              "reduce+store (4->5)"]
     order = [(0, 1), (1, 6), (6, 2), (2, 2), (2, 3), (3, 4), (4, 5)]
-    for tag, gin, gout, Z in (("qkv  [RESID_NORM]", k1_in, k1_out, eng.dim), ("wo   [PLAIN]", k3_in, k3_out, eng.dim),
-                              ("g|u  [RESID_NORM]", k4_in, k4_out, eng.dim), ("down [SILU_MUL]", k5_in, k5_out, eng.inter)):
+    for tag, gin, gout, Z in (("qkv  [RESID_NORM]", k1_in, k1_out, eng.dim), ("wo   [MASKED]", k3_in, k3_out, eng.dim),
+                              ("g|u  [PAIR]", k4_in, k4_out, eng.dim), ("down [MASKED]", k5_in, k5_out, eng.inter)):
         spans, rows = [], []
         for it in range(8):
             # evict the weights from the Infinity Cache between repeats: run the other layers

@@ -57,6 +57,7 @@ struct InSpec {
     const float* slabs;        // mode 1: [nslabs][Z]
     const void* norm_w;        // mode 1: RMSNorm weight [Z]
     void* resid_out;           // mode 1: updated residual, written by workgroup 0
+    const unsigned long long* masks;  // mode 3: keep masks (one per 64 activations) emitted by the producer
     float eps;
 };
 
@@ -72,6 +73,9 @@ struct Params {
     int cap;       // LDS list capacity (entries)
     int to_ws;     // 1: always write fp32 slabs (an epilogue kernel follows)
     int swizzle;   // 1: XOR-swizzle tiles inside aligned groups of 8 (XCD decorrelation)
+    int pair;      // 1: seg[0] = gate, seg[1] = up over the SAME column tile; epilogue silu(g)*u -> seg[0].y
+    unsigned long long* mask_out;  // pair: keep masks of the output vs mask_tau for the next launch (or null)
+    float mask_tau;
     unsigned long long* phase;  // optional: per-workgroup phase timestamps (teal_set_phase_buffer)
     Seg seg[kMaxSeg];
 };
@@ -202,7 +206,7 @@ __device__ __forceinline__ int lane_rank(unsigned long long mask) {
 // ------------------------------------------------------------------------------------------------
 // The sparse GEMV.  grid = ntiles * split workgroups of WAVES*64 threads.
 // ------------------------------------------------------------------------------------------------
-template <int LPR, int WAVES, int U, bool BF16, int MODE, int KRT>
+template <int LPR, int WAVES, int U, bool BF16, int MODE, int KRT, bool PAIR>
 __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p) {
     constexpr int RPW = 64 / LPR;  // rows a wave touches per load instruction
     constexpr int BN = LPR * 8;    // columns per tile (16 B per lane)
@@ -247,7 +251,8 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
     constexpr int PER = 64 / WAVES;  // owned chunks per group of 64 chunks
     constexpr int KR = KRT;
     constexpr int GREG = KR / PER;   // groups of 64 chunks covered by the register cache
-    const float tau = sg.tau;
+    // PAIR: the list is the union of the two keep sets (smaller threshold); see the stream loop
+    const float tau = PAIR ? fminf(p.seg[0].tau, p.seg[1].tau) : sg.tau;
     uint32_t xr[KR];
     int mcl[KR];  // clamped element index of (k, lane)
 #pragma unroll
@@ -325,6 +330,11 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
             xr[k] = (m < Z) ? (uint32_t)float_to_bits<BF16>(xn * bits_to_float(wb[k], BF16)) : 0u;
             if (rout && blockIdx.x == 0 && m < Z) rout[m] = float_to_bits<BF16>(rv[k]);
         }
+    } else if constexpr (MODE == 3) {
+        // masks come from the producer (attention / gate|up epilogue): no compare, no ballot, and —
+        // because nothing here depends on another wave — no barrier before the scatter either
+#pragma unroll
+        for (int k = 0; k < KR; ++k) xr[k] = x[mcl[k]];
     } else if constexpr (MODE == 2) {
         uint32_t gb[KR], ub[KR];
 #pragma unroll
@@ -343,39 +353,48 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
 #pragma unroll
         for (int k = 0; k < KR; ++k) xr[k] = x[mcl[k]];
     }
-    int mycnt = 0;
-#pragma unroll
-    for (int k = 0; k < KR; ++k) {
-        const int c = (k / PER) * 64 + wave + (k % PER) * WAVES;
-        if (c < nch) {
-            const float v = bits_to_float(xr[k], BF16);
-            // NaN propagates like the reference's 0 * NaN on masked rows
-            const bool kp = ((c << 6) + lane < Z) && (keep_rule(v, tau) || (v != v));
+    const unsigned long long* gmask = MODE == 3 ? p.in.masks : masks;  // where chunk masks live
+    if constexpr (MODE != 3) {
+        int mycnt = 0;
+    #pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const int c = (k / PER) * 64 + wave + (k % PER) * WAVES;
+            if (c < nch) {
+                const float v = bits_to_float(xr[k], BF16);
+                // NaN propagates like the reference's 0 * NaN on masked rows
+                const bool kp = ((c << 6) + lane < Z) && (keep_rule(v, tau) || (v != v));
+                const unsigned long long mask = __ballot(kp);
+                if (lane == 0) masks[c] = mask;
+                mycnt += __popcll(mask);
+            }
+        }
+        for (int c = GREG * 64 + wave; c < nch; c += WAVES) {  // long vectors: beyond the register cache
+            const int m = (c << 6) + lane;
+            bool kp = false;
+            if (m < Z) {
+                const float v = bits_to_float(load_act(m), BF16);
+                kp = keep_rule(v, tau) || (v != v);
+            }
             const unsigned long long mask = __ballot(kp);
             if (lane == 0) masks[c] = mask;
             mycnt += __popcll(mask);
         }
+        if (lane == 0) wavecnt[wave] = mycnt;
+        stamp(p, 1);
+        __syncthreads();
+        stamp(p, 6);
     }
-    for (int c = GREG * 64 + wave; c < nch; c += WAVES) {  // long vectors: beyond the register cache
-        const int m = (c << 6) + lane;
-        bool kp = false;
-        if (m < Z) {
-            const float v = bits_to_float(load_act(m), BF16);
-            kp = keep_rule(v, tau) || (v != v);
-        }
-        const unsigned long long mask = __ballot(kp);
-        if (lane == 0) masks[c] = mask;
-        mycnt += __popcll(mask);
-    }
-    if (lane == 0) wavecnt[wave] = mycnt;
-    stamp(p, 1);
-    __syncthreads();
-    stamp(p, 6);
 
     // ---- phase B: every wave scans the chunk popcounts itself (DPP, no second barrier, no serial
     //      wave) and scatters the (row, x) pairs of its own chunks into the LDS list, ascending ------
     int total;
-    {
+    if constexpr (MODE == 3) {
+        int acc = 0;
+        for (int c = lane; c < nch; c += 64) acc += __popcll(gmask[c]);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+        total = __builtin_amdgcn_readfirstlane(acc);
+    } else {
         int t = (lane < WAVES) ? wavecnt[lane] : 0;
         t += __builtin_amdgcn_update_dpp(0, t, 0x111, 0xf, 0xf, false);
         t += __builtin_amdgcn_update_dpp(0, t, 0x112, 0xf, 0xf, false);
@@ -391,7 +410,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         int base = 0;
         auto scatter_group = [&](const int g0, const uint32_t* xg) {
             const int cg = g0 + lane;
-            const int v = (cg < nch) ? __popcll(masks[cg]) : 0;
+            const int v = (cg < nch) ? __popcll(gmask[cg]) : 0;
             const int incl = wave_incl_scan(v, lane);
             const int excl = base + incl - v;
             base += __builtin_amdgcn_readlane(incl, 63);
@@ -403,7 +422,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
                 const int pre = __builtin_amdgcn_readlane(excl, j);
                 const int cnt = __builtin_amdgcn_readlane(v, j);
                 if (pre + cnt <= lo || pre >= hi) continue;  // chunk outside this workgroup's share
-                const unsigned long long mask = masks[c];
+                const unsigned long long mask = gmask[c];
                 if ((mask >> lane) & 1ull) {
                     const int m = (c << 6) + lane;
                     const int pos = pre + lane_rank(mask);
@@ -429,16 +448,26 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
     const char* wp = reinterpret_cast<const char*>(sg.w) +
                      ((size_t)(sg.col0 + (col_ok ? col : 0))) * 2;
     const size_t ldb = (size_t)sg.ld * 2;
+    // PAIR: the up-projection's tile (same columns) streamed with the same list
+    const char* wp2 = PAIR ? reinterpret_cast<const char*>(p.seg[1].w) +
+                                 ((size_t)(p.seg[1].col0 + (col_ok ? col : 0))) * 2 : nullptr;
+    const size_t ldb2 = PAIR ? (size_t)p.seg[1].ld * 2 : 0;
+    // PAIR with two different thresholds (block-wise greedy): the list holds the union (smaller tau);
+    // a row is dropped from one of the two products by zeroing its weights (exactly a masked load)
+    const float tau_g = p.seg[0].tau, tau_u = PAIR ? p.seg[1].tau : 0.0f;
+    const bool two_tau = PAIR && (tau_g != tau_u);
 
-    float acc[8];
+    float acc[8], acc2[PAIR ? 8 : 1];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < (PAIR ? 8 : 1); ++j) acc2[j] = 0.0f;
 
     int eb = wave * RPW;  // wave-uniform list position
     if (col_ok) {
         // full steps: every lane of the wave has U valid entries
         for (; eb + (U - 1) * STRIDE + RPW <= nloc; eb += U * STRIDE) {
-            u32x4 w[U];
+            u32x4 w[U], w2[PAIR ? U : 1];
             float xv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -446,13 +475,28 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
                 xv[u] = bits_to_float(ent & 0xFFFFu, BF16);
                 w[u] = __builtin_nontemporal_load(
                     reinterpret_cast<const u32x4*>(wp + (size_t)(ent >> 16) * ldb));
+                if constexpr (PAIR)
+                    w2[u] = __builtin_nontemporal_load(
+                        reinterpret_cast<const u32x4*>(wp2 + (size_t)(ent >> 16) * ldb2));
+            }
+            if (two_tau) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float ax = fabsf(xv[u]);
+                    const bool nanx = xv[u] != xv[u];
+                    if (!(ax > tau_g || nanx)) w[u] = (u32x4){0u, 0u, 0u, 0u};
+                    if constexpr (PAIR) if (!(ax > tau_u || nanx)) w2[u] = (u32x4){0u, 0u, 0u, 0u};
+                }
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) fma8<BF16>(acc, w[u], xv[u]);
+            for (int u = 0; u < U; ++u) {
+                fma8<BF16>(acc, w[u], xv[u]);
+                if constexpr (PAIR) fma8<BF16>(acc2, w2[u], xv[u]);
+            }
         }
         // tail: clamp the entry index, zero the contribution of clamped lanes
         if (eb < nloc) {
-            u32x4 w[U];
+            u32x4 w[U], w2[PAIR ? U : 1];
             float xv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -464,9 +508,27 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
                     reinterpret_cast<const u32x4*>(wp + (size_t)(ent >> 16) * ldb));
                 if (!ok) t = (u32x4){0u, 0u, 0u, 0u};
                 w[u] = t;
+                if constexpr (PAIR) {
+                    u32x4 t2 = __builtin_nontemporal_load(
+                        reinterpret_cast<const u32x4*>(wp2 + (size_t)(ent >> 16) * ldb2));
+                    if (!ok) t2 = (u32x4){0u, 0u, 0u, 0u};
+                    w2[u] = t2;
+                }
+            }
+            if (two_tau) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float ax = fabsf(xv[u]);
+                    const bool nanx = xv[u] != xv[u];
+                    if (!(ax > tau_g || nanx)) w[u] = (u32x4){0u, 0u, 0u, 0u};
+                    if constexpr (PAIR) if (!(ax > tau_u || nanx)) w2[u] = (u32x4){0u, 0u, 0u, 0u};
+                }
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) fma8<BF16>(acc, w[u], xv[u]);
+            for (int u = 0; u < U; ++u) {
+                fma8<BF16>(acc, w[u], xv[u]);
+                if constexpr (PAIR) fma8<BF16>(acc2, w2[u], xv[u]);
+            }
         }
     }
 
@@ -476,23 +538,61 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
     for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], off);
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc2[j] += __shfl_xor(acc2[j], off);
+        }
     }
     if (lane < LPR) {
         float* r = red + wave * BN + lane * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) r[j] = acc[j];
+        if constexpr (PAIR) {
+            float* r2 = red + (WAVES + wave) * BN + lane * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r2[j] = acc2[j];
+        }
     }
     __syncthreads();
-    for (int t = tid; t < BN; t += T) {
-        const int c = tcol0 + t;
-        if (c >= sg.ncols) break;
-        float sum = 0.0f;
+    if constexpr (PAIR) {
+        // h = silu(gate) * up with the roundings of the unfused sequence (gpt-fast/model.py:258-259),
+        // applied ONCE here instead of in every consumer workgroup; plus the keep masks of h against
+        // the down-projection's threshold, so the consumer skips its compare/ballot phase entirely.
+        static_assert(!PAIR || BN <= WAVES * 64, "one thread per tile column");
+        if (tid < BN) {  // whole waves: BN is a multiple of 64
+            const int c = tcol0 + tid;
+            uint32_t hb = 0u;
+            bool kp = false;
+            if (c < sg.ncols) {
+                float gs = 0.0f, us = 0.0f;
 #pragma unroll
-        for (int wv = 0; wv < WAVES; ++wv) sum += red[wv * BN + t];
-        if (p.split == 1 && !p.to_ws) {
-            reinterpret_cast<uint16_t*>(sg.y)[c] = float_to_bits<BF16>(sum);
-        } else {
-            p.ws[(size_t)slice * p.ws_ld + sg.ws_off + c] = sum;
+                for (int wv = 0; wv < WAVES; ++wv) {
+                    gs += red[wv * BN + tid];
+                    us += red[(WAVES + wv) * BN + tid];
+                }
+                const float g16 = bits_to_float(float_to_bits<BF16>(gs), BF16);
+                const float u16 = bits_to_float(float_to_bits<BF16>(us), BF16);
+                const float sl = bits_to_float(float_to_bits<BF16>(g16 / (1.0f + expf(-g16))), BF16);
+                hb = float_to_bits<BF16>(sl * u16);
+                reinterpret_cast<uint16_t*>(sg.y)[c] = (uint16_t)hb;
+                const float hv = bits_to_float(hb, BF16);
+                kp = keep_rule(hv, p.mask_tau) || (hv != hv);
+            }
+            const unsigned long long mk = __ballot(kp);
+            if (p.mask_out && lane == 0) p.mask_out[(tcol0 >> 6) + (tid >> 6)] = mk;
+        }
+    } else {
+        for (int t = tid; t < BN; t += T) {
+            const int c = tcol0 + t;
+            if (c >= sg.ncols) break;
+            float sum = 0.0f;
+#pragma unroll
+            for (int wv = 0; wv < WAVES; ++wv) sum += red[wv * BN + t];
+            if (p.split == 1 && !p.to_ws) {
+                reinterpret_cast<uint16_t*>(sg.y)[c] = float_to_bits<BF16>(sum);
+            } else {
+                p.ws[(size_t)slice * p.ws_ld + sg.ws_off + c] = sum;
+            }
         }
     }
     stamp(p, 5);
@@ -567,6 +667,7 @@ template <bool BF16, int NT>
 __global__ __launch_bounds__(NT) void decode_attention_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ rope, const int* __restrict__ pos_ptr,
     uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache, uint16_t* __restrict__ y,
+    unsigned long long* __restrict__ mask_out, const float mask_tau,
     const int n_head, const int n_kv, const int hd, const int max_seq, const float scale) {
     constexpr int NW = NT / 64;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -691,11 +792,17 @@ __global__ __launch_bounds__(NT) void decode_attention_kernel(
         for (int j = 0; j < 8; ++j) part[wave * hd + lane * 8 + j] = o[j];
     }
     __syncthreads();
-    if (tid < hd) {
+    if (tid < hd) {  // whole waves (hd = 64 or 128)
         float acc = 0.0f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) acc += part[w * hd + tid];
-        y[(size_t)h * hd + tid] = float_to_bits<BF16>(acc);
+        const uint16_t yb = float_to_bits<BF16>(acc);
+        y[(size_t)h * hd + tid] = yb;
+        if (mask_out) {  // keep masks of y for the wo projection (TEAL_IN_MASKED consumer)
+            const float yv = bits_to_float(yb, BF16);
+            const unsigned long long mk = __ballot(keep_rule(yv, mask_tau) || (yv != yv));
+            if (lane == 0) mask_out[((size_t)h * hd + tid) >> 6] = mk;
+        }
     }
 }
 
@@ -858,9 +965,9 @@ int g_swizzle = 0;
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-size_t lds_bytes(int Z, int cap, int waves, int lpr) {
+size_t lds_bytes(int Z, int cap, int waves, int lpr, bool pair = false) {
     const int nch = (Z + 63) >> 6;
-    return (size_t)nch * 8 + 128 + (size_t)cap * 4 + (size_t)waves * lpr * 8 * 4;
+    return (size_t)nch * 8 + 128 + (size_t)cap * 4 + (size_t)waves * lpr * 8 * 4 * (pair ? 2 : 1);
 }
 
 int count_tiles(const Params& p, int bn) {
@@ -912,36 +1019,38 @@ Config pick_config(int Z, int ncols_total, int nseg_tiles_hint) {
     return c;
 }
 
-template <int LPR, int WAVES, int U, int MODE, int KRT>
+template <int LPR, int WAVES, int U, int MODE, int KRT, bool PAIR>
 hipError_t launch_gemv_k(const Params& p, int dtype, size_t lds, hipStream_t st) {
     const dim3 grid(p.ntiles * p.split), block(WAVES * 64);
     if (dtype == TEAL_BF16)
-        hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, true, MODE, KRT>), grid, block, lds, st, p);
+        hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, true, MODE, KRT, PAIR>), grid, block, lds, st, p);
     else
-        hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, false, MODE, KRT>), grid, block, lds, st, p);
+        hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, false, MODE, KRT, PAIR>), grid, block, lds, st, p);
     return hipGetLastError();
 }
 
 // register-cache depth: smallest KRT with KRT * WAVES * 64 >= Z (16-wave production geometry);
-// longer vectors use KRT = 16 plus the reload path (plain / silu-mul producers only)
-template <int LPR, int WAVES, int U, int MODE>
+// longer vectors use KRT = 16 plus the reload path (plain / silu-mul / masked producers only)
+template <int LPR, int WAVES, int U, int MODE, bool PAIR>
 hipError_t launch_gemv_m(const Params& p, int dtype, size_t lds, hipStream_t st) {
     if constexpr (WAVES == 16) {
         const int owned = (((p.Z + 63) >> 6) + WAVES - 1) / WAVES;
-        if (owned <= 4) return launch_gemv_k<LPR, WAVES, U, MODE, 4>(p, dtype, lds, st);
-        if (owned <= 8) return launch_gemv_k<LPR, WAVES, U, MODE, 8>(p, dtype, lds, st);
-        return launch_gemv_k<LPR, WAVES, U, MODE, 16>(p, dtype, lds, st);
+        if (owned <= 4) return launch_gemv_k<LPR, WAVES, U, MODE, 4, PAIR>(p, dtype, lds, st);
+        if (owned <= 8) return launch_gemv_k<LPR, WAVES, U, MODE, 8, PAIR>(p, dtype, lds, st);
+        return launch_gemv_k<LPR, WAVES, U, MODE, 16, PAIR>(p, dtype, lds, st);
     } else {
-        return launch_gemv_k<LPR, WAVES, U, MODE, 16>(p, dtype, lds, st);
+        return launch_gemv_k<LPR, WAVES, U, MODE, 16, PAIR>(p, dtype, lds, st);
     }
 }
 
 template <int LPR, int WAVES, int U>
 hipError_t launch_gemv_t(const Params& p, int dtype, size_t lds, hipStream_t st) {
-    if (p.in.mode == 0) return launch_gemv_m<LPR, WAVES, U, 0>(p, dtype, lds, st);
-    if constexpr (WAVES == 16) {  // fused producers are built for the production geometry only
-        if (p.in.mode == 1) return launch_gemv_m<LPR, WAVES, U, 1>(p, dtype, lds, st);
-        if (p.in.mode == 2) return launch_gemv_m<LPR, WAVES, U, 2>(p, dtype, lds, st);
+    if (p.in.mode == 0 && !p.pair) return launch_gemv_m<LPR, WAVES, U, 0, false>(p, dtype, lds, st);
+    if constexpr (WAVES == 16 && U == 4) {  // fused variants are built for the production geometry only
+        if (p.pair) return p.in.mode == 1 ? launch_gemv_m<LPR, WAVES, U, 1, true>(p, dtype, lds, st) : hipErrorInvalidValue;
+        if (p.in.mode == 1) return launch_gemv_m<LPR, WAVES, U, 1, false>(p, dtype, lds, st);
+        if (p.in.mode == 2) return launch_gemv_m<LPR, WAVES, U, 2, false>(p, dtype, lds, st);
+        if (p.in.mode == 3) return launch_gemv_m<LPR, WAVES, U, 3, false>(p, dtype, lds, st);
     }
     return hipErrorInvalidValue;
 }
@@ -993,18 +1102,31 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
         c.split = split;
         while ((size_t)((p.Z + c.split - 1) / c.split) * 4 > 40 * 1024 && c.split < kMaxSplit) ++c.split;
     }
-    if (p.in.mode != 0) {  // fused producers exist for 16-wave workgroups
+    if (p.in.mode != 0 || p.pair) {  // fused variants exist for 16-wave workgroups, unroll 4
         c.waves = 16;
+        c.unroll = 4;
         if (p.in.mode == 1 && p.Z > 16 * 64 * 16) return TEAL_ERR_SHAPE;  // register-resident norm
+    }
+    if (p.pair) {  // both matrices in one workgroup; the activation needs complete sums: no split-K
+        c.split = 1;
+        if ((size_t)(p.Z + 1) * 4 > 44 * 1024) return TEAL_ERR_SHAPE;
+        if (!g_override.lpr) {
+            const int ncu = g_num_cu > 0 ? g_num_cu : 256;
+            const int n1 = p.seg[0].ncols;
+            c.lpr = 8;
+            for (int lpr = 64; lpr > 8; lpr >>= 1)  // widest tile that still gives >= 2/3 of the CUs a tile
+                if (((n1 + lpr * 8 - 1) / (lpr * 8)) * 3 >= ncu * 2) { c.lpr = lpr; break; }
+        }
     }
     const int bn = c.lpr * 8;
     int t = 0, off = 0;
-    for (int i = 0; i < p.nseg; ++i) {
+    for (int i = 0; i < (p.pair ? 1 : p.nseg); ++i) {
         p.seg[i].tile0 = t;
         p.seg[i].ws_off = off;
         t += (p.seg[i].ncols + bn - 1) / bn;
         off += p.seg[i].ncols;
     }
+    if (p.pair) p.nseg = 1;  // tile space = the gate columns; seg[1] rides along
     p.ntiles = t;
     p.split = c.split;
     p.ws_ld = off;
@@ -1013,7 +1135,7 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
     p.ws = reinterpret_cast<float*>(ws);
     p.phase = g_phase;
     p.swizzle = g_swizzle;
-    const size_t lds = lds_bytes(p.Z, p.cap, c.waves, c.lpr);
+    const size_t lds = lds_bytes(p.Z, p.cap, c.waves, c.lpr, p.pair != 0);
     if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
     if (c.split > 1 || to_ws) {
         if (!ws || ws_bytes < (size_t)c.split * off * sizeof(float)) return TEAL_ERR_WORKSPACE;
@@ -1215,6 +1337,11 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
             if (!in->x) return TEAL_ERR_ARG;
             p.x = in->x;
             break;
+        case TEAL_IN_MASKED:
+            if (!in->x || !in->masks) return TEAL_ERR_ARG;
+            p.x = in->x;
+            p.in.masks = reinterpret_cast<const unsigned long long*>(in->masks);
+            break;
         case TEAL_IN_RESID_NORM:
             if (!in->resid_in || !in->norm_weight || in->nslabs < 0 || (in->nslabs > 0 && !in->slabs)) return TEAL_ERR_ARG;
             if (in->resid_out == in->resid_in && !in->row_index) return TEAL_ERR_ARG;  // must ping-pong
@@ -1244,7 +1371,14 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     Config used = {};
     int rc;
-    if (out->mode == TEAL_OUT_SLABS) {
+    if (out->mode == TEAL_OUT_PAIR_SILU) {
+        // seg 0 = gate (w1), seg 1 = up (w3), same shape; y[0] receives h = silu(gate) * up
+        if (out->nseg != 2 || in->mode != TEAL_IN_RESID_NORM || out->ncols[0] != out->ncols[1] || !out->y[0]) return TEAL_ERR_ARG;
+        p.pair = 1;
+        p.mask_out = reinterpret_cast<unsigned long long*>(out->mask_out);
+        p.mask_tau = out->mask_tau;
+        rc = run_gemv(p, dtype, ws, ws_bytes, false, st, &used, false);
+    } else if (out->mode == TEAL_OUT_SLABS) {
         if (!out->slabs) return TEAL_ERR_ARG;
         rc = run_gemv(p, dtype, out->slabs, out->slabs_bytes, true, st, &used, true);
     } else if (out->mode == TEAL_OUT_ROUNDED) {
@@ -1256,8 +1390,9 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
     return rc;
 }
 
-int teal_decode_attention(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,
-                          void* y, int n_head, int n_kv_head, int head_dim, int max_seq, int dtype, void* stream) {
+int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,
+                                 void* y, void* mask_out, float mask_tau, int n_head, int n_kv_head, int head_dim,
+                                 int max_seq, int dtype, void* stream) {
     if (!qkv || !rope || !pos || !k_cache || !v_cache || !y) return TEAL_ERR_ARG;
     if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
     if ((head_dim != 64 && head_dim != 128) || n_head <= 0 || n_kv_head <= 0 || n_head % n_kv_head || max_seq <= 0)
@@ -1273,11 +1408,18 @@ int teal_decode_attention(const void* qkv, const void* rope, const int32_t* pos,
     auto* kc = reinterpret_cast<uint16_t*>(k_cache);
     auto* vc = reinterpret_cast<uint16_t*>(v_cache);
     auto* yo = reinterpret_cast<uint16_t*>(y);
+    auto* mo = reinterpret_cast<unsigned long long*>(mask_out);
     if (dtype == TEAL_BF16)
-        hipLaunchKernelGGL((decode_attention_kernel<true, NT>), grid, block, lds, st, q, r, pos, kc, vc, yo, n_head, n_kv_head, head_dim, max_seq, scale);
+        hipLaunchKernelGGL((decode_attention_kernel<true, NT>), grid, block, lds, st, q, r, pos, kc, vc, yo, mo, mask_tau, n_head, n_kv_head, head_dim, max_seq, scale);
     else
-        hipLaunchKernelGGL((decode_attention_kernel<false, NT>), grid, block, lds, st, q, r, pos, kc, vc, yo, n_head, n_kv_head, head_dim, max_seq, scale);
+        hipLaunchKernelGGL((decode_attention_kernel<false, NT>), grid, block, lds, st, q, r, pos, kc, vc, yo, mo, mask_tau, n_head, n_kv_head, head_dim, max_seq, scale);
     return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
+}
+
+int teal_decode_attention(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,
+                          void* y, int n_head, int n_kv_head, int head_dim, int max_seq, int dtype, void* stream) {
+    return teal_decode_attention_masked(qkv, rope, pos, k_cache, v_cache, y, nullptr, 0.0f, n_head, n_kv_head, head_dim,
+                                        max_seq, dtype, stream);
 }
 
 int teal_sample_topk(const void* logits, int vocab, int dtype, int top_k, float temperature, void* rng_state,

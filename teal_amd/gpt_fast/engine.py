@@ -28,22 +28,23 @@ from .. import _lib, runtime
 from ..monkeypatch import to_column_major
 from .model import Transformer
 
-TEAL_IN_PLAIN, TEAL_IN_RESID_NORM, TEAL_IN_SILU_MUL = 0, 1, 2
-TEAL_OUT_ROUNDED, TEAL_OUT_SLABS = 0, 1
+TEAL_IN_PLAIN, TEAL_IN_RESID_NORM, TEAL_IN_SILU_MUL, TEAL_IN_MASKED = 0, 1, 2, 3
+TEAL_OUT_ROUNDED, TEAL_OUT_SLABS, TEAL_OUT_PAIR_SILU = 0, 1, 2
 MAX_SLABS = 32
 
 
 class GemvIn(ctypes.Structure):  # teal_gemv_in_t
     _fields_ = [("mode", ctypes.c_int), ("x", ctypes.c_void_p), ("resid_in", ctypes.c_void_p),
                 ("row_index", ctypes.c_void_p), ("slabs", ctypes.c_void_p), ("nslabs", ctypes.c_int),
-                ("norm_weight", ctypes.c_void_p), ("eps", ctypes.c_float), ("resid_out", ctypes.c_void_p)]
+                ("norm_weight", ctypes.c_void_p), ("eps", ctypes.c_float), ("resid_out", ctypes.c_void_p),
+                ("masks", ctypes.c_void_p)]
 
 
 class GemvOut(ctypes.Structure):  # teal_gemv_out_t
     _fields_ = [("nseg", ctypes.c_int), ("w", ctypes.c_void_p * 3), ("ld", ctypes.c_int * 3),
                 ("col0", ctypes.c_int * 3), ("ncols", ctypes.c_int * 3), ("tau", ctypes.c_float * 3),
                 ("y", ctypes.c_void_p * 3), ("mode", ctypes.c_int), ("slabs", ctypes.c_void_p),
-                ("slabs_bytes", ctypes.c_size_t)]
+                ("slabs_bytes", ctypes.c_size_t), ("mask_out", ctypes.c_void_p), ("mask_tau", ctypes.c_float)]
 
 
 def _out(segs, mode, slabs: Optional[torch.Tensor] = None) -> GemvOut:
@@ -67,7 +68,7 @@ class DecodeEngine:
     (`setup_caches`) are shared: prefill runs through the module path, decode through the engine.
     """
 
-    def __init__(self, model: Transformer, thresholds: List[Dict[str, float]]):
+    def __init__(self, model: Transformer, thresholds: List[Dict[str, float]], pair: Optional[bool] = None):
         self.L = _lib.load()
         runtime.init()
         cfg = model.config
@@ -87,6 +88,12 @@ class DecodeEngine:
         e = lambda *shape, dtype=dt: torch.zeros(*shape, device=dev, dtype=dtype)  # noqa: E731
         self.resid = [e(dim), e(dim)]
         self.qkv, self.y_attn, self.gu = e(self.nqkv), e(dim), e(2 * inter)
+        self.h_mlp = e(inter)                                                  # silu(gate) * up (PAIR epilogue)
+        self.y_mask = e((dim + 63) // 64, dtype=torch.int64)                   # keep masks of y_attn vs tau_o
+        self.h_mask = e((inter + 63) // 64, dtype=torch.int64)                 # keep masks of h_mlp vs tau_down
+        # gate|up as one PAIR launch needs whole 64-column chunks and Z small enough for a single list
+        can_pair = inter % 64 == 0 and dim % 64 == 0 and (dim + 1) * 4 <= 44 * 1024
+        self.pair = can_pair if pair is None else (bool(pair) and can_pair)
         self.s_wo, self.s_down = e(MAX_SLABS, dim, dtype=torch.float32), e(MAX_SLABS, dim, dtype=torch.float32)
         self.logits = e(1, 1, cfg.vocab_size)
         self.ws = runtime.reserve_workspace(max(dim, inter), max(self.nqkv, inter, cfg.vocab_size))
@@ -119,17 +126,25 @@ class DecodeEngine:
             k1_out = _out([(wq, ldq, 0, dim, th["q"], self.qkv.data_ptr()),
                            (wq, ldq, dim, kv, th["k"], self.qkv.data_ptr() + 2 * dim),
                            (wq, ldq, dim + kv, kv, th["v"], self.qkv.data_ptr() + 2 * (dim + kv))], TEAL_OUT_ROUNDED)
-            k3_in = GemvIn(mode=TEAL_IN_PLAIN, x=self.y_attn.data_ptr())
+            k3_in = (GemvIn(mode=TEAL_IN_MASKED, x=self.y_attn.data_ptr(), masks=self.y_mask.data_ptr()) if self.pair
+                     else GemvIn(mode=TEAL_IN_PLAIN, x=self.y_attn.data_ptr()))
             k3_out = _out([(at.wo.weight.data_ptr(), at.wo.weight.stride(1), 0, dim, th["o"], None)], TEAL_OUT_SLABS, self.s_wo)
             k4_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=B.data_ptr(), slabs=self.s_wo.data_ptr(), nslabs=0,
                            norm_weight=layer.ffn_norm.weight.data_ptr(), eps=self.eps, resid_out=A.data_ptr())
             k4_out = _out([(ff.w1.weight.data_ptr(), ff.w1.weight.stride(1), 0, inter, th["gate"], self.gu.data_ptr()),
                            (ff.w3.weight.data_ptr(), ff.w3.weight.stride(1), 0, inter, th["up"], self.gu.data_ptr() + 2 * inter)], TEAL_OUT_ROUNDED)
-            k5_in = GemvIn(mode=TEAL_IN_SILU_MUL, x=self.gu.data_ptr())
+            if self.pair:
+                k4_out = _out([(ff.w1.weight.data_ptr(), ff.w1.weight.stride(1), 0, inter, th["gate"], self.h_mlp.data_ptr()),
+                               (ff.w3.weight.data_ptr(), ff.w3.weight.stride(1), 0, inter, th["up"], None)], TEAL_OUT_PAIR_SILU)
+                k4_out.mask_out = self.h_mask.data_ptr()
+                k4_out.mask_tau = th["down"]
+                k5_in = GemvIn(mode=TEAL_IN_MASKED, x=self.h_mlp.data_ptr(), masks=self.h_mask.data_ptr())
+            else:
+                k5_in = GemvIn(mode=TEAL_IN_SILU_MUL, x=self.gu.data_ptr())
             k5_out = _out([(ff.w2.weight.data_ptr(), ff.w2.weight.stride(1), 0, dim, th["down"], None)], TEAL_OUT_SLABS, self.s_down)
             kc, vc = at.kv_cache.k_cache, at.kv_cache.v_cache
             assert kc.is_contiguous() and kc.shape[0] == 1 and kc.shape[2] == self.max_seq
-            self.stages.append((k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out))
+            self.stages.append((k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out, th["o"]))
         self.head_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=A.data_ptr(), slabs=self.s_down.data_ptr(), nslabs=0,
                               norm_weight=m.norm.weight.data_ptr(), eps=self.eps, resid_out=None)
         self.head_out = _out([(m.output.weight.data_ptr(), m.output.weight.stride(1), 0, self.cfg.vocab_size, float("-inf"),
@@ -148,15 +163,16 @@ class DecodeEngine:
         cfg = self.cfg
         self._stream = runtime.stream_ptr()
         tok_ptr, pos_ptr = idx.data_ptr(), input_pos.data_ptr()
-        for i, (k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out) in enumerate(self.stages):
+        for i, (k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out, tau_o) in enumerate(self.stages):
             if i == 0:
                 k1_in.row_index = tok_ptr
             else:
                 k1_in.nslabs = self.n_down.value
             self._gemv(k1_in, k1_out, self.dim)
-            rc = self.L.teal_decode_attention(self.qkv.data_ptr(), self.rope.data_ptr(), pos_ptr, kc.data_ptr(), vc.data_ptr(),
-                                              self.y_attn.data_ptr(), cfg.n_head, cfg.n_local_heads, cfg.head_dim,
-                                              self.max_seq, self.code, self._stream)
+            rc = self.L.teal_decode_attention_masked(self.qkv.data_ptr(), self.rope.data_ptr(), pos_ptr, kc.data_ptr(), vc.data_ptr(),
+                                                     self.y_attn.data_ptr(), self.y_mask.data_ptr() if self.pair else None, tau_o,
+                                                     cfg.n_head, cfg.n_local_heads, cfg.head_dim, self.max_seq, self.code,
+                                                     self._stream)
             if rc != 0:
                 _lib.check(rc, "teal_decode_attention")
             self._gemv(k3_in, k3_out, self.dim, self.n_wo)

@@ -58,8 +58,9 @@ def test_decode_attention_kernel_vs_torch(dtype):
         assert torch.allclose(y.float(), want, atol=tol, rtol=tol), float((y.float() - want).abs().max())
 
 
+@pytest.mark.parametrize("pair", [True, False])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_engine_matches_module_path_dense_thresholds(dtype):
+def test_engine_matches_module_path_dense_thresholds(dtype, pair):
     """tau = -1 (everything kept): no threshold flips, so the fused step must track the unfused
     module path to rounding for several tokens, including the KV caches it appends to."""
     from teal_amd.gpt_fast.engine import DecodeEngine
@@ -68,7 +69,8 @@ def test_engine_matches_module_path_dense_thresholds(dtype):
     with torch.no_grad():
         for m in (ref, eng_m):
             m(prompt.view(1, -1), torch.arange(6, device=DEV))
-        eng = DecodeEngine(eng_m, ths)
+        eng = DecodeEngine(eng_m, ths, pair=pair)
+        assert eng.pair == pair
         tok = torch.tensor([[11]], device=DEV, dtype=torch.int)
         for step in range(5):
             pos = torch.tensor([6 + step], device=DEV, dtype=torch.int)
@@ -234,3 +236,24 @@ def test_generate_with_engine_decoder():
     prompt = torch.randint(0, 512, (6,), device=DEV, dtype=torch.int)
     y = G.generate(m, prompt, 12, dec, temperature=0.8, top_k=50)
     assert y.numel() == 18 and torch.equal(y[:6], prompt) and int(y.max()) < 512 and int(y.min()) >= 0
+
+
+def test_pair_and_masked_stages_equal_unfused_stages():
+    """PAIR (gate|up in one workgroup + silu*mul epilogue + masks) and MASKED consumers reproduce the
+    SILU_MUL / PLAIN path bit for bit at 50 % with two different gate/up thresholds."""
+    from teal_amd.gpt_fast.engine import DecodeEngine
+    _, m1, ths = _models(torch.float16, 0.5)
+    _, m2, _ = _models(torch.float16, 0.5)
+    for t in ths:  # block-wise-greedy style: gate and up thresholds differ
+        t["up"] = t["gate"] * 0.8
+    prompt = torch.tensor([3, 141, 59, 26, 500, 358], device=DEV, dtype=torch.int)
+    with torch.no_grad():
+        for m in (m1, m2):
+            m(prompt.view(1, -1), torch.arange(6, device=DEV))
+        e1, e2 = DecodeEngine(m1, ths, pair=True), DecodeEngine(m2, ths, pair=False)
+        tok = torch.tensor([[5]], device=DEV, dtype=torch.int)
+        for step in range(4):
+            pos = torch.tensor([6 + step], device=DEV, dtype=torch.int)
+            a, b = e1(tok, pos), e2(tok, pos)
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16)), step
+            tok = a.float().argmax().view(1, 1).to(torch.int)
