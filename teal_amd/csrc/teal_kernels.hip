@@ -663,13 +663,17 @@ __global__ __launch_bounds__(1024) void compact_kernel(const uint16_t* __restric
 // reference's fp16/bf16 tensors: rotated q/k, scores, probabilities and the output are rounded to
 // dtype; accumulation is fp32.
 // ------------------------------------------------------------------------------------------------
-template <bool BF16, int NT>
+template <bool BF16, int NT, int HD>
 __global__ __launch_bounds__(NT) void decode_attention_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ rope, const int* __restrict__ pos_ptr,
     uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache, uint16_t* __restrict__ y,
     unsigned long long* __restrict__ mask_out, const float mask_tau,
-    const int n_head, const int n_kv, const int hd, const int max_seq, const float scale) {
+    const int n_head, const int n_kv, const int max_seq, const float scale) {
     constexpr int NW = NT / 64;
+    constexpr int hd = HD;
+    constexpr int SL = HD / 8;   // 16-byte slices per row (16 for hd=128, 8 for hd=64)
+    constexpr int RW = 64 / SL;  // V rows per wave step (4 or 8)
+    constexpr int VPF = 4;       // V steps prefetched (covers pos < VPF * NW * RW = 256 / 512)
     extern __shared__ __align__(16) unsigned char smem[];
     float* qs = reinterpret_cast<float*>(smem);  // [hd] rotated q
     float* kn = qs + hd;                         // [hd] rotated new k
@@ -688,6 +692,23 @@ __global__ __launch_bounds__(NT) void decode_attention_kernel(
     const uint16_t* vh = qkv + dim + kvs + (size_t)kvh * hd;
     uint16_t* kc = k_cache + (size_t)kvh * max_seq * hd;
     uint16_t* vc = v_cache + (size_t)kvh * max_seq * hd;
+
+    // ---- everything that only depends on `pos` is requested first: this thread's cached K row and
+    //      its V slices are in flight while q/k are rotated (one memory round trip instead of three)
+    u32x4 kreg[SL];
+    const bool have_k = tid < pos;
+    {
+        const u32x4* kr = reinterpret_cast<const u32x4*>(kc + (size_t)(have_k ? tid : 0) * hd);
+#pragma unroll
+        for (int v8 = 0; v8 < SL; ++v8) kreg[v8] = kr[v8];
+    }
+    const int ds = lane % SL, rw = lane / SL;
+    u32x4 vreg[VPF];
+#pragma unroll
+    for (int i = 0; i < VPF; ++i) {
+        const int t = wave * RW + rw + i * NW * RW;
+        vreg[i] = *reinterpret_cast<const u32x4*>(vc + (size_t)(t < pos ? t : 0) * hd + ds * 8);
+    }
 
     // RoPE on interleaved pairs (model.py apply_rotary_emb), table rows are (cos, sin) in dtype
     if (tid < hd / 2) {
@@ -713,8 +734,7 @@ __global__ __launch_bounds__(NT) void decode_attention_kernel(
     }
     __syncthreads();
 
-    // scores: one THREAD per cached position (all rows' 16-byte loads are in flight together);
-    // the new token's own key comes from LDS, not from the cache line being written
+    // scores: one THREAD per cached position; the new token's own key comes from LDS
     float lmax = -INFINITY;
     for (int t0 = 0; t0 <= pos; t0 += NT) {
         const int t = t0 + tid;
@@ -723,10 +743,14 @@ __global__ __launch_bounds__(NT) void decode_attention_kernel(
             if (t == pos) {
                 for (int e = 0; e < hd; ++e) a += qs[e] * kn[e];
             } else {
-                const u32x4* kr = reinterpret_cast<const u32x4*>(kc + (size_t)t * hd);
-#pragma unroll 8
-                for (int v8 = 0; v8 < hd / 8; ++v8) {
-                    const u32x4 w = kr[v8];
+                if (t0 > 0) {  // beyond the prefetched batch
+                    const u32x4* kr = reinterpret_cast<const u32x4*>(kc + (size_t)t * hd);
+#pragma unroll
+                    for (int v8 = 0; v8 < SL; ++v8) kreg[v8] = kr[v8];
+                }
+#pragma unroll
+                for (int v8 = 0; v8 < SL; ++v8) {
+                    const u32x4 w = kreg[v8];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         a += qs[v8 * 8 + 2 * j] * bits_to_float(w[j] & 0xFFFFu, BF16);
@@ -760,28 +784,32 @@ __global__ __launch_bounds__(NT) void decode_attention_kernel(
     for (int w = 0; w < NW; ++w) tot += red[NW + w];
     const float inv = 1.0f / tot;
 
-    // output: 16-byte slices of V rows; lane = (row-in-wave rw, 8-dim slice ds); a wave covers
-    // RW = 64/SL rows per step, the workgroup NW*RW rows
-    const int SL = hd / 8;   // slices per row (16 for hd=128, 8 for hd=64)
-    const int RW = 64 / SL;  // rows per wave step (4 or 8)
-    const int ds = lane % SL, rw = lane / SL;
+    // output: 16-byte slices of V rows; lane = (row-in-wave rw, 8-dim slice ds)
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = 0.0f;
-#pragma unroll 4
-    for (int t = wave * RW + rw; t <= pos; t += NW * RW) {
+    auto accum = [&](const int t, const u32x4 w) {
         const float pr = bits_to_float(float_to_bits<BF16>(sc[t] * inv), BF16);
         if (t == pos) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += pr * vn[ds * 8 + j];
         } else {
-            const u32x4 w = *reinterpret_cast<const u32x4*>(vc + (size_t)t * hd + ds * 8);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 o[2 * j] += pr * bits_to_float(w[j] & 0xFFFFu, BF16);
                 o[2 * j + 1] += pr * bits_to_float(w[j] >> 16, BF16);
             }
         }
+    };
+#pragma unroll
+    for (int i = 0; i < VPF; ++i) {
+        const int t = wave * RW + rw + i * NW * RW;
+        if (t <= pos) accum(t, vreg[i]);
+    }
+#pragma unroll 4
+    for (int t = wave * RW + rw + VPF * NW * RW; t <= pos; t += NW * RW) {
+        const u32x4 w = (t < pos) ? *reinterpret_cast<const u32x4*>(vc + (size_t)t * hd + ds * 8) : (u32x4){0u, 0u, 0u, 0u};
+        accum(t, w);
     }
     for (int off = SL; off < 64; off <<= 1) {
 #pragma unroll
@@ -1409,10 +1437,10 @@ int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_
     auto* vc = reinterpret_cast<uint16_t*>(v_cache);
     auto* yo = reinterpret_cast<uint16_t*>(y);
     auto* mo = reinterpret_cast<unsigned long long*>(mask_out);
-    if (dtype == TEAL_BF16)
-        hipLaunchKernelGGL((decode_attention_kernel<true, NT>), grid, block, lds, st, q, r, pos, kc, vc, yo, mo, mask_tau, n_head, n_kv_head, head_dim, max_seq, scale);
-    else
-        hipLaunchKernelGGL((decode_attention_kernel<false, NT>), grid, block, lds, st, q, r, pos, kc, vc, yo, mo, mask_tau, n_head, n_kv_head, head_dim, max_seq, scale);
+#define TEAL_ATT(BF, HDV) hipLaunchKernelGGL((decode_attention_kernel<BF, NT, HDV>), grid, block, lds, st, q, r, pos, kc, vc, yo, mo, mask_tau, n_head, n_kv_head, max_seq, scale)
+    if (dtype == TEAL_BF16) { if (head_dim == 128) TEAL_ATT(true, 128); else TEAL_ATT(true, 64); }
+    else { if (head_dim == 128) TEAL_ATT(false, 128); else TEAL_ATT(false, 64); }
+#undef TEAL_ATT
     return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
 }
 
