@@ -1007,7 +1007,7 @@ int count_tiles(const Params& p, int bn) {
 // Launch geometry from (Z, columns, CU count).  Deterministic: no autotune at first call.
 // Measured on MI355X (profiles/, scripts/tune_gemv.py): the kernel wants ONE 16-wave workgroup per
 // CU (every workgroup repeats the compaction prologue, so more workgroups only add latency), and
-// a single launch (split == 1) whenever the column tiles alone can occupy >= ~2/3 of the CUs.
+// a single launch (split == 1) whenever the column tiles alone can occupy >= ~60 % of the CUs.
 Config pick_config(int Z, int ncols_total, int nseg_tiles_hint) {
     (void)nseg_tiles_hint;
     const int ncu = g_num_cu > 0 ? g_num_cu : 256;
@@ -1019,7 +1019,7 @@ Config pick_config(int Z, int ncols_total, int nseg_tiles_hint) {
     // widest tile whose tile count still covers most CUs -> no split-K, no second launch
     for (int lpr = 64; lpr >= 8; lpr >>= 1) {
         const int tiles = (ncols_total + lpr * 8 - 1) / (lpr * 8);
-        if (tiles <= ncu + ncu / 8 && tiles * 3 >= ncu * 2) { c.lpr = lpr; break; }
+        if (tiles <= ncu + ncu / 8 && tiles * 5 >= ncu * 3) { c.lpr = lpr; break; }
     }
     if (c.lpr == 0) {
         const int t8 = (ncols_total + 63) / 64;

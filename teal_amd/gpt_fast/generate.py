@@ -142,7 +142,14 @@ def apply_sparsity(model: Transformer, *, sparsity: float, hist_path: Optional[s
                    synthetic: bool) -> List[Dict[str, float]]:
     """monkeypatch every layer (gpt-fast/generate.py:328-331); returns the thresholds used."""
     L = len(model.layers)
-    if greedy_lookup:
+    if greedy_lookup and greedy_lookup.endswith(".json"):
+        # block-wise greedy table captured from the reference (tests/golden/greedy_*.json, generated by
+        # oracle/gen_golden.py from models/<name>/lookup): {"targets": {"0.5": {"sparsities": {proj: [...]}}}}
+        with open(greedy_lookup) as f:
+            table = json.load(f)["targets"][repr(float(sparsity))]["sparsities"]
+        sparsities = {p: [float(v) for v in table[p][:L]] for p in PROJS}
+        assert all(len(v) == L for v in sparsities.values()), "greedy table has fewer layers than the model"
+    elif greedy_lookup:
         sparsities = get_layer_greedy_sparsities([sparsity] * L, greedy_lookup)
     else:
         sparsities = {p: [sparsity] * L for p in PROJS}
@@ -155,6 +162,37 @@ def apply_sparsity(model: Transformer, *, sparsity: float, hist_path: Optional[s
         ths = [monkeypatch_layer(i, layer, sparsity, hist_path, device, sparsities=sparsities)
                for i, layer in enumerate(model.layers)]
     return ths
+
+
+@torch.no_grad()
+def report_kept_fractions(model: Transformer, thresholds, prompt: torch.Tensor) -> Dict[str, float]:
+    """Achieved kept fraction per projection (the quantity that determines the bytes read), measured on
+    one pass of the prompt through the patched model with the installed thresholds."""
+    acts = {k: [] for k in ("attn_in", "attn_out", "mlp_in", "mlp_mid")}
+    site = {"q": "attn_in", "k": "attn_in", "v": "attn_in", "o": "attn_out", "gate": "mlp_in", "up": "mlp_in", "down": "mlp_mid"}
+    kept = {p: [] for p in PROJS}
+    hooks = []
+    for i, layer in enumerate(model.layers):
+        th = thresholds[i]
+
+        def pre_attn(m, a, th=th):
+            x = a[0].detach().float().abs()
+            for p in ("q", "k", "v"):
+                kept[p].append(float((x > th[p]).float().mean()))
+
+        def pre_ffn(m, a, th=th):
+            x = a[0].detach().float().abs()
+            for p in ("gate", "up"):
+                kept[p].append(float((x > th[p]).float().mean()))
+
+        hooks.append(layer.attention.register_forward_pre_hook(pre_attn))
+        hooks.append(layer.feed_forward.register_forward_pre_hook(pre_ffn))
+    model(prompt.view(1, -1), torch.arange(prompt.numel(), device=prompt.device))
+    for h in hooks:
+        h.remove()
+    out = {p: sum(v) / len(v) for p, v in kept.items() if v}
+    print("achieved kept fraction (prompt activations):", {k: round(v, 3) for k, v in out.items()})
+    return out
 
 
 def _get_model_size(model) -> int:
@@ -311,6 +349,8 @@ def main(args) -> Dict:
         print(f"Time for inference {i + 1}: {t:.02f} sec total, {tps[-1]:.02f} tokens/sec")
         print(f"Bandwidth achieved: {model_size * tps[-1] / 1e9:.02f} GB/s (dense parameter bytes x tok/s, as the reference reports)")
     print("==========")
+    if thresholds is not None and args.report_kept:
+        report_kept_fractions(model, thresholds, prompt)
     mean = sum(tps) / max(1, len(tps))
     print(f"Average tokens/sec: {mean:.2f}")
     print(f"Memory used: {torch.cuda.max_memory_reserved() / 1e9:.02f} GB")
@@ -337,6 +377,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--synthetic", type=str, default=None, help="architecture name, e.g. 7B, llama-3-8b, 70B")
     p.add_argument("--n_layer", type=int, default=None, help="override the layer count (synthetic smoke runs)")
     p.add_argument("--dense", action="store_true", help="do not monkeypatch: dense baseline")
+    p.add_argument("--report_kept", action="store_true", help="print the achieved kept fraction per projection")
     p.add_argument("--engine", action="store_true", help="fused HIP decode step (teal_amd/gpt_fast/engine.py)")
     return p
 
