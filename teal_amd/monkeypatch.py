@@ -100,4 +100,6 @@ def monkeypatch_layer(layer_idx: int, layer, sparsity, hist_path: Optional[str],
 
     ff.apply_monkeypatch()
     attn.apply_monkeypatch()
+    if torch.cuda.is_available() and ff.w1.weight.is_cuda:
+        torch.cuda.empty_cache()  # release the pre-relayout copies (generate.py:323); matters for 70B in 288 GB
     return thresholds
