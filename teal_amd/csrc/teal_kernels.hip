@@ -465,13 +465,13 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
 
     int eb = wave * RPW;  // wave-uniform list position
     if (col_ok) {
-        // full steps: every lane of the wave has U valid entries
-        for (; eb + (U - 1) * STRIDE + RPW <= nloc; eb += U * STRIDE) {
-            u32x4 w[U], w2[PAIR ? U : 1];
-            float xv[U];
+        constexpr int STEP = U * STRIDE;
+        auto full = [&](const int e) { return e + (U - 1) * STRIDE + RPW <= nloc; };
+        // issue the U (x2 for PAIR) 16-byte loads of one batch; nothing here waits
+        auto issue = [&](u32x4 (&w)[U], u32x4 (&w2)[PAIR ? U : 1], float (&xv)[U], const int e0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const uint32_t ent = list[eb + u * STRIDE + g];
+                const uint32_t ent = list[e0 + u * STRIDE + g];
                 xv[u] = bits_to_float(ent & 0xFFFFu, BF16);
                 w[u] = __builtin_nontemporal_load(
                     reinterpret_cast<const u32x4*>(wp + (size_t)(ent >> 16) * ldb));
@@ -479,6 +479,8 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
                     w2[u] = __builtin_nontemporal_load(
                         reinterpret_cast<const u32x4*>(wp2 + (size_t)(ent >> 16) * ldb2));
             }
+        };
+        auto consume = [&](u32x4 (&w)[U], u32x4 (&w2)[PAIR ? U : 1], float (&xv)[U]) {
             if (two_tau) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -493,42 +495,46 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
                 fma8<BF16>(acc, w[u], xv[u]);
                 if constexpr (PAIR) fma8<BF16>(acc2, w2[u], xv[u]);
             }
+        };
+        // two batches in flight per wave (software pipeline): the next batch's loads are issued before
+        // the current batch is consumed, so a wave never sits with an empty memory queue
+        u32x4 wa[U], wb[U], w2a[PAIR ? U : 1], w2b[PAIR ? U : 1];
+        float xa[U], xb[U];
+        bool fa = full(eb);
+        if (fa) issue(wa, w2a, xa, eb);
+        while (fa) {
+            int ebn = eb + STEP;
+            const bool fb = full(ebn);
+            if (fb) issue(wb, w2b, xb, ebn);
+            consume(wa, w2a, xa);
+            eb = ebn;
+            if (!fb) break;
+            ebn = eb + STEP;
+            fa = full(ebn);
+            if (fa) issue(wa, w2a, xa, ebn);
+            consume(wb, w2b, xb);
+            eb = ebn;
         }
         // tail: clamp the entry index, zero the contribution of clamped lanes
         if (eb < nloc) {
-            u32x4 w[U], w2[PAIR ? U : 1];
-            float xv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int e = eb + u * STRIDE + g;
                 const bool ok = e < nloc;
                 const uint32_t ent = list[ok ? e : nloc - 1];
-                xv[u] = ok ? bits_to_float(ent & 0xFFFFu, BF16) : 0.0f;
+                xa[u] = ok ? bits_to_float(ent & 0xFFFFu, BF16) : 0.0f;
                 u32x4 t = __builtin_nontemporal_load(
                     reinterpret_cast<const u32x4*>(wp + (size_t)(ent >> 16) * ldb));
                 if (!ok) t = (u32x4){0u, 0u, 0u, 0u};
-                w[u] = t;
+                wa[u] = t;
                 if constexpr (PAIR) {
                     u32x4 t2 = __builtin_nontemporal_load(
                         reinterpret_cast<const u32x4*>(wp2 + (size_t)(ent >> 16) * ldb2));
                     if (!ok) t2 = (u32x4){0u, 0u, 0u, 0u};
-                    w2[u] = t2;
+                    w2a[u] = t2;
                 }
             }
-            if (two_tau) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const float ax = fabsf(xv[u]);
-                    const bool nanx = xv[u] != xv[u];
-                    if (!(ax > tau_g || nanx)) w[u] = (u32x4){0u, 0u, 0u, 0u};
-                    if constexpr (PAIR) if (!(ax > tau_u || nanx)) w2[u] = (u32x4){0u, 0u, 0u, 0u};
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                fma8<BF16>(acc, w[u], xv[u]);
-                if constexpr (PAIR) fma8<BF16>(acc2, w2[u], xv[u]);
-            }
+            consume(wa, w2a, xa);
         }
     }
 
