@@ -193,7 +193,9 @@ def roofline_engine_gateup(eng, a):
     ns = eng.n_wo.value
     B = eng.resid[1]
     # the producer's output, recomputed in torch to count kept rows per layer
-    h = (B.float() + eng.s_wo[:ns].sum(0).to(B.dtype).float()).to(B.dtype)
+    stride = (ns + 3) & ~3  # interleaved slabs: [Z][stride]
+    ssum = eng.s_wo.view(-1)[: Z * stride].view(Z, stride)[:, :ns].sum(1)
+    h = (B.float() + ssum.to(B.dtype).float()).to(B.dtype)
     hf = h.float()
     xn = (hf * torch.rsqrt(hf.pow(2).mean() + eng.eps)).to(B.dtype)
     total_bytes, launches = 0, []
@@ -204,7 +206,7 @@ def roofline_engine_gateup(eng, a):
         nnz_u = int((x > k4_out.tau[1]).sum())
         out_bytes = (N * 2 + N // 8) if eng.pair else 2 * N * 2  # h (+ keep masks) vs gate|up
         total_bytes += (nnz_g + nnz_u) * N * 2 + Z * 2 + ns * Z * 4 + Z * 2 + out_bytes
-        gin = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=B.data_ptr(), slabs=eng.s_wo.data_ptr(), nslabs=ns,
+        gin = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=B.data_ptr(), slabs=eng.s_wo.data_ptr(), nslabs=ns, slabs_interleaved=1,
                      norm_weight=m.layers[i].ffn_norm.weight.data_ptr(), eps=eng.eps, resid_out=None)
         launches.append((gin, k4_out))
 

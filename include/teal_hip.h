@@ -130,6 +130,8 @@ typedef struct teal_gemv_in {
     float eps;
     void* resid_out;          /* RESID_NORM, optional: updated residual [Z]; must not alias resid_in */
     const void* masks;        /* MASKED: uint64 [ceil(Z/64)] keep masks of x */
+    int slabs_interleaved;    /* RESID_NORM: slabs are [Z][(nslabs+3)&~3] (as written by a producer with
+                               * slabs_interleaved = 1) instead of planar [nslabs][Z]; nslabs <= 8 */
 } teal_gemv_in_t;
 
 typedef struct teal_gemv_out {
@@ -145,6 +147,8 @@ typedef struct teal_gemv_out {
     size_t slabs_bytes;
     void* mask_out;      /* PAIR_SILU, optional: uint64 [ceil(ncols/64)] keep masks of h */
     float mask_tau;      /* PAIR_SILU: threshold of the consumer (the down projection) */
+    int slabs_interleaved; /* SLABS: write slabs[col][slice] with row stride (nslabs+3)&~3 so that the consumer
+                            * fetches every partial of an element with one 16-byte load */
 } teal_gemv_out_t;
 
 /* One launch: [fused producer] -> mask + compaction -> gathered GEMV over every segment.

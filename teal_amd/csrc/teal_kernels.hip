@@ -57,6 +57,7 @@ struct InSpec {
     const float* slabs;        // mode 1: [nslabs][Z]
     const void* norm_w;        // mode 1: RMSNorm weight [Z]
     void* resid_out;           // mode 1: updated residual, written by workgroup 0
+    int slabs_il;              // mode 1: slabs are interleaved [Z][(nslabs + 3) & ~3] (one 16-byte load per element)
     const unsigned long long* masks;  // mode 3: keep masks (one per 64 activations) emitted by the producer
     float eps;
 };
@@ -73,6 +74,7 @@ struct Params {
     int cap;       // LDS list capacity (entries)
     int to_ws;     // 1: always write fp32 slabs (an epilogue kernel follows)
     int swizzle;   // 1: XOR-swizzle tiles inside aligned groups of 8 (XCD decorrelation)
+    int ws_il;     // 1: slabs written interleaved, ws[col * stride + slice], stride = (split + 3) & ~3
     int pair;      // 1: seg[0] = gate, seg[1] = up over the SAME column tile; epilogue silu(g)*u -> seg[0].y
     unsigned long long* mask_out;  // pair: keep masks of the output vs mask_tau for the next launch (or null)
     float mask_tau;
@@ -286,6 +288,29 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         float sacc[KR];
 #pragma unroll
         for (int k = 0; k < KR; ++k) sacc[k] = 0.0f;
+        if (p.in.slabs_il && p.in.nslabs > 0) {
+            // producer wrote ws[col][slice]: all slabs of an element arrive in one (two) 16-byte loads,
+            // issued together with the residual/weight loads above -> a single memory round trip
+            const int stride = (p.in.nslabs + 3) & ~3;
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            f32x4 v0[KR], v1[KR];
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                const f32x4* sp = reinterpret_cast<const f32x4*>(p.in.slabs + (size_t)mcl[k] * stride);
+                v0[k] = sp[0];
+                v1[k] = stride > 4 ? sp[1] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            const int ns = p.in.nslabs;
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                float a = 0.0f;  // slab order 0,1,2,... (same order as the planar path and the reduce kernel)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a += (j < ns) ? v0[k][j] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a += (4 + j < ns) ? v1[k][j] : 0.0f;
+                sacc[k] = a;
+            }
+        } else
         for (int q = 0; q < p.in.nslabs; q += 2) {  // two slabs per round trip, summed in slab order
             const bool two = q + 1 < p.in.nslabs;
             const float* s0 = p.in.slabs + (size_t)q * Z;
@@ -596,6 +621,8 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
             for (int wv = 0; wv < WAVES; ++wv) sum += red[wv * BN + t];
             if (p.split == 1 && !p.to_ws) {
                 reinterpret_cast<uint16_t*>(sg.y)[c] = float_to_bits<BF16>(sum);
+            } else if (p.ws_il) {
+                p.ws[(size_t)(sg.ws_off + c) * ((p.split + 3) & ~3) + slice] = sum;
             } else {
                 p.ws[(size_t)slice * p.ws_ld + sg.ws_off + c] = sum;
             }
@@ -1120,7 +1147,7 @@ hipError_t launch_gemv(const Params& p, int dtype, size_t lds, const Config& c, 
 // Common driver: fills geometry fields of `p` (segments' w/y/tau/ld/col0/ncols are set by the
 // caller), launches the GEMV and, if needed, the ordered slab reduce.
 int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStream_t st,
-             Config* used, bool few_slabs = false) {
+             Config* used, bool few_slabs = false, bool interleave = false) {
     int total_cols = 0;
     for (int i = 0; i < p.nseg; ++i) total_cols += p.seg[i].ncols;
     Config c = pick_config(p.Z, total_cols, p.nseg);
@@ -1171,8 +1198,10 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
     p.swizzle = g_swizzle;
     const size_t lds = lds_bytes(p.Z, p.cap, c.waves, c.lpr, p.pair != 0);
     if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
+    p.ws_il = (interleave && to_ws && c.split <= 8) ? 1 : 0;
     if (c.split > 1 || to_ws) {
-        if (!ws || ws_bytes < (size_t)c.split * off * sizeof(float)) return TEAL_ERR_WORKSPACE;
+        const size_t slabs = p.ws_il ? (size_t)((c.split + 3) & ~3) : (size_t)c.split;
+        if (!ws || ws_bytes < slabs * off * sizeof(float)) return TEAL_ERR_WORKSPACE;
         if (!aligned16(ws)) return TEAL_ERR_ALIGN;
     }
     if (used) *used = c;
@@ -1384,6 +1413,8 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
             p.in.row_index = in->row_index;
             p.in.slabs = in->slabs;
             p.in.nslabs = in->nslabs;
+            p.in.slabs_il = in->slabs_interleaved ? 1 : 0;
+            if (p.in.slabs_il && in->nslabs > 8) return TEAL_ERR_ARG;
             p.in.norm_w = in->norm_weight;
             p.in.resid_out = in->resid_out;
             p.in.eps = in->eps;
@@ -1414,7 +1445,8 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
         rc = run_gemv(p, dtype, ws, ws_bytes, false, st, &used, false);
     } else if (out->mode == TEAL_OUT_SLABS) {
         if (!out->slabs) return TEAL_ERR_ARG;
-        rc = run_gemv(p, dtype, out->slabs, out->slabs_bytes, true, st, &used, true);
+        rc = run_gemv(p, dtype, out->slabs, out->slabs_bytes, true, st, &used, true, out->slabs_interleaved != 0);
+        if (rc == TEAL_OK && out->slabs_interleaved && !p.ws_il) return TEAL_ERR_CONFIG;  // > 8 slices cannot interleave
     } else if (out->mode == TEAL_OUT_ROUNDED) {
         rc = run_gemv(p, dtype, ws, ws_bytes, false, st, &used, false);
     } else {

@@ -37,14 +37,15 @@ class GemvIn(ctypes.Structure):  # teal_gemv_in_t
     _fields_ = [("mode", ctypes.c_int), ("x", ctypes.c_void_p), ("resid_in", ctypes.c_void_p),
                 ("row_index", ctypes.c_void_p), ("slabs", ctypes.c_void_p), ("nslabs", ctypes.c_int),
                 ("norm_weight", ctypes.c_void_p), ("eps", ctypes.c_float), ("resid_out", ctypes.c_void_p),
-                ("masks", ctypes.c_void_p)]
+                ("masks", ctypes.c_void_p), ("slabs_interleaved", ctypes.c_int)]
 
 
 class GemvOut(ctypes.Structure):  # teal_gemv_out_t
     _fields_ = [("nseg", ctypes.c_int), ("w", ctypes.c_void_p * 3), ("ld", ctypes.c_int * 3),
                 ("col0", ctypes.c_int * 3), ("ncols", ctypes.c_int * 3), ("tau", ctypes.c_float * 3),
                 ("y", ctypes.c_void_p * 3), ("mode", ctypes.c_int), ("slabs", ctypes.c_void_p),
-                ("slabs_bytes", ctypes.c_size_t), ("mask_out", ctypes.c_void_p), ("mask_tau", ctypes.c_float)]
+                ("slabs_bytes", ctypes.c_size_t), ("mask_out", ctypes.c_void_p), ("mask_tau", ctypes.c_float),
+                ("slabs_interleaved", ctypes.c_int)]
 
 
 def _out(segs, mode, slabs: Optional[torch.Tensor] = None) -> GemvOut:
@@ -57,6 +58,7 @@ def _out(segs, mode, slabs: Optional[torch.Tensor] = None) -> GemvOut:
     if slabs is not None:
         o.slabs = slabs.data_ptr()
         o.slabs_bytes = slabs.numel() * 4
+        o.slabs_interleaved = 1
     return o
 
 
@@ -120,7 +122,7 @@ class DecodeEngine:
         for i, layer in enumerate(m.layers):
             at, ff, th = layer.attention, layer.feed_forward, ths[i]
             k1_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=(m.tok_embeddings.weight.data_ptr() if i == 0 else A.data_ptr()),
-                           slabs=(None if i == 0 else self.s_down.data_ptr()), nslabs=0,
+                           slabs=(None if i == 0 else self.s_down.data_ptr()), nslabs=0, slabs_interleaved=1,
                            norm_weight=layer.attention_norm.weight.data_ptr(), eps=self.eps, resid_out=B.data_ptr())
             wq, ldq = at.wqkv.weight.data_ptr(), at.wqkv.weight.stride(1)
             k1_out = _out([(wq, ldq, 0, dim, th["q"], self.qkv.data_ptr()),
@@ -129,7 +131,7 @@ class DecodeEngine:
             k3_in = (GemvIn(mode=TEAL_IN_MASKED, x=self.y_attn.data_ptr(), masks=self.y_mask.data_ptr()) if self.pair
                      else GemvIn(mode=TEAL_IN_PLAIN, x=self.y_attn.data_ptr()))
             k3_out = _out([(at.wo.weight.data_ptr(), at.wo.weight.stride(1), 0, dim, th["o"], None)], TEAL_OUT_SLABS, self.s_wo)
-            k4_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=B.data_ptr(), slabs=self.s_wo.data_ptr(), nslabs=0,
+            k4_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=B.data_ptr(), slabs=self.s_wo.data_ptr(), nslabs=0, slabs_interleaved=1,
                            norm_weight=layer.ffn_norm.weight.data_ptr(), eps=self.eps, resid_out=A.data_ptr())
             k4_out = _out([(ff.w1.weight.data_ptr(), ff.w1.weight.stride(1), 0, inter, th["gate"], self.gu.data_ptr()),
                            (ff.w3.weight.data_ptr(), ff.w3.weight.stride(1), 0, inter, th["up"], self.gu.data_ptr() + 2 * inter)], TEAL_OUT_ROUNDED)
@@ -145,7 +147,7 @@ class DecodeEngine:
             kc, vc = at.kv_cache.k_cache, at.kv_cache.v_cache
             assert kc.is_contiguous() and kc.shape[0] == 1 and kc.shape[2] == self.max_seq
             self.stages.append((k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out, th["o"]))
-        self.head_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=A.data_ptr(), slabs=self.s_down.data_ptr(), nslabs=0,
+        self.head_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=A.data_ptr(), slabs=self.s_down.data_ptr(), nslabs=0, slabs_interleaved=1,
                               norm_weight=m.norm.weight.data_ptr(), eps=self.eps, resid_out=None)
         self.head_out = _out([(m.output.weight.data_ptr(), m.output.weight.stride(1), 0, self.cfg.vocab_size, float("-inf"),
                                self.logits.data_ptr())], TEAL_OUT_ROUNDED)

@@ -257,3 +257,38 @@ def test_pair_and_masked_stages_equal_unfused_stages():
             a, b = e1(tok, pos), e2(tok, pos)
             assert torch.equal(a.view(torch.int16), b.view(torch.int16)), step
             tok = a.float().argmax().view(1, 1).to(torch.int)
+
+
+def test_interleaved_slabs_equal_planar():
+    """SLABS producer with slabs_interleaved + RESID_NORM consumer reading them == planar slabs."""
+    from teal_amd import _lib, runtime
+    from teal_amd.gpt_fast.engine import GemvIn, _out, TEAL_IN_PLAIN, TEAL_IN_RESID_NORM, TEAL_OUT_ROUNDED, TEAL_OUT_SLABS
+    L = _lib.load()
+    runtime.init()
+    Z, N = 4096, 4096
+    dt = torch.float16
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(Z, device=DEV, generator=g).to(dt)
+    W = (torch.randn(N, Z, device=DEV, generator=g) * 0.03).to(dt).T.contiguous().T
+    W2 = (torch.randn(1024, N, device=DEV, generator=g) * 0.03).to(dt).T.contiguous().T
+    resid = torch.randn(N, device=DEV, generator=g).to(dt)
+    nw = torch.ones(N, device=DEV, dtype=dt)
+    ws = runtime.reserve_workspace(Z, N)
+    outs = []
+    for il in (0, 1):
+        slabs = torch.zeros(32 * N, device=DEV, dtype=torch.float32)
+        gout = _out([(W.data_ptr(), N, 0, N, 0.7, None)], TEAL_OUT_SLABS, slabs)
+        gout.slabs_interleaved = il
+        ns = ctypes.c_int(0)
+        gin = GemvIn(mode=TEAL_IN_PLAIN, x=x.data_ptr())
+        assert L.teal_fused_gemv(ctypes.byref(gin), ctypes.byref(gout), Z, 0, ws.data_ptr(), ws.numel() * 4, ctypes.byref(ns), runtime.stream_ptr()) == 0
+        assert 1 < ns.value <= 8
+        y = torch.zeros(1024, device=DEV, dtype=dt)
+        rout = torch.zeros(N, device=DEV, dtype=dt)
+        cin = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=resid.data_ptr(), slabs=slabs.data_ptr(), nslabs=ns.value, slabs_interleaved=il,
+                     norm_weight=nw.data_ptr(), eps=1e-5, resid_out=rout.data_ptr())
+        cout = _out([(W2.data_ptr(), 1024, 0, 1024, 0.5, y.data_ptr())], TEAL_OUT_ROUNDED)
+        assert L.teal_fused_gemv(ctypes.byref(cin), ctypes.byref(cout), N, 0, ws.data_ptr(), ws.numel() * 4, None, runtime.stream_ptr()) == 0
+        outs.append((y.clone(), rout.clone()))
+    assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
+    assert torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
