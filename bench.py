@@ -297,6 +297,8 @@ def cpu_baseline(model, a, budget_s=12.0):
         for k, (wb, Z, N) in host.items():
             O.fast_sparse_gemv(xs[k], wb, tau, Z, N, code)
 
+    wbg, Zg, Ng = host["gate"]
+    used_threads = O.pick_threads(xs["gate"], wbg, tau, Zg, Ng, code)  # the fastest OpenMP width on this host
     one_layer()  # warm-up (page-in)
     t0 = time.perf_counter()
     reps = 0
@@ -316,7 +318,7 @@ def cpu_baseline(model, a, budget_s=12.0):
             break
     t_lm = (time.perf_counter() - t1) / r2
     t_token = cfg.n_layer * t_layer + t_lm
-    return {"value": 1.0 / t_token, "unit": "tokens/s", "cores": O.num_threads(), "kind": "port",
+    return {"value": 1.0 / t_token, "unit": "tokens/s", "cores": used_threads, "kind": "port",
             "sample": f"oracle/teal_oracle.c fast path: 1 of {cfg.n_layer} layers (qkv, o, gate, up, down sparse GEMVs at kept "
                       f"fraction {1 - a.sparsity:.2f}) x {reps} reps + dense lm_head x {r2} reps, scaled to one token "
                       f"({cfg.n_layer} layers + lm_head); GEMVs only (no attention/norms), so it flatters the CPU",

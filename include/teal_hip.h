@@ -188,7 +188,8 @@ int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll);
 /* Column-tile XOR swizzle that spreads every XCD over all DRAM channel residues (default on). */
 int teal_set_swizzle(int on);
 
-/* Diagnostics: when set (device pointer to >= 8 * workgroups uint64), thread 0 of every GEMV
+/* Diagnostics: when set (device pointer to >= 24 * workgroups uint64; the last 16 per workgroup receive each
+ * wave's end-of-stream stamp), thread 0 of every GEMV
  * workgroup stores 100 MHz wall-clock stamps of its phases (0 start, 1 ballots, 2 scatter,
  * 3 list ready, 4 rows streamed, 5 done).  NULL (default) disables.  Process-global. */
 int teal_set_phase_buffer(void* dev_u64);

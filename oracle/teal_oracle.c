@@ -273,6 +273,14 @@ static void axpy_f16_avx2(float* a, const uint16_t* r, float x, int w) { (void)a
 static void axpy_bf16_avx2(float* a, const uint16_t* r, float x, int w) { (void)a; (void)r; (void)x; (void)w; }
 #endif
 
+void teal_oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int teal_oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
@@ -297,41 +305,58 @@ int teal_oracle_fast_qkv_gemv(const uint16_t* x, const uint16_t* wT, uint16_t* y
         for (int m = 0; m < Z; ++m) if (fabsf(xv[m]) > taus[s]) lists[s][c++] = m;
         cnt[s] = c;
     }
-    const int TILE = 256;
+    /* tasks = column tiles x row parts, so that every host thread has work even for N = 4096;
+     * each task accumulates its part of the kept rows in fp32, parts are then summed in order */
+    const int TILE = 512;
     const int simd = have_avx2();
-    int ntiles = (N + TILE - 1) / TILE;
-#pragma omp parallel for schedule(dynamic, 1)
+    const int ntiles = (N + TILE - 1) / TILE;
+    int nthreads = teal_oracle_num_threads();
+    int parts = (4 * nthreads + ntiles - 1) / ntiles;
+    if (parts < 1) parts = 1;
+    if (parts > 32) parts = 32;
+    float* partial = (float*)malloc(sizeof(float) * (size_t)parts * (size_t)N);
+    if (!partial) { free(idx); free(xv); return -3; }
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int t = 0; t < ntiles; ++t) {
-        int n0 = t * TILE;
-        int n1 = n0 + TILE < N ? n0 + TILE : N;
-        /* a tile may straddle a segment boundary only if N_q / N_kv are not
-         * multiples of TILE; handle generally by per-column segment lookup */
-        float acc[256];
-        for (int j = 0; j < TILE; ++j) acc[j] = 0.0f;
-        int c = n0;
-        while (c < n1) {
-            int seg = c < N_q ? 0 : (c < N_q + N_kv ? 1 : 2);
-            int segend = seg == 0 ? N_q : (seg == 1 ? N_q + N_kv : N);
-            int e = segend < n1 ? segend : n1;
-            const int32_t* L = lists[seg];
-            int w = e - c;
-            float* a = acc + (c - n0);
-            for (int k = 0; k < cnt[seg]; ++k) {
-                int m = L[k];
-                float xm = xv[m];
-                const uint16_t* row = wT + (size_t)m * N + c;
-                if (simd) {
-                    if (dtype == TEAL_BF16) axpy_bf16_avx2(a, row, xm, w);
-                    else axpy_f16_avx2(a, row, xm, w);
-                } else if (dtype == TEAL_BF16)
-                    for (int j = 0; j < w; ++j) a[j] += u32_as_f32((uint32_t)row[j] << 16) * xm;
-                else
-                    for (int j = 0; j < w; ++j) a[j] += g_h2f[row[j]] * xm;
+        for (int pp = 0; pp < parts; ++pp) {
+            int n0 = t * TILE;
+            int n1 = n0 + TILE < N ? n0 + TILE : N;
+            float acc[512];
+            for (int j = 0; j < TILE; ++j) acc[j] = 0.0f;
+            int c = n0;
+            while (c < n1) {
+                int seg = c < N_q ? 0 : (c < N_q + N_kv ? 1 : 2);
+                int segend = seg == 0 ? N_q : (seg == 1 ? N_q + N_kv : N);
+                int e = segend < n1 ? segend : n1;
+                const int32_t* L = lists[seg];
+                int w = e - c;
+                float* a = acc + (c - n0);
+                int k0 = (int)((long long)cnt[seg] * pp / parts), k1 = (int)((long long)cnt[seg] * (pp + 1) / parts);
+                for (int k = k0; k < k1; ++k) {
+                    int m = L[k];
+                    float xm = xv[m];
+                    const uint16_t* row = wT + (size_t)m * N + c;
+                    if (simd) {
+                        if (dtype == TEAL_BF16) axpy_bf16_avx2(a, row, xm, w);
+                        else axpy_f16_avx2(a, row, xm, w);
+                    } else if (dtype == TEAL_BF16)
+                        for (int j = 0; j < w; ++j) a[j] += u32_as_f32((uint32_t)row[j] << 16) * xm;
+                    else
+                        for (int j = 0; j < w; ++j) a[j] += g_h2f[row[j]] * xm;
+                }
+                c = e;
             }
-            c = e;
+            float* dst = partial + (size_t)pp * N + n0;
+            for (int j = 0; j < n1 - n0; ++j) dst[j] = acc[j];
         }
-        for (int j = 0; j < n1 - n0; ++j) y[n0 + j] = store16(acc[j], dtype);
     }
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; ++n) {
+        float sacc = 0.0f;
+        for (int pp = 0; pp < parts; ++pp) sacc += partial[(size_t)pp * N + n];
+        y[n] = store16(sacc, dtype);
+    }
+    free(partial);
     free(idx);
     free(xv);
     return 0;

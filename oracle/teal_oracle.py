@@ -58,6 +58,7 @@ def lib() -> ctypes.CDLL:
         L.teal_oracle_fast_dense_gemv.argtypes = [u16p, u16p, u16p, c_int, c_int, c_int]
         L.teal_oracle_hash_uniform.argtypes = [u16p, ctypes.c_size_t, ctypes.c_uint32, c_float, c_int]
         L.teal_oracle_num_threads.restype = c_int
+        L.teal_oracle_set_threads.argtypes = [c_int]
         L.teal_oracle_half_to_float.argtypes = [ctypes.c_uint16]
         L.teal_oracle_half_to_float.restype = c_float
         L.teal_oracle_float_to_half.argtypes = [c_float]
@@ -224,6 +225,32 @@ def fast_dense_gemv(x_bits, wT_bits, Z, N, dtype=F16) -> np.ndarray:
 
 def num_threads() -> int:
     return int(lib().teal_oracle_num_threads())
+
+
+def set_threads(n: int) -> None:
+    lib().teal_oracle_set_threads(int(n))
+
+
+def pick_threads(x_bits, wT_bits, tau, Z, N, dtype=F16, candidates=(1, 2, 4, 8, 16, 32, 64, 128)) -> int:
+    """containers often expose more logical CPUs than their quota: time one GEMV per thread count and
+    keep the fastest (the CPU baseline reports the count it actually used)."""
+    import os
+    import time
+    best, best_t = 1, float("inf")
+    ncpu = os.cpu_count() or 1
+    for n in candidates:
+        if n > ncpu:
+            break
+        set_threads(n)
+        fast_sparse_gemv(x_bits, wT_bits, tau, Z, N, dtype)
+        t0 = time.perf_counter()
+        fast_sparse_gemv(x_bits, wT_bits, tau, Z, N, dtype)
+        fast_sparse_gemv(x_bits, wT_bits, tau, Z, N, dtype)
+        t = (time.perf_counter() - t0) / 2
+        if t < best_t:
+            best, best_t = n, t
+    set_threads(best)
+    return best
 
 
 # ----------------------------------------------------------------------------------------

@@ -31,7 +31,7 @@ def main():
     for _ in range(3):
         eng(tok, pos)
     torch.cuda.synchronize()
-    phase = torch.zeros(2048 * 8, dtype=torch.int64, device="cuda")
+    phase = torch.zeros(2048 * 24, dtype=torch.int64, device="cuda")
     k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out, _tau_o = eng.stages[3]
     k1_in.nslabs = eng.n_down.value
     k4_in.nslabs = eng.n_wo.value
@@ -52,8 +52,16 @@ def main():
             eng._gemv(gin, gout, Z)
             torch.cuda.synchronize()
             L.teal_set_phase_buffer(None)
-            p = phase.view(-1, 8)
-            n = int((p[:, 5] > 0).sum())
+            p = phase[: 2048 * 8].view(-1, 8)
+            n = int((p[:, 5] > 0).sum()) // 3  # n rows of phase stamps + 2n rows' worth of per-wave stamps
+            p = p[:n]
+            pw = phase[n * 8: n * 8 + n * 16].view(n, 16).cpu().double() * 10.0 / 1e3  # per-wave end of stream, us
+            p3 = p[:n, 3].cpu().double() * 10.0 / 1e3
+            if it == 7:
+                print('      per-wave mean stream us:', ' '.join(f'{v:.1f}' for v in (pw - p3[:, None]).mean(dim=0).tolist()))
+            wave_spread = float((pw.max(dim=1).values - pw.min(dim=1).values).mean())
+            wave_mean_dur = float((pw.mean(dim=1) - p3).mean())
+            wave_max_dur = float((pw.max(dim=1).values - p3).mean())
             if it == 7:
                 import numpy as np
                 np.save(os.path.join(ROOT, "gpurun_out", f"ephase_{tag.split()[0].replace('|', '')}.npy"), p[:n].cpu().numpy())
@@ -63,6 +71,7 @@ def main():
             rows.append([float((p[:, 0] - t0).max()) / 1e3] + [float((p[:, b] - p[:, a]).mean()) / 1e3 for a, b in order] +
                         [float((p[:, 5] - t0).min()) / 1e3])
         r = torch.tensor(rows).median(dim=0).values.tolist()
+        print(f"    per-wave stream time inside a WG: mean {wave_mean_dur:.2f} us, slowest wave {wave_max_dur:.2f} us, spread {wave_spread:.2f} us")
         print(f"[{tag}] wgs={n} span {sorted(spans)[len(spans) // 2]:.2f} us; dispatch skew {r[0]:.2f}; earliest end {r[-1]:.2f}")
         for nm, v in zip(names, r[1:8]):
             print(f"    {nm:28s} {v:6.2f} us")

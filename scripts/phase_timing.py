@@ -31,7 +31,7 @@ def main():
         cfg = (ctypes.c_int * 5)()
         L.teal_get_config(Z, N * nmat, 1, cfg)
         wgs = cfg[4]
-        phase = torch.zeros(wgs * 8, dtype=torch.int64, device="cuda")
+        phase = torch.zeros(wgs * 24, dtype=torch.int64, device="cuda")
         spans, rows = [], []
         for it in range(12):
             phase.zero_()
@@ -48,7 +48,7 @@ def main():
             L.teal_set_phase_buffer(None)
             if it < 2:
                 continue
-            p = phase.view(wgs, 8).cpu().double() * 10.0  # ns
+            p = phase[: wgs * 8].view(wgs, 8).cpu().double() * 10.0  # ns
             t0 = p[:, 0].min()
             spans.append(float(p[:, 5].max() - t0) / 1e3)
             rows.append([float((p[:, 0] - t0).max()) / 1e3] + [float((p[:, i + 1] - p[:, i]).mean()) / 1e3 for i in range(5)] +

@@ -564,6 +564,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
     }
 
     stamp(p, 4);
+    if (p.phase && lane == 0) p.phase[(size_t)gridDim.x * 8 + (size_t)blockIdx.x * 16 + wave] = wall_clock64();  // per-wave end of stream
     // ---- reduce: row groups of the wave, then waves (fixed order) --------------------------------
 #pragma unroll
     for (int off = LPR; off < 64; off <<= 1) {
@@ -893,6 +894,8 @@ __global__ __launch_bounds__(1024) void sample_topk_kernel(const uint16_t* __res
                                                             int* __restrict__ token_out, int* __restrict__ pos_inout,
                                                             int* __restrict__ history, const int history_len) {
     __shared__ unsigned int hist[256];
+    __shared__ unsigned int whist[16][256];  // per-wave sub-histograms: logits cluster in a few bins, a single
+                                             // shared histogram serialises on LDS atomics
     __shared__ float fred[16];
     __shared__ int ired[16];
     __shared__ unsigned int sel[2];
@@ -902,7 +905,7 @@ __global__ __launch_bounds__(1024) void sample_topk_kernel(const uint16_t* __res
     const u32x4* lv = reinterpret_cast<const u32x4*>(logits);
     uint32_t pivot_key = 0;  // keep keys >= pivot_key
     float mx = -INFINITY;
-    if (tid < 256) hist[tid] = 0;
+    for (int i = tid; i < 16 * 256; i += 1024) (&whist[0][0])[i] = 0;
     __syncthreads();
     // pass 1: high-byte histogram of the order-preserving 16-bit keys + global max
     for (int i = tid; i < V8; i += 1024) {
@@ -912,18 +915,25 @@ __global__ __launch_bounds__(1024) void sample_topk_kernel(const uint16_t* __res
             const uint32_t lo = w[j] & 0xFFFFu, hi = w[j] >> 16;
             mx = fmaxf(mx, fmaxf(bits_to_float(lo, BF16), bits_to_float(hi, BF16)));
             if (filter) {
-                atomicAdd(&hist[order_key16(lo, BF16) >> 8], 1u);
-                atomicAdd(&hist[order_key16(hi, BF16) >> 8], 1u);
+                atomicAdd(&whist[wave][order_key16(lo, BF16) >> 8], 1u);
+                atomicAdd(&whist[wave][order_key16(hi, BF16) >> 8], 1u);
             }
         }
     }
     for (int i = (V8 << 3) + tid; i < V; i += 1024) {
         mx = fmaxf(mx, bits_to_float(logits[i], BF16));
-        if (filter) atomicAdd(&hist[order_key16(logits[i], BF16) >> 8], 1u);
+        if (filter) atomicAdd(&whist[wave][order_key16(logits[i], BF16) >> 8], 1u);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
     if (lane == 0) fred[wave] = mx;
+    __syncthreads();
+    if (tid < 256) {
+        unsigned int a = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) a += whist[w][tid];
+        hist[tid] = a;
+    }
     __syncthreads();
     mx = fred[0];
 #pragma unroll
@@ -942,7 +952,7 @@ __global__ __launch_bounds__(1024) void sample_topk_kernel(const uint16_t* __res
         __syncthreads();
         const unsigned int hb = sel[0], need2 = sel[1];
         __syncthreads();
-        if (tid < 256) hist[tid] = 0;
+        for (int i = tid; i < 16 * 256; i += 1024) (&whist[0][0])[i] = 0;
         __syncthreads();
         // pass 2: low-byte histogram inside the selected high-byte bin
         for (int i = tid; i < V8; i += 1024) {
@@ -950,13 +960,20 @@ __global__ __launch_bounds__(1024) void sample_topk_kernel(const uint16_t* __res
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t k0 = order_key16(w[j] & 0xFFFFu, BF16), k1 = order_key16(w[j] >> 16, BF16);
-                if ((k0 >> 8) == hb) atomicAdd(&hist[k0 & 0xFFu], 1u);
-                if ((k1 >> 8) == hb) atomicAdd(&hist[k1 & 0xFFu], 1u);
+                if ((k0 >> 8) == hb) atomicAdd(&whist[wave][k0 & 0xFFu], 1u);
+                if ((k1 >> 8) == hb) atomicAdd(&whist[wave][k1 & 0xFFu], 1u);
             }
         }
         for (int i = (V8 << 3) + tid; i < V; i += 1024) {
             const uint32_t k = order_key16(logits[i], BF16);
-            if ((k >> 8) == hb) atomicAdd(&hist[k & 0xFFu], 1u);
+            if ((k >> 8) == hb) atomicAdd(&whist[wave][k & 0xFFu], 1u);
+        }
+        __syncthreads();
+        if (tid < 256) {
+            unsigned int a = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) a += whist[w][tid];
+            hist[tid] = a;
         }
         __syncthreads();
         if (tid == 0) {
