@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--n_layer", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense comparator run")
-    ap.add_argument("--swizzle", type=int, default=1, help="XCD-decorrelating tile swizzle (A/B switch)")
+    ap.add_argument("--swizzle", type=int, default=0, help="XCD-decorrelating tile swizzle (A/B switch)")
+    ap.add_argument("--wave-local", type=int, default=1, help="wave-local compaction (A/B switch)")
     return ap.parse_args()
 
 
@@ -333,6 +334,7 @@ def main():
     runtime.init()
     from teal_amd import _lib
     _lib.load().teal_set_swizzle(a.swizzle)
+    _lib.load().teal_set_wave_local(a.wave_local)
     dt = {"fp16": torch.float16, "bf16": torch.bfloat16}[a.precision]
     torch.manual_seed(1234)
     mode = a.mode

@@ -185,6 +185,10 @@ int teal_sample_topk(const void* logits, int vocab, int dtype, int top_k, float 
  * Process-global; meant for benchmark sweeps only. */
 int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll);
 
+/* Wave-local compaction (default on): each wave streams the rows it ballots itself instead of an even share
+ * of a workgroup-wide list; removes every barrier between the activation and the first weight load. */
+int teal_set_wave_local(int on);
+
 /* Column-tile XOR swizzle that spreads every XCD over all DRAM channel residues (default on). */
 int teal_set_swizzle(int on);
 

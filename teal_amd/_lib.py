@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_PKG, "libteal_hip.so")
 EXPORTS = (
     "teal_version", "teal_strerror", "teal_init", "teal_workspace_bytes", "teal_compact",
     "teal_sparse_gemv", "teal_sparse_qkv_gemv", "teal_dense_gemv", "teal_sparse_gateup_silu",
-    "teal_set_tuning", "teal_get_config", "teal_set_phase_buffer", "teal_fused_gemv", "teal_decode_attention", "teal_sample_topk", "teal_set_swizzle", "teal_sparse_qkv_gemv_ld", "teal_decode_attention_masked",
+    "teal_set_tuning", "teal_get_config", "teal_set_phase_buffer", "teal_fused_gemv", "teal_decode_attention", "teal_sample_topk", "teal_set_swizzle", "teal_set_wave_local", "teal_sparse_qkv_gemv_ld", "teal_decode_attention_masked",
 )
 
 _lib = None
@@ -80,6 +80,7 @@ def load() -> ctypes.CDLL:
     L.teal_fused_gemv.argtypes = [vp, vp, ci, ci, vp, sz, ctypes.POINTER(ci), vp]
     L.teal_sample_topk.argtypes = [vp, ci, ci, ci, cf, vp, vp, vp, vp, ci, vp]
     L.teal_set_swizzle.argtypes = [ci]
+    L.teal_set_wave_local.argtypes = [ci]
     L.teal_decode_attention_masked.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, ci, vp]
     L.teal_decode_attention.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
     L.teal_get_config.argtypes = [ci, ci, ci, ctypes.POINTER(ci)]

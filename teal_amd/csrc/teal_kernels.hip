@@ -74,6 +74,7 @@ struct Params {
     int cap;       // LDS list capacity (entries)
     int to_ws;     // 1: always write fp32 slabs (an epilogue kernel follows)
     int swizzle;   // 1: XOR-swizzle tiles inside aligned groups of 8 (XCD decorrelation)
+    int wl;        // 1: wave-local compaction (no cross-wave list, no barriers before the stream); cap = per-wave capacity
     int ws_il;     // 1: slabs written interleaved, ws[col * stride + slice], stride = (split + 3) & ~3
     int pair;      // 1: seg[0] = gate, seg[1] = up over the SAME column tile; epilogue silu(g)*u -> seg[0].y
     unsigned long long* mask_out;  // pair: keep masks of the output vs mask_tau for the next launch (or null)
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
     int* wavecnt = reinterpret_cast<int*>(masks + nch);
     float* sumsq = reinterpret_cast<float*>(wavecnt + 16);
     uint32_t* list = reinterpret_cast<uint32_t*>(sumsq + 16);
-    float* red = reinterpret_cast<float*>(list + p.cap);
+    float* red = reinterpret_cast<float*>(list + (p.wl ? (size_t)p.cap * WAVES : (size_t)p.cap));
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -379,91 +380,137 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         for (int k = 0; k < KR; ++k) xr[k] = x[mcl[k]];
     }
     const unsigned long long* gmask = MODE == 3 ? p.in.masks : masks;  // where chunk masks live
-    if constexpr (MODE != 3) {
-        int mycnt = 0;
-    #pragma unroll
+    int nloc = 0;                      // entries this wave/workgroup will stream
+    const uint32_t* lp = list;         // where they are
+    int estride = STRIDE;              // distance between the U entries a lane takes in one batch
+    int eb = wave * RPW;               // first entry position of this wave
+    if (p.wl) {
+        // ---- wave-local compaction: every wave keeps the rows of the chunks it ballots itself (rounds
+        //      k == slice mod split belong to this workgroup).  No cross-wave list, hence no scan and NO
+        //      barrier between the activation and the first weight load.  Per-wave row counts differ by
+        //      the binomial spread only; the launch is HBM-bound, so that does not cost time.
+        uint32_t* mylist = list + (size_t)wave * p.cap;
+        int base = 0, kmod = 0;
+        unsigned long long mk[KR];
+        if constexpr (MODE == 3) {
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                const int c = (k / PER) * 64 + wave + (k % PER) * WAVES;
+                mk[k] = (c < nch) ? gmask[c] : 0ull;
+            }
+        }
+#pragma unroll
         for (int k = 0; k < KR; ++k) {
             const int c = (k / PER) * 64 + wave + (k % PER) * WAVES;
-            if (c < nch) {
-                const float v = bits_to_float(xr[k], BF16);
-                // NaN propagates like the reference's 0 * NaN on masked rows
-                const bool kp = ((c << 6) + lane < Z) && (keep_rule(v, tau) || (v != v));
+            const bool own = (kmod == slice) && (c < nch);
+            kmod = (kmod + 1 == p.split) ? 0 : kmod + 1;
+            if (own) {
+                unsigned long long mask;
+                if constexpr (MODE == 3) {
+                    mask = mk[k];
+                } else {
+                    const float v = bits_to_float(xr[k], BF16);
+                    mask = __ballot(((c << 6) + lane < Z) && (keep_rule(v, tau) || (v != v)));
+                }
+                if ((mask >> lane) & 1ull) mylist[base + lane_rank(mask)] = ((uint32_t)((c << 6) + lane) << 16) | xr[k];
+                base += __popcll(mask);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS is in-order per wave; keep the compiler honest
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        nloc = base;
+        lp = mylist;
+        estride = RPW;
+        eb = 0;
+        stamp(p, 1); stamp(p, 6); stamp(p, 2); stamp(p, 3);
+    } else {
+            if constexpr (MODE != 3) {
+            int mycnt = 0;
+        #pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                const int c = (k / PER) * 64 + wave + (k % PER) * WAVES;
+                if (c < nch) {
+                    const float v = bits_to_float(xr[k], BF16);
+                    // NaN propagates like the reference's 0 * NaN on masked rows
+                    const bool kp = ((c << 6) + lane < Z) && (keep_rule(v, tau) || (v != v));
+                    const unsigned long long mask = __ballot(kp);
+                    if (lane == 0) masks[c] = mask;
+                    mycnt += __popcll(mask);
+                }
+            }
+            for (int c = GREG * 64 + wave; c < nch; c += WAVES) {  // long vectors: beyond the register cache
+                const int m = (c << 6) + lane;
+                bool kp = false;
+                if (m < Z) {
+                    const float v = bits_to_float(load_act(m), BF16);
+                    kp = keep_rule(v, tau) || (v != v);
+                }
                 const unsigned long long mask = __ballot(kp);
                 if (lane == 0) masks[c] = mask;
                 mycnt += __popcll(mask);
             }
+            if (lane == 0) wavecnt[wave] = mycnt;
+            stamp(p, 1);
+            __syncthreads();
+            stamp(p, 6);
         }
-        for (int c = GREG * 64 + wave; c < nch; c += WAVES) {  // long vectors: beyond the register cache
-            const int m = (c << 6) + lane;
-            bool kp = false;
-            if (m < Z) {
-                const float v = bits_to_float(load_act(m), BF16);
-                kp = keep_rule(v, tau) || (v != v);
-            }
-            const unsigned long long mask = __ballot(kp);
-            if (lane == 0) masks[c] = mask;
-            mycnt += __popcll(mask);
-        }
-        if (lane == 0) wavecnt[wave] = mycnt;
-        stamp(p, 1);
-        __syncthreads();
-        stamp(p, 6);
-    }
 
-    // ---- phase B: every wave scans the chunk popcounts itself (DPP, no second barrier, no serial
-    //      wave) and scatters the (row, x) pairs of its own chunks into the LDS list, ascending ------
-    int total;
-    if constexpr (MODE == 3) {
-        int acc = 0;
-        for (int c = lane; c < nch; c += 64) acc += __popcll(gmask[c]);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-        total = __builtin_amdgcn_readfirstlane(acc);
-    } else {
-        int t = (lane < WAVES) ? wavecnt[lane] : 0;
-        t += __builtin_amdgcn_update_dpp(0, t, 0x111, 0xf, 0xf, false);
-        t += __builtin_amdgcn_update_dpp(0, t, 0x112, 0xf, 0xf, false);
-        t += __builtin_amdgcn_update_dpp(0, t, 0x114, 0xf, 0xf, false);
-        t += __builtin_amdgcn_update_dpp(0, t, 0x118, 0xf, 0xf, false);
-        total = __builtin_amdgcn_readlane(t, 15);  // WAVES <= 16: one DPP row holds every count
-    }
-    const int lo = (int)(((long long)total * slice) / p.split);
-    const int hi = (int)(((long long)total * (slice + 1)) / p.split);
-    const int nloc = hi - lo;
-    stamp(p, 7);
-    {
-        int base = 0;
-        auto scatter_group = [&](const int g0, const uint32_t* xg) {
-            const int cg = g0 + lane;
-            const int v = (cg < nch) ? __popcll(gmask[cg]) : 0;
-            const int incl = wave_incl_scan(v, lane);
-            const int excl = base + incl - v;
-            base += __builtin_amdgcn_readlane(incl, 63);
-#pragma unroll
-            for (int kk = 0; kk < PER; ++kk) {
-                const int j = wave + kk * WAVES;  // lane that holds an owned chunk's prefix (uniform)
-                const int c = g0 + j;
-                if (c >= nch) break;
-                const int pre = __builtin_amdgcn_readlane(excl, j);
-                const int cnt = __builtin_amdgcn_readlane(v, j);
-                if (pre + cnt <= lo || pre >= hi) continue;  // chunk outside this workgroup's share
-                const unsigned long long mask = gmask[c];
-                if ((mask >> lane) & 1ull) {
-                    const int m = (c << 6) + lane;
-                    const int pos = pre + lane_rank(mask);
-                    const uint32_t xb = xg ? xg[kk] : load_act(m);
-                    if (pos >= lo && pos < hi) list[pos - lo] = ((uint32_t)m << 16) | xb;
+        // ---- phase B: every wave scans the chunk popcounts itself (DPP, no second barrier, no serial
+        //      wave) and scatters the (row, x) pairs of its own chunks into the LDS list, ascending ------
+        int total;
+        if constexpr (MODE == 3) {
+            int acc = 0;
+            for (int c = lane; c < nch; c += 64) acc += __popcll(gmask[c]);
+    #pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+            total = __builtin_amdgcn_readfirstlane(acc);
+        } else {
+            int t = (lane < WAVES) ? wavecnt[lane] : 0;
+            t += __builtin_amdgcn_update_dpp(0, t, 0x111, 0xf, 0xf, false);
+            t += __builtin_amdgcn_update_dpp(0, t, 0x112, 0xf, 0xf, false);
+            t += __builtin_amdgcn_update_dpp(0, t, 0x114, 0xf, 0xf, false);
+            t += __builtin_amdgcn_update_dpp(0, t, 0x118, 0xf, 0xf, false);
+            total = __builtin_amdgcn_readlane(t, 15);  // WAVES <= 16: one DPP row holds every count
+        }
+        const int lo = (int)(((long long)total * slice) / p.split);
+        const int hi = (int)(((long long)total * (slice + 1)) / p.split);
+        nloc = hi - lo;
+        stamp(p, 7);
+        {
+            int base = 0;
+            auto scatter_group = [&](const int g0, const uint32_t* xg) {
+                const int cg = g0 + lane;
+                const int v = (cg < nch) ? __popcll(gmask[cg]) : 0;
+                const int incl = wave_incl_scan(v, lane);
+                const int excl = base + incl - v;
+                base += __builtin_amdgcn_readlane(incl, 63);
+    #pragma unroll
+                for (int kk = 0; kk < PER; ++kk) {
+                    const int j = wave + kk * WAVES;  // lane that holds an owned chunk's prefix (uniform)
+                    const int c = g0 + j;
+                    if (c >= nch) break;
+                    const int pre = __builtin_amdgcn_readlane(excl, j);
+                    const int cnt = __builtin_amdgcn_readlane(v, j);
+                    if (pre + cnt <= lo || pre >= hi) continue;  // chunk outside this workgroup's share
+                    const unsigned long long mask = gmask[c];
+                    if ((mask >> lane) & 1ull) {
+                        const int m = (c << 6) + lane;
+                        const int pos = pre + lane_rank(mask);
+                        const uint32_t xb = xg ? xg[kk] : load_act(m);
+                        if (pos >= lo && pos < hi) list[pos - lo] = ((uint32_t)m << 16) | xb;
+                    }
                 }
-            }
-        };
-#pragma unroll
-        for (int g = 0; g < GREG; ++g)
-            if (g * 64 < nch && base < hi) scatter_group(g * 64, &xr[g * PER]);
-        for (int g0 = GREG * 64; g0 < nch && base < hi; g0 += 64) scatter_group(g0, nullptr);
+            };
+    #pragma unroll
+            for (int g = 0; g < GREG; ++g)
+                if (g * 64 < nch && base < hi) scatter_group(g * 64, &xr[g * PER]);
+            for (int g0 = GREG * 64; g0 < nch && base < hi; g0 += 64) scatter_group(g0, nullptr);
+        }
+        stamp(p, 2);
+        __syncthreads();
+        stamp(p, 3);
     }
-    stamp(p, 2);
-    __syncthreads();
-    stamp(p, 3);
 
     // ---- stream the kept rows ----------------------------------------------------------------------
     const int g = lane / LPR;   // row group inside the wave
@@ -488,15 +535,14 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
 #pragma unroll
     for (int j = 0; j < (PAIR ? 8 : 1); ++j) acc2[j] = 0.0f;
 
-    int eb = wave * RPW;  // wave-uniform list position
     if (col_ok) {
-        constexpr int STEP = U * STRIDE;
-        auto full = [&](const int e) { return e + (U - 1) * STRIDE + RPW <= nloc; };
+        const int STEP = U * estride;
+        auto full = [&](const int e) { return e + (U - 1) * estride + RPW <= nloc; };
         // issue the U (x2 for PAIR) 16-byte loads of one batch; nothing here waits
         auto issue = [&](u32x4 (&w)[U], u32x4 (&w2)[PAIR ? U : 1], float (&xv)[U], const int e0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const uint32_t ent = list[e0 + u * STRIDE + g];
+                const uint32_t ent = lp[e0 + u * estride + g];
                 xv[u] = bits_to_float(ent & 0xFFFFu, BF16);
                 w[u] = __builtin_nontemporal_load(
                     reinterpret_cast<const u32x4*>(wp + (size_t)(ent >> 16) * ldb));
@@ -544,9 +590,9 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         if (eb < nloc) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int e = eb + u * STRIDE + g;
+                const int e = eb + u * estride + g;
                 const bool ok = e < nloc;
-                const uint32_t ent = list[ok ? e : nloc - 1];
+                const uint32_t ent = lp[ok ? e : nloc - 1];
                 xa[u] = ok ? bits_to_float(ent & 0xFFFFu, BF16) : 0.0f;
                 u32x4 t = __builtin_nontemporal_load(
                     reinterpret_cast<const u32x4*>(wp + (size_t)(ent >> 16) * ldb));
@@ -1040,6 +1086,7 @@ int g_num_cu = 0;
 Config g_override = {0, 0, 0, 0};
 unsigned long long* g_phase = nullptr;
 int g_swizzle = 0;
+int g_wave_local = 1;
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -1209,11 +1256,22 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
     p.split = c.split;
     p.ws_ld = off;
     p.cap = (p.Z + c.split - 1) / c.split + 1;
+    p.wl = 0;
+    if (g_wave_local && c.waves == 16) {
+        const int nch = (p.Z + 63) >> 6;
+        const int owned = (nch + 15) / 16;
+        const int krt = owned <= 4 ? 4 : (owned <= 8 ? 8 : 16);
+        const int capw = ((krt + c.split - 1) / c.split) * 64;  // entries one wave can own
+        if (owned <= krt && (size_t)16 * capw * 4 <= 40 * 1024) {
+            p.wl = 1;
+            p.cap = capw;
+        }
+    }
     p.to_ws = to_ws ? 1 : 0;
     p.ws = reinterpret_cast<float*>(ws);
     p.phase = g_phase;
     p.swizzle = g_swizzle;
-    const size_t lds = lds_bytes(p.Z, p.cap, c.waves, c.lpr, p.pair != 0);
+    const size_t lds = lds_bytes(p.Z, p.wl ? p.cap * c.waves : p.cap, c.waves, c.lpr, p.pair != 0);
     if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
     p.ws_il = (interleave && to_ws && c.split <= 8) ? 1 : 0;
     if (c.split > 1 || to_ws) {
@@ -1292,6 +1350,11 @@ int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll) {
         !in(unroll, {0, 4, 8}) || split < 0 || split > kMaxSplit)
         return TEAL_ERR_CONFIG;
     g_override = {lanes_per_row, waves, split, unroll};
+    return TEAL_OK;
+}
+
+int teal_set_wave_local(int on) {
+    g_wave_local = on ? 1 : 0;
     return TEAL_OK;
 }
 

@@ -164,10 +164,13 @@ def test_ragged_shapes_vs_oracle(oracle, Z, N, dtype):
     check_gemv(oracle, bits_from_torch(yd.view(-1)), oracle.truth64(xb, wb, Z, N, -1.0, dtype=dtype), dtype)
 
 
-def test_every_launch_geometry_agrees(oracle):
-    """all (lanes_per_row, waves, split, unroll) variants compute the same GEMV (within rounding)."""
+@pytest.mark.parametrize("wave_local", [1, 0])
+def test_every_launch_geometry_agrees(oracle, wave_local):
+    """all (lanes_per_row, waves, split, unroll) variants compute the same GEMV (within rounding), with
+    the wave-local compaction and with the workgroup-wide even-share list."""
     from teal_amd import _lib
     L = _lib.load()
+    L.teal_set_wave_local(wave_local)
     Z, N, dtype = 1536, 1280, 0
     xb = oracle.hash_uniform(Z, 5, 4.0, dtype)
     wb = oracle.hash_uniform_c(Z * N, 6, 0.1, dtype)
@@ -184,6 +187,7 @@ def test_every_launch_geometry_agrees(oracle):
                         check_gemv(oracle, bits_from_torch(y.view(-1)), truth, dtype, None, f"cfg {lpr},{waves},{split},{unroll}")
     finally:
         L.teal_set_tuning(0, 0, 0, 0)
+        L.teal_set_wave_local(1)
 
 
 @pytest.mark.parametrize("Z,N,dtype,s", [(8192, 8192, 0, 0.5), (8192, 28672, 0, 0.5), (28672, 8192, 0, 0.5),
@@ -232,8 +236,9 @@ def test_gateup_silu_fusion_equals_unfused_sequence(oracle):
         diff = (got.float() - want.float()).abs()
         ulp = torch.from_numpy(oracle.ulp16(want.float().cpu().numpy(), dtype)).to(DEV)
         # silu's expf may round differently from torch's by 1 ulp of the fp16 activation
-        assert (diff.view(-1) <= 2 * ulp.view(-1).float() + 1e-7).all(), float(diff.max())
-        assert (diff == 0).float().mean() > 0.95
+        # + a 1-ulp difference of gate (different fp32 summation order) scaled by |up|
+        assert (diff.view(-1) <= 2 * ulp.view(-1).float() + 1e-3).all(), float(diff.max())
+        assert (diff == 0).float().mean() > 0.9
 
 
 def test_hipgraph_capture_and_replay(oracle):
@@ -259,6 +264,28 @@ def test_hipgraph_capture_and_replay(oracle):
     torch.cuda.synchronize()
     want = K().splitk_sparse_gemv(x * 0.5, W, 1.0, 0)
     assert torch.equal(out.view(torch.int16), want.view(torch.int16))
+
+
+@pytest.mark.parametrize("Z,N,dtype", [(4096, 4096, 0), (11008, 4096, 0), (4096, 11008, 1), (1000, 1000, 0), (8192, 8192, 0)])
+def test_wave_local_and_list_paths_agree(oracle, Z, N, dtype):
+    """the two compaction strategies keep the same rows; results agree to fp32 summation order"""
+    from teal_amd import _lib
+    L = _lib.load()
+    xb = oracle.hash_uniform(Z, 71, 4.0, dtype)
+    wb = oracle.hash_uniform_c(Z * N, 72, 0.08, dtype)
+    x = torch_from_bits(xb, dtype, DEV).view(1, 1, Z)
+    W = colmajor_weight(wb, Z, N, dtype, DEV)
+    truth = oracle.truth64(xb, wb, Z, N, 1.0, dtype=dtype)
+    try:
+        outs = []
+        for wl in (1, 0):
+            L.teal_set_wave_local(wl)
+            y = K().splitk_sparse_gemv(x, W, 1.0, 0)
+            check_gemv(oracle, bits_from_torch(y.view(-1)), truth, dtype, None, f"wl={wl}")
+            outs.append(y.float())
+        assert (outs[0] - outs[1]).abs().max() <= 2 * float(oracle.ulp16(np.abs(truth).max(), dtype))
+    finally:
+        L.teal_set_wave_local(1)
 
 
 def test_padded_row_stride_equals_unpadded(oracle):
