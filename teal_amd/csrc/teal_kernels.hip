@@ -1124,15 +1124,29 @@ Config pick_config(int Z, int ncols_total, int nseg_tiles_hint) {
             c.lpr = 8;
             for (int lpr = 64; lpr > 8; lpr >>= 1)
                 if ((ncols_total + lpr * 8 - 1) / (lpr * 8) >= ncu) { c.lpr = lpr; break; }
-        } else {  // few columns: 512-byte row segments, split the kept rows to reach ~1 WG per CU
-            c.lpr = ncols_total >= 2048 ? 32 : 8;
-            const int tiles = (ncols_total + c.lpr * 8 - 1) / (c.lpr * 8);
-            int split = ncu / tiles;
-            const int max_by_rows = Z / (4 * c.waves * (64 / c.lpr));  // >= ~2 steps per workgroup at 50 %
-            if (split > max_by_rows) split = max_by_rows;
-            if (split < 1) split = 1;
-            if (split > kMaxSplit) split = kMaxSplit;
-            c.split = split;
+        } else {  // few columns: 64-column tiles, split the kept rows to reach ~1 workgroup per CU.  With the
+                  // wave-local compaction a slice is a set of 16-chunk rounds, so split <= rounds (and <= 8
+                  // keeps the slab count small for consumers that re-read them); without it, 512-byte row
+                  // segments and a deeper split measured best.
+            const int rounds = (((Z + 63) >> 6) + 15) / 16;
+            if (g_wave_local && rounds >= 2) {
+                c.lpr = 8;
+                const int tiles = (ncols_total + 63) / 64;
+                int split = ncu / tiles;
+                if (split > rounds) split = rounds;
+                if (split > 8) split = 8;
+                if (split < 1) split = 1;
+                c.split = split;
+            } else {
+                c.lpr = ncols_total >= 2048 ? 32 : 8;
+                const int tiles = (ncols_total + c.lpr * 8 - 1) / (c.lpr * 8);
+                int split = ncu / tiles;
+                const int max_by_rows = Z / (4 * c.waves * (64 / c.lpr));  // >= ~2 steps per workgroup at 50 %
+                if (split > max_by_rows) split = max_by_rows;
+                if (split < 1) split = 1;
+                if (split > kMaxSplit) split = kMaxSplit;
+                c.split = split;
+            }
         }
     }
     if (g_override.lpr) c.lpr = g_override.lpr;
@@ -1262,7 +1276,7 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
         const int owned = (nch + 15) / 16;
         const int krt = owned <= 4 ? 4 : (owned <= 8 ? 8 : 16);
         const int capw = ((krt + c.split - 1) / c.split) * 64;  // entries one wave can own
-        if (owned <= krt && (size_t)16 * capw * 4 <= 40 * 1024) {
+        if (owned <= krt && c.split <= owned && (size_t)16 * capw * 4 <= 40 * 1024) {
             p.wl = 1;
             p.cap = capw;
         }
