@@ -51,15 +51,27 @@ def parse():
 
 
 def dist_setup(n):
+    """one process per GPU (torch.distributed.run sets RANK/LOCAL_RANK/WORLD_SIZE).  RCCL ("nccl") on a
+    GPU box; gloo when no GPU is visible (the CPU test of this replica/timing logic)."""
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    torch.cuda.set_device(local)
+    have_gpu = torch.cuda.is_available()
+    if have_gpu:
+        torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if have_gpu:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
     return rank, world, local
+
+
+def _sync():
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
 
 
 def barrier(world):
@@ -72,21 +84,26 @@ def timed_decode(step_fn, steps, warmup, world):
     """W untimed steps, then exactly K steps between barrier+synchronize on both sides."""
     for _ in range(warmup):
         step_fn()
-    torch.cuda.synchronize()
+    _sync()
     barrier(world)
-    torch.cuda.synchronize()
+    _sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         step_fn()
-    torch.cuda.synchronize()
+    _sync()
     barrier(world)
     t = time.perf_counter() - t0
-    if world > 1:
+    if world > 1:  # the job's time is the slowest replica's
         import torch.distributed as dist
-        tt = torch.tensor([t], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([t], device="cuda" if torch.cuda.is_available() else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t = float(tt.item())
     return t
+
+
+def aggregate_tokens_per_sec(world, steps, t):
+    """replicas only (no data-path collective): every rank decodes `steps` tokens of its own stream."""
+    return world * steps / t
 
 
 def make_stepper(model, a, dense=False):
@@ -354,7 +371,7 @@ def main():
     else:
         step, info = make_stepper(model, a)
     t = timed_decode(step, a.steps, a.warmup, world)
-    tps = world * a.steps / t
+    tps = aggregate_tokens_per_sec(world, a.steps, t)
     out = {"metric": "decode tokens/sec (bs=1), Llama-2-7B fp16 @50% activation sparsity", "value": tps, "unit": "tokens/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": t / a.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if dt == torch.float16 else "bf16",

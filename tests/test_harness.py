@@ -139,3 +139,29 @@ def test_sparse_thresholds_reduce_rows_read():
     x = torch.randn(1, 1, 256, device=dev, dtype=torch.float16) * 0.05
     _, n = K.compact(x, ths[0]["q"])
     assert 0 <= n <= 256
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--engine"], [], ["--engine", "--precision", "bf16"], ["--engine", "--sparsity", "0.0"]])
+def test_generate_main_synthetic_cli(extra):
+    """the reference-shaped CLI end to end on a tiny synthetic model: load -> monkeypatch -> capture ->
+    timed samples, through the fused engine and through the module path."""
+    args = G.build_parser().parse_args(["--synthetic", "tiny-test", "--sparsity", "0.5", "--compile", "--num_samples", "2",
+                                        "--max_new_tokens", "16", "--top_k", "50", "--report_kept"] + extra)
+    res = G.main(args)
+    assert len(res["tokens_per_sec"]) == 2 and all(t > 0 for t in res["tokens_per_sec"])
+    assert res["thresholds"] is not None and len(res["thresholds"]) == 2
+
+
+@pytest.mark.gpu
+def test_generate_greedy_fixture_table():
+    """block-wise greedy sparsities from the reference-derived table (tests/golden/greedy_llama2_7b.json):
+    three distinct q/k/v thresholds and gate != up reach the kernels."""
+    import os
+    from helpers import GOLDEN
+    m = G.build_synthetic_model("tiny-test", "cuda", torch.float16, seed=3, std=0.05)
+    ths = G.apply_sparsity(m, sparsity=0.5, hist_path=None, greedy_lookup=os.path.join(GOLDEN, "greedy_llama2_7b.json"),
+                           synthetic=True)
+    assert len({ths[0]["q"], ths[0]["k"], ths[0]["v"]}) == 3 and ths[0]["gate"] != ths[0]["up"]
+    at = m.layers[0].attention
+    assert (at.thresh_q, at.thresh_k, at.thresh_v) == (ths[0]["q"], ths[0]["k"], ths[0]["v"])
