@@ -753,7 +753,7 @@ __global__ __launch_bounds__(NT) void decode_attention_kernel(
     constexpr int hd = HD;
     constexpr int SL = HD / 8;   // 16-byte slices per row (16 for hd=128, 8 for hd=64)
     constexpr int RW = 64 / SL;  // V rows per wave step (4 or 8)
-    constexpr int VPF = 4;       // V steps prefetched (covers pos < VPF * NW * RW = 256 / 512)
+    constexpr int VPF = 256 / (NW * RW) > 0 ? 256 / (NW * RW) : 1;  // V steps prefetched: the first 256 rows (hd=128)
     extern __shared__ __align__(16) unsigned char smem[];
     float* qs = reinterpret_cast<float*>(smem);  // [hd] rotated q
     float* kn = qs + hd;                         // [hd] rotated new k
@@ -1557,21 +1557,25 @@ int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_
     if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
     if ((head_dim != 64 && head_dim != 128) || n_head <= 0 || n_kv_head <= 0 || n_head % n_kv_head || max_seq <= 0)
         return TEAL_ERR_SHAPE;
-    constexpr int NT = 1024;
-    const size_t lds = (size_t)(3 * head_dim + 2 * (NT / 64) + (NT / 64) * head_dim + max_seq) * sizeof(float);
+    // short contexts: 4 waves per head (cheaper barriers and dispatch, everything prefetched);
+    // long contexts: 16 waves so that one pass covers 1024 positions
+    const int nt = max_seq <= 512 ? 256 : 1024;
+    const size_t lds = (size_t)(3 * head_dim + 2 * (nt / 64) + (nt / 64) * head_dim + max_seq) * sizeof(float);
     if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const float scale = 1.0f / sqrtf((float)head_dim);
-    const dim3 grid(n_head), block(NT);
+    const dim3 grid(n_head), block(nt);
     auto* q = reinterpret_cast<const uint16_t*>(qkv);
     auto* r = reinterpret_cast<const uint16_t*>(rope);
     auto* kc = reinterpret_cast<uint16_t*>(k_cache);
     auto* vc = reinterpret_cast<uint16_t*>(v_cache);
     auto* yo = reinterpret_cast<uint16_t*>(y);
     auto* mo = reinterpret_cast<unsigned long long*>(mask_out);
-#define TEAL_ATT(BF, HDV) hipLaunchKernelGGL((decode_attention_kernel<BF, NT, HDV>), grid, block, lds, st, q, r, pos, kc, vc, yo, mo, mask_tau, n_head, n_kv_head, max_seq, scale)
-    if (dtype == TEAL_BF16) { if (head_dim == 128) TEAL_ATT(true, 128); else TEAL_ATT(true, 64); }
-    else { if (head_dim == 128) TEAL_ATT(false, 128); else TEAL_ATT(false, 64); }
+#define TEAL_ATT(BF, NTV, HDV) hipLaunchKernelGGL((decode_attention_kernel<BF, NTV, HDV>), grid, block, lds, st, q, r, pos, kc, vc, yo, mo, mask_tau, n_head, n_kv_head, max_seq, scale)
+#define TEAL_ATT_HD(BF, NTV) do { if (head_dim == 128) TEAL_ATT(BF, NTV, 128); else TEAL_ATT(BF, NTV, 64); } while (0)
+    if (dtype == TEAL_BF16) { if (nt == 256) TEAL_ATT_HD(true, 256); else TEAL_ATT_HD(true, 1024); }
+    else { if (nt == 256) TEAL_ATT_HD(false, 256); else TEAL_ATT_HD(false, 1024); }
+#undef TEAL_ATT_HD
 #undef TEAL_ATT
     return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
 }

@@ -28,8 +28,8 @@ def test_decode_attention_kernel_vs_torch(dtype):
     from teal_amd.gpt_fast.model import apply_rotary_emb, precompute_freqs_cis
     L = _lib.load()
     runtime.init()
-    for n_head, n_kv, hd, pos in ((4, 2, 64, 0), (4, 2, 64, 17), (8, 8, 128, 40), (8, 2, 128, 63)):
-        S = 64
+    for n_head, n_kv, hd, pos, S in ((4, 2, 64, 0, 64), (4, 2, 64, 17, 64), (8, 8, 128, 40, 64), (8, 2, 128, 63, 64),
+                                     (4, 2, 128, 300, 512), (4, 4, 64, 700, 2048), (8, 2, 128, 1500, 2048)):
         g = torch.Generator(device=DEV).manual_seed(pos + hd)
         qkv = (torch.randn((n_head + 2 * n_kv) * hd, device=DEV, generator=g) * 0.5).to(dtype)
         kc = (torch.randn(n_kv, S, hd, device=DEV, generator=g) * 0.5).to(dtype)
