@@ -20,6 +20,7 @@ Fixtures written:
   F4 kat_qkv_*.npz           same with three thresholds (MHA + GQA geometries)
   F5 kat_boundary.npz        compare-rule edge values run through the reference kernel
   F6 hist/…/histograms.pt, lookup/…/results.csv   raw calibration data files (MIT, data only)
+  F7 kat_hist_producer.npz   ActivationModule.find_histogram on seeded activations (producer-side KAT)
 
 Usage:  python oracle/gen_golden.py [--quick]
 """
@@ -266,6 +267,33 @@ def gen_boundary(inner, SparsifyFn):
     print(f"  F5 boundary: probe keeps fp16(0.1)? {0 in k};  nan poisons all: {bool(np.isnan(O.from_bits(out['nan_y'], 0)).all())}")
 
 
+def gen_hist_producer():
+    """F7: the reference's own ActivationModule.find_histogram (utils/utils.py:145-177) on a seeded
+    activation tensor.  It moves data to 'cuda' for the sort; there is no GPU in this container, so
+    Tensor.to is shimmed to ignore that one device argument while the reference code runs."""
+    from utils.utils import ActivationModule  # type: ignore
+    g = torch.Generator().manual_seed(123)
+    acts = torch.randn(6, 512, generator=g) * 0.7
+    acts[0, :8] = torch.tensor([9.0, -11.0, 7.5, -6.0, 12.0, -3.0, 5.0, 4.0])  # outliers
+    am = ActivationModule("/tmp/unused")
+    am.activations = {"h1": [acts[:3]], "h2": [acts[3:] * 2.0 + 0.1]}
+    orig_to = torch.Tensor.to
+
+    def to_no_cuda(self, *a, **k):
+        if a and a[0] == "cuda":
+            return self
+        return orig_to(self, *a, **k)
+
+    torch.Tensor.to = to_no_cuda
+    try:
+        hist = am.find_histogram(num_bins=1000, outlier_threshold=0.01)
+    finally:
+        torch.Tensor.to = orig_to
+    np.savez_compressed(os.path.join(OUT, "kat_hist_producer.npz"), acts=acts.numpy(), num_bins=1000,
+                        **{k: v.numpy() for k, v in hist.items()})
+    print("  F7 find_histogram:", {k: tuple(v.shape) for k, v in hist.items()})
+
+
 def copy_raw_data():
     for sub in ("mlp", "self_attn"):
         for layer in (0, 15):
@@ -296,6 +324,7 @@ def main():
         "index": lambda: gen_index_only(a.quick),
         "gemv": lambda: gen_gemv_kats(inner, a.quick),
         "qkv": lambda: gen_qkv_kats(qkv_inner, a.quick),
+        "hist_producer": gen_hist_producer,
         "raw": copy_raw_data,
     }
     for name, fn in steps.items():
