@@ -292,3 +292,34 @@ def test_interleaved_slabs_equal_planar():
         outs.append((y.clone(), rout.clone()))
     assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
     assert torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
+
+
+@pytest.mark.parametrize("name,dtype,n_layer", [("7B", torch.float16, 2), ("llama-3-8b", torch.bfloat16, 1)])
+def test_engine_matches_module_path_full_width(name, dtype, n_layer):
+    """real layer widths (MHA 4096/11008 and GQA 4096/14336 with the 128k vocabulary), every row kept so
+    that no threshold can flip: fused engine vs unfused module path over a few tokens."""
+    from teal_amd.gpt_fast import generate as G
+    from teal_amd.gpt_fast.engine import DecodeEngine
+    ref = G.build_synthetic_model(name, DEV, dtype, seed=5, n_layer=n_layer)
+    eng_m = G.build_synthetic_model(name, DEV, dtype, seed=5, n_layer=n_layer)
+    ths = G.apply_sparsity(ref, sparsity=0.0, hist_path=None, greedy_lookup=None, synthetic=True)
+    G.apply_sparsity(eng_m, sparsity=0.0, hist_path=None, greedy_lookup=None, synthetic=True)
+    V = ref.config.vocab_size
+    prompt = torch.randint(0, V, (6,), device=DEV, dtype=torch.int, generator=torch.Generator(device=DEV).manual_seed(2))
+    with torch.no_grad():
+        for m in (ref, eng_m):
+            m.max_seq_length = -1
+            m.setup_caches(1, 32)
+            m(prompt.view(1, -1), torch.arange(6, device=DEV))
+        eng = DecodeEngine(eng_m, ths)
+        tok = torch.tensor([[17]], device=DEV, dtype=torch.int)
+        for step in range(3):
+            pos = torch.tensor([6 + step], device=DEV, dtype=torch.int)
+            a = ref(tok, pos).float().view(-1)
+            b = eng(tok, pos).float().view(-1)
+            scale = float(a.abs().max())
+            tol = (4e-3 if dtype == torch.float16 else 4e-2) * max(1.0, scale)
+            assert float((a - b).abs().max()) <= tol, (step, float((a - b).abs().max()), scale)
+            tok = a.argmax().view(1, 1).to(torch.int)
+    del ref, eng_m, eng
+    torch.cuda.empty_cache()
