@@ -933,6 +933,27 @@ __device__ __forceinline__ uint32_t hash3(uint32_t a, uint32_t b, uint32_t c) {
     return h;
 }
 
+// sel[0] = the bin b (counted from the top) in which the `need`-th largest key falls, sel[1] = its rank
+// inside that bin.  hist[256] -> suffix counts by a Hillis-Steele scan (all threads must call this).
+__device__ __forceinline__ void select_bin(const unsigned int* hist, unsigned int* suf, unsigned int* sel,
+                                           const unsigned int need, const int tid) {
+    if (tid < 256) suf[tid] = hist[tid];
+    __syncthreads();
+#pragma unroll
+    for (int d = 1; d < 256; d <<= 1) {
+        const unsigned int v = (tid < 256 && tid + d < 256) ? suf[tid + d] : 0u;
+        __syncthreads();
+        if (tid < 256) suf[tid] += v;
+        __syncthreads();
+    }
+    if (tid < 256) {
+        const unsigned int above = tid < 255 ? suf[tid + 1] : 0u;  // keys in strictly higher bins
+        if (suf[tid] >= need && above < need) { sel[0] = (unsigned int)tid; sel[1] = need - above; }
+    }
+    if (tid == 0 && suf[0] < need) { sel[0] = 0u; sel[1] = need; }  // fewer keys than requested: keep all
+    __syncthreads();
+}
+
 template <bool BF16>
 __global__ __launch_bounds__(1024) void sample_topk_kernel(const uint16_t* __restrict__ logits, const int V,
                                                             const int top_k, const float inv_temp,
@@ -945,6 +966,7 @@ __global__ __launch_bounds__(1024) void sample_topk_kernel(const uint16_t* __res
     __shared__ float fred[16];
     __shared__ int ired[16];
     __shared__ unsigned int sel[2];
+    __shared__ unsigned int suf[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool filter = top_k > 0 && top_k < V;
     const int V8 = V >> 3;  // 16-byte vectors (vocab sizes are multiples of 8; the tail is handled scalar)
@@ -985,16 +1007,8 @@ __global__ __launch_bounds__(1024) void sample_topk_kernel(const uint16_t* __res
 #pragma unroll
     for (int w = 1; w < 16; ++w) mx = fmaxf(mx, fred[w]);
     if (filter) {
-        if (tid == 0) {
-            unsigned int need = (unsigned int)top_k, acc = 0;
-            int bsel = 0;
-            for (int b = 255; b >= 0; --b) {
-                if (acc + hist[b] >= need) { bsel = b; break; }
-                acc += hist[b];
-            }
-            sel[0] = (unsigned int)bsel;
-            sel[1] = need - acc;  // rank wanted inside the selected bin
-        }
+        // suffix counts over the 256 bins (parallel scan), then the bin holding the top_k-th key
+        select_bin(hist, suf, sel, (unsigned int)top_k, tid);
         __syncthreads();
         const unsigned int hb = sel[0], need2 = sel[1];
         __syncthreads();
@@ -1022,15 +1036,8 @@ __global__ __launch_bounds__(1024) void sample_topk_kernel(const uint16_t* __res
             hist[tid] = a;
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned int acc = 0;
-            int bsel = 0;
-            for (int b = 255; b >= 0; --b) {
-                if (acc + hist[b] >= need2) { bsel = b; break; }
-                acc += hist[b];
-            }
-            sel[0] = (hb << 8) | (unsigned int)bsel;
-        }
+        select_bin(hist, suf, sel, need2, tid);
+        if (tid == 0) sel[0] = (hb << 8) | sel[0];
         __syncthreads();
         pivot_key = sel[0];
     }
