@@ -169,6 +169,14 @@ int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_
                                  void* y, void* mask_out, float mask_tau, int n_head, int n_kv_head, int head_dim,
                                  int max_seq, int dtype, void* stream);
 
+/* Long-context form (flash-decoding): the cached positions of every head are split over `nsplit` workgroups
+ * that write un-normalised partials {max, sum, o[head_dim]} (fp32, n_head*nsplit*(head_dim+2) floats), then
+ * a merge launch rescales, sums, rounds once and emits the masks.  Use when max_seq is in the thousands:
+ * one workgroup per head would leave most CUs idle while n_head of them stream the whole KV cache. */
+int teal_decode_attention_split(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,
+                                void* y, void* mask_out, float mask_tau, int n_head, int n_kv_head, int head_dim,
+                                int max_seq, int nsplit, void* partials, size_t partials_bytes, int dtype, void* stream);
+
 /* Sampling step of the decode loop (gpt-fast/generate.py:49-66): logits / temperature, top-k filter
  * (ties at the pivot kept), softmax, exponential-race multinomial.  rng_state = device uint64[2]
  * {seed, draw counter}; the kernel bumps the counter so hipGraph replays draw fresh numbers.

@@ -915,6 +915,172 @@ __global__ __launch_bounds__(NT) void decode_attention_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Long contexts: split the cached positions of a head over `nsplit` workgroups (flash-decoding).
+// Each workgroup produces an un-normalised partial {running max m, sum l, o[hd]} over its range; the
+// merge kernel rescales and sums them, rounds once and emits the keep masks for the wo projection.
+// With one workgroup per head a 4k context would leave 224 CUs idle while 32 stream 2 MB each.
+// ------------------------------------------------------------------------------------------------
+template <bool BF16, int HD>
+__global__ __launch_bounds__(256) void decode_attention_split_kernel(
+    const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ rope, const int* __restrict__ pos_ptr,
+    uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache, float* __restrict__ partials,
+    const int n_head, const int n_kv, const int max_seq, const int nsplit, const int chunk_max, const float scale) {
+    constexpr int NT = 256, NW = NT / 64, hd = HD, SL = HD / 8, RW = 64 / SL;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* qs = reinterpret_cast<float*>(smem);
+    float* kn = qs + hd;
+    float* vn = kn + hd;
+    float* red = vn + hd;            // [2 * NW]
+    float* part = red + 2 * NW;      // [NW][hd]
+    float* sc = part + NW * hd;      // [chunk_max]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+    const int rep = n_head / n_kv, kvh = h / rep;
+    const int pos = pos_ptr[0], n = pos + 1;
+    const int chunk = (n + nsplit - 1) / nsplit;
+    const int t0 = sp * chunk, t1 = min(n, t0 + chunk);
+    float* out = partials + (size_t)blockIdx.x * (hd + 2);
+    if (t0 >= t1) {  // empty range (short sequence, many splits)
+        if (tid < hd) out[2 + tid] = 0.0f;
+        if (tid == 0) { out[0] = -INFINITY; out[1] = 0.0f; }
+        return;
+    }
+    const bool has_new = (t1 == n);  // this workgroup's range ends with the token being decoded
+    const int dim = n_head * hd, kvs = n_kv * hd;
+    const uint16_t* qh = qkv + (size_t)h * hd;
+    const uint16_t* kh = qkv + dim + (size_t)kvh * hd;
+    const uint16_t* vh = qkv + dim + kvs + (size_t)kvh * hd;
+    uint16_t* kc = k_cache + (size_t)kvh * max_seq * hd;
+    uint16_t* vc = v_cache + (size_t)kvh * max_seq * hd;
+    if (tid < hd / 2) {
+        const float c = bits_to_float(rope[((size_t)pos * (hd / 2) + tid) * 2], BF16);
+        const float sn = bits_to_float(rope[((size_t)pos * (hd / 2) + tid) * 2 + 1], BF16);
+        const float q0 = bits_to_float(qh[2 * tid], BF16), q1 = bits_to_float(qh[2 * tid + 1], BF16);
+        qs[2 * tid] = bits_to_float(float_to_bits<BF16>(q0 * c - q1 * sn), BF16);
+        qs[2 * tid + 1] = bits_to_float(float_to_bits<BF16>(q1 * c + q0 * sn), BF16);
+        if (has_new) {
+            const float k0 = bits_to_float(kh[2 * tid], BF16), k1 = bits_to_float(kh[2 * tid + 1], BF16);
+            const uint16_t ka = float_to_bits<BF16>(k0 * c - k1 * sn), kb = float_to_bits<BF16>(k1 * c + k0 * sn);
+            kn[2 * tid] = bits_to_float(ka, BF16);
+            kn[2 * tid + 1] = bits_to_float(kb, BF16);
+            if (h % rep == 0) {
+                kc[(size_t)pos * hd + 2 * tid] = ka;
+                kc[(size_t)pos * hd + 2 * tid + 1] = kb;
+            }
+        }
+    } else if (has_new && tid >= 128 && tid < 128 + hd) {
+        const int d = tid - 128;
+        const uint16_t vb = vh[d];
+        vn[d] = bits_to_float(vb, BF16);
+        if (h % rep == 0) vc[(size_t)pos * hd + d] = vb;
+    }
+    __syncthreads();
+    float lmax = -INFINITY;
+    for (int t = t0 + tid; t < t1; t += NT) {
+        float a = 0.0f;
+        if (t == pos) {
+            for (int e = 0; e < hd; ++e) a += qs[e] * kn[e];
+        } else {
+            const u32x4* kr = reinterpret_cast<const u32x4*>(kc + (size_t)t * hd);
+#pragma unroll
+            for (int v8 = 0; v8 < SL; ++v8) {
+                const u32x4 w = kr[v8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a += qs[v8 * 8 + 2 * j] * bits_to_float(w[j] & 0xFFFFu, BF16);
+                    a += qs[v8 * 8 + 2 * j + 1] * bits_to_float(w[j] >> 16, BF16);
+                }
+            }
+        }
+        const float sv = bits_to_float(float_to_bits<BF16>(a * scale), BF16);
+        sc[t - t0] = sv;
+        lmax = fmaxf(lmax, sv);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, d));
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    float mx = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w]);
+    float lsum = 0.0f;
+    for (int t = t0 + tid; t < t1; t += NT) {
+        const float e = expf(sc[t - t0] - mx);
+        sc[t - t0] = e;
+        lsum += e;
+    }
+    lsum = wave_sum_f(lsum);
+    if (lane == 0) red[NW + wave] = lsum;
+    __syncthreads();
+    float tot = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += red[NW + w];
+    const int ds = lane % SL, rw = lane / SL;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.0f;
+#pragma unroll 4
+    for (int t = t0 + wave * RW + rw; t < t1; t += NW * RW) {
+        const float pr = sc[t - t0];
+        if (t == pos) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += pr * vn[ds * 8 + j];
+        } else {
+            const u32x4 w = *reinterpret_cast<const u32x4*>(vc + (size_t)t * hd + ds * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[2 * j] += pr * bits_to_float(w[j] & 0xFFFFu, BF16);
+                o[2 * j + 1] += pr * bits_to_float(w[j] >> 16, BF16);
+            }
+        }
+    }
+    for (int off = SL; off < 64; off <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += __shfl_xor(o[j], off);
+    }
+    if (lane < SL) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[wave * hd + lane * 8 + j] = o[j];
+    }
+    __syncthreads();
+    if (tid < hd) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) acc += part[w * hd + tid];
+        out[2 + tid] = acc;
+    }
+    if (tid == 0) { out[0] = mx; out[1] = tot; }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(128) void decode_attention_merge_kernel(const float* __restrict__ partials,
+                                                                     uint16_t* __restrict__ y,
+                                                                     unsigned long long* __restrict__ mask_out,
+                                                                     const float mask_tau, const int hd, const int nsplit) {
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const float* p = partials + (size_t)h * nsplit * (hd + 2);
+    if (tid >= hd) return;  // hd = 64 or 128: whole waves
+    float M = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, p[(size_t)s * (hd + 2)]);
+    float L = 0.0f, O = 0.0f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float* ps = p + (size_t)s * (hd + 2);
+        if (ps[1] > 0.0f) {
+            const float f = expf(ps[0] - M);
+            L += ps[1] * f;
+            O += ps[2 + tid] * f;
+        }
+    }
+    const uint16_t yb = float_to_bits<BF16>(O / L);
+    y[(size_t)h * hd + tid] = yb;
+    if (mask_out) {
+        const float yv = bits_to_float(yb, BF16);
+        const unsigned long long mk = __ballot(keep_rule(yv, mask_tau) || (yv != yv));
+        if (lane == 0) mask_out[((size_t)h * hd + tid) >> 6] = mk;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused sampler (gpt-fast/generate.py:49-66): logits / T -> keep the top-k -> softmax -> exponential-
 // race multinomial (argmax p_i / q_i, q_i ~ Exp(1)), no host sync.  One workgroup; the k-th largest
 // logit is found EXACTLY by a two-pass radix select on the 16-bit keys (ties at the pivot are all
@@ -1584,6 +1750,40 @@ int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_
     else { if (nt == 256) TEAL_ATT_HD(false, 256); else TEAL_ATT_HD(false, 1024); }
 #undef TEAL_ATT_HD
 #undef TEAL_ATT
+    return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
+}
+
+int teal_decode_attention_split(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,
+                                void* y, void* mask_out, float mask_tau, int n_head, int n_kv_head, int head_dim,
+                                int max_seq, int nsplit, void* partials, size_t partials_bytes, int dtype, void* stream) {
+    if (!qkv || !rope || !pos || !k_cache || !v_cache || !y || !partials) return TEAL_ERR_ARG;
+    if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
+    if ((head_dim != 64 && head_dim != 128) || n_head <= 0 || n_kv_head <= 0 || n_head % n_kv_head || max_seq <= 0 ||
+        nsplit < 1 || nsplit > 64)
+        return TEAL_ERR_SHAPE;
+    if (partials_bytes < (size_t)n_head * nsplit * (head_dim + 2) * sizeof(float)) return TEAL_ERR_WORKSPACE;
+    const int chunk_max = (max_seq + nsplit - 1) / nsplit;
+    const size_t lds = (size_t)(3 * head_dim + 8 + 4 * head_dim + chunk_max) * sizeof(float);
+    if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    auto* q = reinterpret_cast<const uint16_t*>(qkv);
+    auto* r = reinterpret_cast<const uint16_t*>(rope);
+    auto* kc = reinterpret_cast<uint16_t*>(k_cache);
+    auto* vc = reinterpret_cast<uint16_t*>(v_cache);
+    auto* pw = reinterpret_cast<float*>(partials);
+    const dim3 grid(n_head * nsplit), block(256);
+#define TEAL_ATTS(BF, HDV) hipLaunchKernelGGL((decode_attention_split_kernel<BF, HDV>), grid, block, lds, st, q, r, pos, kc, vc, pw, n_head, n_kv_head, max_seq, nsplit, chunk_max, scale)
+    if (dtype == TEAL_BF16) { if (head_dim == 128) TEAL_ATTS(true, 128); else TEAL_ATTS(true, 64); }
+    else { if (head_dim == 128) TEAL_ATTS(false, 128); else TEAL_ATTS(false, 64); }
+#undef TEAL_ATTS
+    if (hipGetLastError() != hipSuccess) return TEAL_ERR_LAUNCH;
+    auto* yo = reinterpret_cast<uint16_t*>(y);
+    auto* mo = reinterpret_cast<unsigned long long*>(mask_out);
+    if (dtype == TEAL_BF16)
+        hipLaunchKernelGGL((decode_attention_merge_kernel<true>), dim3(n_head), dim3(128), 0, st, pw, yo, mo, mask_tau, head_dim, nsplit);
+    else
+        hipLaunchKernelGGL((decode_attention_merge_kernel<false>), dim3(n_head), dim3(128), 0, st, pw, yo, mo, mask_tau, head_dim, nsplit);
     return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
 }
 

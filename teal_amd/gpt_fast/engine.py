@@ -102,6 +102,9 @@ class DecodeEngine:
         self.rope = model.freqs_cis.contiguous()
         assert self.rope.dtype == dt and self.rope.shape[1:] == (hd // 2, 2)
         self.max_seq = model.max_seq_length
+        # long contexts: split every head's KV range over several workgroups (flash-decoding)
+        self.att_split = 0 if self.max_seq <= 2048 else min(16, max(2, (256 + cfg.n_head - 1) // cfg.n_head, (self.max_seq + 2047) // 2048))
+        self.att_ws = e(cfg.n_head * max(1, self.att_split) * (hd + 2), dtype=torch.float32)
         self.eps = float(cfg.norm_eps)
         self.n_wo = ctypes.c_int(0)
         self.n_down = ctypes.c_int(0)
@@ -171,10 +174,16 @@ class DecodeEngine:
             else:
                 k1_in.nslabs = self.n_down.value
             self._gemv(k1_in, k1_out, self.dim)
-            rc = self.L.teal_decode_attention_masked(self.qkv.data_ptr(), self.rope.data_ptr(), pos_ptr, kc.data_ptr(), vc.data_ptr(),
-                                                     self.y_attn.data_ptr(), self.y_mask.data_ptr() if self.pair else None, tau_o,
-                                                     cfg.n_head, cfg.n_local_heads, cfg.head_dim, self.max_seq, self.code,
-                                                     self._stream)
+            ymask = self.y_mask.data_ptr() if self.pair else None
+            if self.att_split:
+                rc = self.L.teal_decode_attention_split(self.qkv.data_ptr(), self.rope.data_ptr(), pos_ptr, kc.data_ptr(), vc.data_ptr(),
+                                                        self.y_attn.data_ptr(), ymask, tau_o, cfg.n_head, cfg.n_local_heads,
+                                                        cfg.head_dim, self.max_seq, self.att_split, self.att_ws.data_ptr(),
+                                                        self.att_ws.numel() * 4, self.code, self._stream)
+            else:
+                rc = self.L.teal_decode_attention_masked(self.qkv.data_ptr(), self.rope.data_ptr(), pos_ptr, kc.data_ptr(), vc.data_ptr(),
+                                                         self.y_attn.data_ptr(), ymask, tau_o, cfg.n_head, cfg.n_local_heads,
+                                                         cfg.head_dim, self.max_seq, self.code, self._stream)
             if rc != 0:
                 _lib.check(rc, "teal_decode_attention")
             self._gemv(k3_in, k3_out, self.dim, self.n_wo)

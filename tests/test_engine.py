@@ -323,3 +323,68 @@ def test_engine_matches_module_path_full_width(name, dtype, n_layer):
             tok = a.argmax().view(1, 1).to(torch.int)
     del ref, eng_m, eng
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_decode_attention_split_long_context(dtype):
+    """flash-decoding form: same result as the single-workgroup kernel and as torch, at thousands of positions"""
+    from teal_amd import _lib, runtime
+    from teal_amd.gpt_fast.model import apply_rotary_emb, precompute_freqs_cis
+    L = _lib.load()
+    runtime.init()
+    code = runtime.dtype_code(dtype)
+    for n_head, n_kv, hd, pos, S, nsplit in ((8, 2, 128, 5000, 8192, 8), (4, 4, 64, 3, 4096, 16), (8, 8, 128, 4095, 4096, 5)):
+        g = torch.Generator(device=DEV).manual_seed(pos + hd)
+        qkv = (torch.randn((n_head + 2 * n_kv) * hd, device=DEV, generator=g) * 0.5).to(dtype)
+        kc = (torch.randn(n_kv, S, hd, device=DEV, generator=g) * 0.5).to(dtype)
+        vc = (torch.randn(n_kv, S, hd, device=DEV, generator=g) * 0.5).to(dtype)
+        rope = precompute_freqs_cis(S, hd, 10000, dtype).to(DEV).contiguous()
+        p = torch.tensor([pos], device=DEV, dtype=torch.int32)
+        kc1, vc1, kc2, vc2 = kc.clone(), vc.clone(), kc.clone(), vc.clone()
+        y1 = torch.empty(n_head * hd, device=DEV, dtype=dtype)
+        y2 = torch.empty_like(y1)
+        m1 = torch.zeros(n_head * hd // 64, device=DEV, dtype=torch.int64)
+        m2 = torch.zeros_like(m1)
+        ws = torch.zeros(n_head * nsplit * (hd + 2), device=DEV, dtype=torch.float32)
+        assert L.teal_decode_attention_masked(qkv.data_ptr(), rope.data_ptr(), p.data_ptr(), kc1.data_ptr(), vc1.data_ptr(), y1.data_ptr(),
+                                              m1.data_ptr(), 0.02, n_head, n_kv, hd, S, code, runtime.stream_ptr()) == 0
+        assert L.teal_decode_attention_split(qkv.data_ptr(), rope.data_ptr(), p.data_ptr(), kc2.data_ptr(), vc2.data_ptr(), y2.data_ptr(),
+                                             m2.data_ptr(), 0.02, n_head, n_kv, hd, S, nsplit, ws.data_ptr(), ws.numel() * 4, code,
+                                             runtime.stream_ptr()) == 0
+        assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2)
+        tol = 4e-3 if dtype == torch.float16 else 3e-2
+        assert torch.allclose(y1.float(), y2.float(), atol=tol, rtol=tol), float((y1.float() - y2.float()).abs().max())
+        q, k, v = qkv.split([n_head * hd, n_kv * hd, n_kv * hd])
+        qr = apply_rotary_emb(q.view(1, 1, n_head, hd), rope[pos:pos + 1]).view(n_head, hd)
+        rep = n_head // n_kv
+        K = kc2[:, :pos + 1].repeat_interleave(rep, dim=0).float()
+        V = vc2[:, :pos + 1].repeat_interleave(rep, dim=0).float()
+        want = torch.einsum("ht,htd->hd", torch.softmax(torch.einsum("hd,htd->ht", qr.float(), K) / hd ** 0.5, dim=-1), V).reshape(-1)
+        assert torch.allclose(y2.float(), want, atol=tol, rtol=tol)
+        # masks = the keep rule on the rounded output
+        bits = (y2.float().abs() > 0.02).view(-1, 64)
+        got = torch.stack([(m2 >> i) & 1 for i in range(64)], dim=1).bool()
+        assert torch.equal(bits, got)
+
+
+def test_engine_long_context_uses_split_attention():
+    from teal_amd.gpt_fast import generate as G
+    from teal_amd.gpt_fast.engine import DecodeEngine
+    ref = G.build_synthetic_model("tiny-test", DEV, torch.float16, seed=3, std=0.05)
+    eng_m = G.build_synthetic_model("tiny-test", DEV, torch.float16, seed=3, std=0.05)
+    for m in (ref, eng_m):
+        m.config.block_size = 4096
+    ths = G.apply_sparsity(ref, sparsity=0.0, hist_path=None, greedy_lookup=None, synthetic=True)
+    G.apply_sparsity(eng_m, sparsity=0.0, hist_path=None, greedy_lookup=None, synthetic=True)
+    prompt = torch.randint(0, 512, (3000,), device=DEV, dtype=torch.int, generator=torch.Generator(device=DEV).manual_seed(4))
+    with torch.no_grad():
+        for m in (ref, eng_m):
+            m.max_seq_length = -1
+            m.setup_caches(1, 4096)
+            m(prompt.view(1, -1), torch.arange(3000, device=DEV))
+        eng = DecodeEngine(eng_m, ths)
+        assert eng.att_split >= 2
+        tok = torch.tensor([[7]], device=DEV, dtype=torch.int)
+        pos = torch.tensor([3000], device=DEV, dtype=torch.int)
+        a, b = ref(tok, pos).float().view(-1), eng(tok, pos).float().view(-1)
+        assert torch.allclose(a, b, atol=8e-3, rtol=8e-3), float((a - b).abs().max())
