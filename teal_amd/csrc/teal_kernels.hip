@@ -57,6 +57,8 @@ struct InSpec {
     const float* slabs;        // mode 1: [nslabs][Z]
     const void* norm_w;        // mode 1: RMSNorm weight [Z]
     void* resid_out;           // mode 1: updated residual, written by workgroup 0
+    const float* att;          // mode 4: attention partials [n_head][4][head_dim + 2] = {max, sum, o[head_dim]}
+    int att_hd;                // mode 4: head_dim (64 or 128)
     int slabs_il;              // mode 1: slabs are interleaved [Z][(nslabs + 3) & ~3] (one 16-byte load per element)
     const unsigned long long* masks;  // mode 3: keep masks (one per 64 activations) emitted by the producer
     float eps;
@@ -194,6 +196,25 @@ __device__ __forceinline__ float wave_sum_f(float v) {
            __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 31)) +
            __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 47)) +
            __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 63));
+}
+
+// sum over the SL (16 or 8) consecutive lanes that hold the 16-byte slices of one K/V row
+template <int SL>
+__device__ __forceinline__ float row_slices_sum(float v) {
+    if constexpr (SL == 16) {  // one DPP row: rotate-and-add, every lane ends with the total
+        auto ror = [](float a, auto ctrl) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), decltype(ctrl)::value, 0xf, 0xf, false));
+        };
+        v += ror(v, std::integral_constant<int, 0x128>{});  // row_ror:8
+        v += ror(v, std::integral_constant<int, 0x124>{});  // row_ror:4
+        v += ror(v, std::integral_constant<int, 0x122>{});  // row_ror:2
+        v += ror(v, std::integral_constant<int, 0x121>{});  // row_ror:1
+        return v;
+    } else {
+#pragma unroll
+        for (int d = 1; d < SL; d <<= 1) v += __shfl_xor(v, d);
+        return v;
+    }
 }
 
 // optional per-workgroup phase timestamps (constant 100 MHz clock, comparable across CUs)
@@ -355,6 +376,42 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
             const float xn = bits_to_float(float_to_bits<BF16>(rv[k] * rstd), BF16);
             xr[k] = (m < Z) ? (uint32_t)float_to_bits<BF16>(xn * bits_to_float(wb[k], BF16)) : 0u;
             if (rout && blockIdx.x == 0 && m < Z) rout[m] = float_to_bits<BF16>(rv[k]);
+        }
+    } else if constexpr (MODE == 4) {
+        // x = attention output merged from 4 split-KV partials per head (flash-decoding): rescale by the
+        // running maxima, sum, normalise, round once — the merge launch folded into the wo projection
+        const int hd = p.in.att_hd, hs = hd + 2;
+        // a wave's 64 consecutive elements lie in one head (head_dim 64 or 128, Z a multiple of it), so the
+        // per-split {max, sum} are wave-uniform per chunk: lane j fetches them for (chunk j/4, split j%4) in
+        // ONE load, turns them into the normalised weight e^(m - M) / L inside its quad, and the weights are
+        // broadcast with v_readlane — only the o[] values go through the vector memory pipe per element
+        static_assert(KR * 4 <= 64, "one lane per (chunk, split)");
+        const int kk = min(lane >> 2, KR - 1), qq = lane & 3;
+        const int mk = min(((kk / PER) * 64 + wave + (kk % PER) * WAVES) << 6, Z - 1);
+        const float2 st = *reinterpret_cast<const float2*>(p.in.att + ((size_t)(mk / hd) * 4 + qq) * hs);
+        float ov[KR][4];
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const int h = mcl[k] / hd, d = mcl[k] - h * hd;
+            const float* b = p.in.att + (size_t)h * 4 * hs + 2 + d;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ov[k][q] = b[q * hs];
+        }
+#define TEAL_QUAD(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
+        float M = fmaxf(st.x, TEAL_QUAD(st.x, 0xB1));  // quad_perm [1,0,3,2]
+        M = fmaxf(M, TEAL_QUAD(M, 0x4E));              // quad_perm [2,3,0,1]
+        const float f = st.y > 0.0f ? expf(st.x - M) : 0.0f;
+        float Ls = st.y * f;
+        Ls += TEAL_QUAD(Ls, 0xB1);
+        Ls += TEAL_QUAD(Ls, 0x4E);
+#undef TEAL_QUAD
+        const int cw = __float_as_int(f / Ls);
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            float Os = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Os += ov[k][q] * __int_as_float(__builtin_amdgcn_readlane(cw, 4 * k + q));
+            xr[k] = float_to_bits<BF16>(Os);
         }
     } else if constexpr (MODE == 3) {
         // masks come from the producer (attention / gate|up epilogue): no compare, no ballot, and —
@@ -748,9 +805,11 @@ __global__ __launch_bounds__(NT) void decode_attention_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ rope, const int* __restrict__ pos_ptr,
     uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache, uint16_t* __restrict__ y,
     unsigned long long* __restrict__ mask_out, const float mask_tau,
-    const int n_head, const int n_kv, const int max_seq, const float scale) {
+    const int n_head, const int n_kv, const int max_seq, const float scale, unsigned long long* __restrict__ phase) {
     constexpr int NW = NT / 64;
     constexpr int hd = HD;
+    auto stamp_a = [&](const int i) { if (phase && threadIdx.x == 0) phase[(size_t)blockIdx.x * 8 + i] = wall_clock64(); };
+    stamp_a(0);
     constexpr int SL = HD / 8;   // 16-byte slices per row (16 for hd=128, 8 for hd=64)
     constexpr int RW = 64 / SL;  // V rows per wave step (4 or 8)
     constexpr int VPF = 256 / (NW * RW) > 0 ? 256 / (NW * RW) : 1;  // V steps prefetched: the first 256 rows (hd=128)
@@ -775,15 +834,14 @@ __global__ __launch_bounds__(NT) void decode_attention_kernel(
 
     // ---- everything that only depends on `pos` is requested first: this thread's cached K row and
     //      its V slices are in flight while q/k are rotated (one memory round trip instead of three)
-    u32x4 kreg[SL];
-    const bool have_k = tid < pos;
-    {
-        const u32x4* kr = reinterpret_cast<const u32x4*>(kc + (size_t)(have_k ? tid : 0) * hd);
-#pragma unroll
-        for (int v8 = 0; v8 < SL; ++v8) kreg[v8] = kr[v8];
-    }
+    // (lane = (row-in-wave rw, 16-byte slice ds): a wave reads 64/SL whole rows = 1 KiB contiguous per load)
     const int ds = lane % SL, rw = lane / SL;
-    u32x4 vreg[VPF];
+    u32x4 kreg[VPF], vreg[VPF];
+#pragma unroll
+    for (int i = 0; i < VPF; ++i) {
+        const int t = wave * RW + rw + i * NW * RW;
+        kreg[i] = *reinterpret_cast<const u32x4*>(kc + (size_t)(t < pos ? t : 0) * hd + ds * 8);
+    }
 #pragma unroll
     for (int i = 0; i < VPF; ++i) {
         const int t = wave * RW + rw + i * NW * RW;
@@ -813,40 +871,45 @@ __global__ __launch_bounds__(NT) void decode_attention_kernel(
         if (h % rep == 0) vc[(size_t)pos * hd + d] = vb;
     }
     __syncthreads();
+    stamp_a(1);
 
-    // scores: one THREAD per cached position; the new token's own key comes from LDS
+    // scores: each lane multiplies its 8-dim slice, the SL lanes of a row are summed with DPP; the new
+    // token's own key comes from LDS, not from the cache line being written
+    float qv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qv[j] = qs[ds * 8 + j];
     float lmax = -INFINITY;
-    for (int t0 = 0; t0 <= pos; t0 += NT) {
-        const int t = t0 + tid;
-        if (t <= pos) {
-            float a = 0.0f;
-            if (t == pos) {
-                for (int e = 0; e < hd; ++e) a += qs[e] * kn[e];
-            } else {
-                if (t0 > 0) {  // beyond the prefetched batch
-                    const u32x4* kr = reinterpret_cast<const u32x4*>(kc + (size_t)t * hd);
+    auto score_row = [&](const int t, const u32x4 w) {
+        float a = 0.0f;
+        if (t == pos) {
 #pragma unroll
-                    for (int v8 = 0; v8 < SL; ++v8) kreg[v8] = kr[v8];
-                }
+            for (int j = 0; j < 8; ++j) a += qv[j] * kn[ds * 8 + j];
+        } else {
 #pragma unroll
-                for (int v8 = 0; v8 < SL; ++v8) {
-                    const u32x4 w = kreg[v8];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        a += qs[v8 * 8 + 2 * j] * bits_to_float(w[j] & 0xFFFFu, BF16);
-                        a += qs[v8 * 8 + 2 * j + 1] * bits_to_float(w[j] >> 16, BF16);
-                    }
-                }
+            for (int j = 0; j < 4; ++j) {
+                a += qv[2 * j] * bits_to_float(w[j] & 0xFFFFu, BF16);
+                a += qv[2 * j + 1] * bits_to_float(w[j] >> 16, BF16);
             }
-            const float sv = bits_to_float(float_to_bits<BF16>(a * scale), BF16);
-            sc[t] = sv;
+        }
+        a = row_slices_sum<SL>(a);
+        const float sv = bits_to_float(float_to_bits<BF16>(a * scale), BF16);
+        if (t <= pos) {
+            if (ds == 0) sc[t] = sv;
             lmax = fmaxf(lmax, sv);
         }
+    };
+#pragma unroll
+    for (int i = 0; i < VPF; ++i) score_row(wave * RW + rw + i * NW * RW, kreg[i]);
+    for (int tb = VPF * NW * RW; tb <= pos; tb += NW * RW) {  // beyond the prefetched rows (wave-uniform trip count)
+        const int t = tb + wave * RW + rw;
+        const u32x4 w = *reinterpret_cast<const u32x4*>(kc + (size_t)(t < pos ? t : 0) * hd + ds * 8);
+        score_row(t, w);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, d));
     if (lane == 0) red[wave] = lmax;
     __syncthreads();
+    stamp_a(2);
     float mx = red[0];
 #pragma unroll
     for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w]);
@@ -859,6 +922,7 @@ __global__ __launch_bounds__(NT) void decode_attention_kernel(
     lsum = wave_sum_f(lsum);
     if (lane == 0) red[NW + wave] = lsum;
     __syncthreads();
+    stamp_a(3);
     float tot = 0.0f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) tot += red[NW + w];
@@ -900,6 +964,7 @@ __global__ __launch_bounds__(NT) void decode_attention_kernel(
         for (int j = 0; j < 8; ++j) part[wave * hd + lane * 8 + j] = o[j];
     }
     __syncthreads();
+    stamp_a(4);
     if (tid < hd) {  // whole waves (hd = 64 or 128)
         float acc = 0.0f;
 #pragma unroll
@@ -912,6 +977,7 @@ __global__ __launch_bounds__(NT) void decode_attention_kernel(
             if (lane == 0) mask_out[((size_t)h * hd + tid) >> 6] = mk;
         }
     }
+    stamp_a(5);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -975,26 +1041,32 @@ __global__ __launch_bounds__(256) void decode_attention_split_kernel(
         if (h % rep == 0) vc[(size_t)pos * hd + d] = vb;
     }
     __syncthreads();
+    const int ds = lane % SL, rw = lane / SL;
+    float qv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qv[j] = qs[ds * 8 + j];
     float lmax = -INFINITY;
-    for (int t = t0 + tid; t < t1; t += NT) {
+#pragma unroll 4
+    for (int tb = t0; tb < t1; tb += NW * RW) {  // whole rows per wave load (coalesced), DPP row sums
+        const int t = tb + wave * RW + rw;
+        const u32x4 w = *reinterpret_cast<const u32x4*>(kc + (size_t)((t < t1 && t != pos) ? t : t0) * hd + ds * 8);
         float a = 0.0f;
         if (t == pos) {
-            for (int e = 0; e < hd; ++e) a += qs[e] * kn[e];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += qv[j] * kn[ds * 8 + j];
         } else {
-            const u32x4* kr = reinterpret_cast<const u32x4*>(kc + (size_t)t * hd);
 #pragma unroll
-            for (int v8 = 0; v8 < SL; ++v8) {
-                const u32x4 w = kr[v8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    a += qs[v8 * 8 + 2 * j] * bits_to_float(w[j] & 0xFFFFu, BF16);
-                    a += qs[v8 * 8 + 2 * j + 1] * bits_to_float(w[j] >> 16, BF16);
-                }
+            for (int j = 0; j < 4; ++j) {
+                a += qv[2 * j] * bits_to_float(w[j] & 0xFFFFu, BF16);
+                a += qv[2 * j + 1] * bits_to_float(w[j] >> 16, BF16);
             }
         }
+        a = row_slices_sum<SL>(a);
         const float sv = bits_to_float(float_to_bits<BF16>(a * scale), BF16);
-        sc[t - t0] = sv;
-        lmax = fmaxf(lmax, sv);
+        if (t < t1) {
+            if (ds == 0) sc[t - t0] = sv;
+            lmax = fmaxf(lmax, sv);
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, d));
@@ -1015,7 +1087,6 @@ __global__ __launch_bounds__(256) void decode_attention_split_kernel(
     float tot = 0.0f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) tot += red[NW + w];
-    const int ds = lane % SL, rw = lane / SL;
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = 0.0f;
@@ -1363,6 +1434,7 @@ hipError_t launch_gemv_t(const Params& p, int dtype, size_t lds, hipStream_t st)
         if (p.in.mode == 1) return launch_gemv_m<LPR, WAVES, U, 1, false>(p, dtype, lds, st);
         if (p.in.mode == 2) return launch_gemv_m<LPR, WAVES, U, 2, false>(p, dtype, lds, st);
         if (p.in.mode == 3) return launch_gemv_m<LPR, WAVES, U, 3, false>(p, dtype, lds, st);
+        if (p.in.mode == 4) return launch_gemv_m<LPR, WAVES, U, 4, false>(p, dtype, lds, st);
     }
     return hipErrorInvalidValue;
 }
@@ -1417,7 +1489,7 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
     if (p.in.mode != 0 || p.pair) {  // fused variants exist for 16-wave workgroups, unroll 4
         c.waves = 16;
         c.unroll = 4;
-        if (p.in.mode == 1 && p.Z > 16 * 64 * 16) return TEAL_ERR_SHAPE;  // register-resident norm
+        if ((p.in.mode == 1 || p.in.mode == 4) && p.Z > 16 * 64 * 16) return TEAL_ERR_SHAPE;  // register-resident producer
     }
     if (p.pair) {  // both matrices in one workgroup; the activation needs complete sums: no split-K
         c.split = 1;
@@ -1667,6 +1739,12 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
             if (!in->x) return TEAL_ERR_ARG;
             p.x = in->x;
             break;
+        case TEAL_IN_ATTN_MERGE:
+            if (!in->x || (in->att_head_dim != 64 && in->att_head_dim != 128) || Z % in->att_head_dim) return TEAL_ERR_ARG;
+            p.x = in->x;
+            p.in.att = reinterpret_cast<const float*>(in->x);
+            p.in.att_hd = in->att_head_dim;
+            break;
         case TEAL_IN_MASKED:
             if (!in->x || !in->masks) return TEAL_ERR_ARG;
             p.x = in->x;
@@ -1744,7 +1822,7 @@ int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_
     auto* vc = reinterpret_cast<uint16_t*>(v_cache);
     auto* yo = reinterpret_cast<uint16_t*>(y);
     auto* mo = reinterpret_cast<unsigned long long*>(mask_out);
-#define TEAL_ATT(BF, NTV, HDV) hipLaunchKernelGGL((decode_attention_kernel<BF, NTV, HDV>), grid, block, lds, st, q, r, pos, kc, vc, yo, mo, mask_tau, n_head, n_kv_head, max_seq, scale)
+#define TEAL_ATT(BF, NTV, HDV) hipLaunchKernelGGL((decode_attention_kernel<BF, NTV, HDV>), grid, block, lds, st, q, r, pos, kc, vc, yo, mo, mask_tau, n_head, n_kv_head, max_seq, scale, g_phase)
 #define TEAL_ATT_HD(BF, NTV) do { if (head_dim == 128) TEAL_ATT(BF, NTV, 128); else TEAL_ATT(BF, NTV, 64); } while (0)
     if (dtype == TEAL_BF16) { if (nt == 256) TEAL_ATT_HD(true, 256); else TEAL_ATT_HD(true, 1024); }
     else { if (nt == 256) TEAL_ATT_HD(false, 256); else TEAL_ATT_HD(false, 1024); }
@@ -1756,7 +1834,7 @@ int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_
 int teal_decode_attention_split(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,
                                 void* y, void* mask_out, float mask_tau, int n_head, int n_kv_head, int head_dim,
                                 int max_seq, int nsplit, void* partials, size_t partials_bytes, int dtype, void* stream) {
-    if (!qkv || !rope || !pos || !k_cache || !v_cache || !y || !partials) return TEAL_ERR_ARG;
+    if (!qkv || !rope || !pos || !k_cache || !v_cache || !partials) return TEAL_ERR_ARG;
     if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
     if ((head_dim != 64 && head_dim != 128) || n_head <= 0 || n_kv_head <= 0 || n_head % n_kv_head || max_seq <= 0 ||
         nsplit < 1 || nsplit > 64)
@@ -1778,6 +1856,7 @@ int teal_decode_attention_split(const void* qkv, const void* rope, const int32_t
     else { if (head_dim == 128) TEAL_ATTS(false, 128); else TEAL_ATTS(false, 64); }
 #undef TEAL_ATTS
     if (hipGetLastError() != hipSuccess) return TEAL_ERR_LAUNCH;
+    if (!y) return TEAL_OK;  // partials only: the consumer merges (TEAL_IN_ATTN_MERGE)
     auto* yo = reinterpret_cast<uint16_t*>(y);
     auto* mo = reinterpret_cast<unsigned long long*>(mask_out);
     if (dtype == TEAL_BF16)

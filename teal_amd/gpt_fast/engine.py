@@ -28,7 +28,7 @@ from .. import _lib, runtime
 from ..monkeypatch import to_column_major
 from .model import Transformer
 
-TEAL_IN_PLAIN, TEAL_IN_RESID_NORM, TEAL_IN_SILU_MUL, TEAL_IN_MASKED = 0, 1, 2, 3
+TEAL_IN_PLAIN, TEAL_IN_RESID_NORM, TEAL_IN_SILU_MUL, TEAL_IN_MASKED, TEAL_IN_ATTN_MERGE = 0, 1, 2, 3, 4
 TEAL_OUT_ROUNDED, TEAL_OUT_SLABS, TEAL_OUT_PAIR_SILU = 0, 1, 2
 MAX_SLABS = 32
 
@@ -37,7 +37,7 @@ class GemvIn(ctypes.Structure):  # teal_gemv_in_t
     _fields_ = [("mode", ctypes.c_int), ("x", ctypes.c_void_p), ("resid_in", ctypes.c_void_p),
                 ("row_index", ctypes.c_void_p), ("slabs", ctypes.c_void_p), ("nslabs", ctypes.c_int),
                 ("norm_weight", ctypes.c_void_p), ("eps", ctypes.c_float), ("resid_out", ctypes.c_void_p),
-                ("masks", ctypes.c_void_p), ("slabs_interleaved", ctypes.c_int)]
+                ("masks", ctypes.c_void_p), ("att_head_dim", ctypes.c_int), ("slabs_interleaved", ctypes.c_int)]
 
 
 class GemvOut(ctypes.Structure):  # teal_gemv_out_t
@@ -103,7 +103,10 @@ class DecodeEngine:
         assert self.rope.dtype == dt and self.rope.shape[1:] == (hd // 2, 2)
         self.max_seq = model.max_seq_length
         # long contexts: split every head's KV range over several workgroups (flash-decoding)
-        self.att_split = 0 if self.max_seq <= 2048 else min(16, max(2, (256 + cfg.n_head - 1) // cfg.n_head, (self.max_seq + 2047) // 2048))
+        # attention: up to 2048 positions 4 workgroups per head write split-KV partials that the wo launch
+        # merges in its prologue (no extra launch); beyond that more splits + a merge launch
+        self.att_split = 4 if self.max_seq <= 2048 else min(16, max(2, (256 + cfg.n_head - 1) // cfg.n_head, (self.max_seq + 2047) // 2048))
+        self.att_fused_merge = self.att_split == 4 and dim <= 16384
         self.att_ws = e(cfg.n_head * max(1, self.att_split) * (hd + 2), dtype=torch.float32)
         self.eps = float(cfg.norm_eps)
         self.n_wo = ctypes.c_int(0)
@@ -120,6 +123,7 @@ class DecodeEngine:
     # ---- static launch descriptors (pointers never change: hipGraph-capture friendly) -------------
     def _build(self, ths):
         m, dim, inter, kv, nq = self.model, self.dim, self.inter, self.kv, self.nqkv
+        hd_ = self.cfg.head_dim
         A, B = self.resid
         self.stages = []
         for i, layer in enumerate(m.layers):
@@ -131,8 +135,12 @@ class DecodeEngine:
             k1_out = _out([(wq, ldq, 0, dim, th["q"], self.qkv.data_ptr()),
                            (wq, ldq, dim, kv, th["k"], self.qkv.data_ptr() + 2 * dim),
                            (wq, ldq, dim + kv, kv, th["v"], self.qkv.data_ptr() + 2 * (dim + kv))], TEAL_OUT_ROUNDED)
-            k3_in = (GemvIn(mode=TEAL_IN_MASKED, x=self.y_attn.data_ptr(), masks=self.y_mask.data_ptr()) if self.pair
-                     else GemvIn(mode=TEAL_IN_PLAIN, x=self.y_attn.data_ptr()))
+            if self.att_fused_merge:
+                k3_in = GemvIn(mode=TEAL_IN_ATTN_MERGE, x=self.att_ws.data_ptr(), att_head_dim=hd_)
+            elif self.pair:
+                k3_in = GemvIn(mode=TEAL_IN_MASKED, x=self.y_attn.data_ptr(), masks=self.y_mask.data_ptr())
+            else:
+                k3_in = GemvIn(mode=TEAL_IN_PLAIN, x=self.y_attn.data_ptr())
             k3_out = _out([(at.wo.weight.data_ptr(), at.wo.weight.stride(1), 0, dim, th["o"], None)], TEAL_OUT_SLABS, self.s_wo)
             k4_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=B.data_ptr(), slabs=self.s_wo.data_ptr(), nslabs=0, slabs_interleaved=1,
                            norm_weight=layer.ffn_norm.weight.data_ptr(), eps=self.eps, resid_out=A.data_ptr())
@@ -177,7 +185,8 @@ class DecodeEngine:
             ymask = self.y_mask.data_ptr() if self.pair else None
             if self.att_split:
                 rc = self.L.teal_decode_attention_split(self.qkv.data_ptr(), self.rope.data_ptr(), pos_ptr, kc.data_ptr(), vc.data_ptr(),
-                                                        self.y_attn.data_ptr(), ymask, tau_o, cfg.n_head, cfg.n_local_heads,
+                                                        None if self.att_fused_merge else self.y_attn.data_ptr(), ymask, tau_o,
+                                                        cfg.n_head, cfg.n_local_heads,
                                                         cfg.head_dim, self.max_seq, self.att_split, self.att_ws.data_ptr(),
                                                         self.att_ws.numel() * 4, self.code, self._stream)
             else:

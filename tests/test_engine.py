@@ -388,3 +388,56 @@ def test_engine_long_context_uses_split_attention():
         pos = torch.tensor([3000], device=DEV, dtype=torch.int)
         a, b = ref(tok, pos).float().view(-1), eng(tok, pos).float().view(-1)
         assert torch.allclose(a, b, atol=8e-3, rtol=8e-3), float((a - b).abs().max())
+
+
+@pytest.mark.parametrize("dtype,n_head,hd,pos", [(torch.float16, 32, 128, 200), (torch.bfloat16, 8, 64, 5),
+                                                 (torch.float16, 64, 128, 1900), (torch.float16, 16, 64, 0)])
+def test_attn_merge_producer_equals_merge_launch(dtype, n_head, hd, pos):
+    """ATTN_MERGE: the wo launch merges the 4 split-KV partials itself; same projection as merge launch + GEMV."""
+    from teal_amd import _lib, runtime
+    from teal_amd.gpt_fast.engine import GemvIn, _out, TEAL_IN_ATTN_MERGE, TEAL_OUT_ROUNDED
+    from teal_amd.gpt_fast.model import precompute_freqs_cis
+    L = _lib.load()
+    runtime.init()
+    code = runtime.dtype_code(dtype)
+    n_kv, S, nsplit = n_head // 4, 2048, 4
+    Z = n_head * hd
+    N = 512
+    g = torch.Generator(device=DEV).manual_seed(pos + hd)
+    qkv = (torch.randn((n_head + 2 * n_kv) * hd, device=DEV, generator=g) * 0.5).to(dtype)
+    kc = (torch.randn(n_kv, S, hd, device=DEV, generator=g) * 0.5).to(dtype)
+    vc = (torch.randn(n_kv, S, hd, device=DEV, generator=g) * 0.5).to(dtype)
+    rope = precompute_freqs_cis(S, hd, 10000, dtype).to(DEV).contiguous()
+    p = torch.tensor([pos], device=DEV, dtype=torch.int32)
+    W = (torch.randn(N, Z, device=DEV, generator=g) * 0.05).to(dtype).T.contiguous().T
+    y_att = torch.empty(Z, device=DEV, dtype=dtype)
+    msk = torch.zeros(Z // 64, device=DEV, dtype=torch.int64)
+    ws_a = torch.zeros(n_head * nsplit * (hd + 2), device=DEV, dtype=torch.float32)
+    ws_b = torch.zeros_like(ws_a)
+    st = runtime.stream_ptr()
+    assert L.teal_decode_attention_split(qkv.data_ptr(), rope.data_ptr(), p.data_ptr(), kc.clone().data_ptr(), vc.clone().data_ptr(),
+                                         y_att.data_ptr(), msk.data_ptr(), 0.0, n_head, n_kv, hd, S, nsplit, ws_a.data_ptr(),
+                                         ws_a.numel() * 4, code, st) == 0
+    # partials only (y = NULL): no merge launch
+    assert L.teal_decode_attention_split(qkv.data_ptr(), rope.data_ptr(), p.data_ptr(), kc.data_ptr(), vc.data_ptr(), None, None, 0.0,
+                                         n_head, n_kv, hd, S, nsplit, ws_b.data_ptr(), ws_b.numel() * 4, code, st) == 0
+    assert torch.equal(ws_a, ws_b)
+    ws = runtime.reserve_workspace(Z, N)
+    y = torch.zeros(N, device=DEV, dtype=dtype)
+    gin = GemvIn(mode=TEAL_IN_ATTN_MERGE, x=ws_b.data_ptr(), att_head_dim=hd)
+    gout = _out([(W.data_ptr(), N, 0, N, -1.0, y.data_ptr())], TEAL_OUT_ROUNDED)
+    assert L.teal_fused_gemv(ctypes.byref(gin), ctypes.byref(gout), Z, code, ws.data_ptr(), ws.numel() * 4, None, st) == 0
+    want = torch.matmul(y_att.float(), W.float().T).view(-1)
+    tol = 3e-3 if dtype == torch.float16 else 2e-2
+    assert torch.allclose(y.float(), want, atol=tol, rtol=tol), float((y.float() - want).abs().max())
+    # with a threshold: the keep rule acts on the merged, rounded activation (elements within an ulp of the
+    # threshold may differ between the two merge roundings; bound the damage instead of demanding equality)
+    tau = float(y_att.float().abs().median())
+    gout = _out([(W.data_ptr(), N, 0, N, tau, y.data_ptr())], TEAL_OUT_ROUNDED)
+    assert L.teal_fused_gemv(ctypes.byref(gin), ctypes.byref(gout), Z, code, ws.data_ptr(), ws.numel() * 4, None, st) == 0
+    xs = torch.where(y_att.float().abs() > tau, y_att.float(), torch.zeros((), device=DEV))
+    want = torch.matmul(xs, W.float().T).view(-1)
+    assert torch.allclose(y.float(), want, atol=4 * tol, rtol=4 * tol), float((y.float() - want).abs().max())
+    # wrong head_dim is refused
+    bad = GemvIn(mode=TEAL_IN_ATTN_MERGE, x=ws_b.data_ptr(), att_head_dim=96)
+    assert L.teal_fused_gemv(ctypes.byref(bad), ctypes.byref(gout), Z, code, ws.data_ptr(), ws.numel() * 4, None, st) < 0
