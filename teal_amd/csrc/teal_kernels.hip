@@ -1018,6 +1018,20 @@ __global__ __launch_bounds__(256) void decode_attention_split_kernel(
     const uint16_t* vh = qkv + dim + kvs + (size_t)kvh * hd;
     uint16_t* kc = k_cache + (size_t)kvh * max_seq * hd;
     uint16_t* vc = v_cache + (size_t)kvh * max_seq * hd;
+    // lanes = (row rw, 16-byte slice ds): a wave load covers RW whole cache rows (coalesced).  The cached
+    // rows depend only on pos, not on this step's q: the first PF row groups of K AND V are requested
+    // before anything else, so their latency hides behind the q/rope loads, the rope and both barriers.
+    const int ds = lane % SL, rw = lane / SL;
+    constexpr int PF = 4, STEP = NW * RW;
+    const int trow = t0 + wave * RW + rw;
+    u32x4 kreg[PF], vreg[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+        const int t = trow + i * STEP;
+        const size_t off = (size_t)((t < t1 && t != pos) ? t : t0) * hd + ds * 8;
+        kreg[i] = *reinterpret_cast<const u32x4*>(kc + off);
+        vreg[i] = *reinterpret_cast<const u32x4*>(vc + off);
+    }
     if (tid < hd / 2) {
         const float c = bits_to_float(rope[((size_t)pos * (hd / 2) + tid) * 2], BF16);
         const float sn = bits_to_float(rope[((size_t)pos * (hd / 2) + tid) * 2 + 1], BF16);
@@ -1041,15 +1055,11 @@ __global__ __launch_bounds__(256) void decode_attention_split_kernel(
         if (h % rep == 0) vc[(size_t)pos * hd + d] = vb;
     }
     __syncthreads();
-    const int ds = lane % SL, rw = lane / SL;
     float qv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) qv[j] = qs[ds * 8 + j];
     float lmax = -INFINITY;
-#pragma unroll 4
-    for (int tb = t0; tb < t1; tb += NW * RW) {  // whole rows per wave load (coalesced), DPP row sums
-        const int t = tb + wave * RW + rw;
-        const u32x4 w = *reinterpret_cast<const u32x4*>(kc + (size_t)((t < t1 && t != pos) ? t : t0) * hd + ds * 8);
+    auto score_row = [&](const int t, const u32x4 w) {
         float a = 0.0f;
         if (t == pos) {
 #pragma unroll
@@ -1067,6 +1077,14 @@ __global__ __launch_bounds__(256) void decode_attention_split_kernel(
             if (ds == 0) sc[t - t0] = sv;
             lmax = fmaxf(lmax, sv);
         }
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+        if (t0 + i * STEP < t1) score_row(trow + i * STEP, kreg[i]);  // workgroup-uniform guard
+#pragma unroll 4
+    for (int tb = t0 + PF * STEP; tb < t1; tb += STEP) {
+        const int t = tb + wave * RW + rw;
+        score_row(t, *reinterpret_cast<const u32x4*>(kc + (size_t)((t < t1 && t != pos) ? t : t0) * hd + ds * 8));
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, d));
@@ -1090,21 +1108,24 @@ __global__ __launch_bounds__(256) void decode_attention_split_kernel(
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = 0.0f;
-#pragma unroll 4
-    for (int t = t0 + wave * RW + rw; t < t1; t += NW * RW) {
+    auto pv_row = [&](const int t, const u32x4 w) {
         const float pr = sc[t - t0];
         if (t == pos) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += pr * vn[ds * 8 + j];
         } else {
-            const u32x4 w = *reinterpret_cast<const u32x4*>(vc + (size_t)t * hd + ds * 8);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 o[2 * j] += pr * bits_to_float(w[j] & 0xFFFFu, BF16);
                 o[2 * j + 1] += pr * bits_to_float(w[j] >> 16, BF16);
             }
         }
-    }
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+        if (trow + i * STEP < t1) pv_row(trow + i * STEP, vreg[i]);
+#pragma unroll 4
+    for (int t = trow + PF * STEP; t < t1; t += STEP) pv_row(t, *reinterpret_cast<const u32x4*>(vc + (size_t)t * hd + ds * 8));
     for (int off = SL; off < 64; off <<= 1) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] += __shfl_xor(o[j], off);
@@ -1808,9 +1829,8 @@ int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_
     if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
     if ((head_dim != 64 && head_dim != 128) || n_head <= 0 || n_kv_head <= 0 || n_head % n_kv_head || max_seq <= 0)
         return TEAL_ERR_SHAPE;
-    // short contexts: 4 waves per head (cheaper barriers and dispatch, everything prefetched);
-    // long contexts: 16 waves so that one pass covers 1024 positions
-    const int nt = max_seq <= 512 ? 256 : 1024;
+    // 16 waves per head: a wave load covers whole cache rows, one pass covers 1024 positions
+    const int nt = 1024;
     const size_t lds = (size_t)(3 * head_dim + 2 * (nt / 64) + (nt / 64) * head_dim + max_seq) * sizeof(float);
     if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1824,8 +1844,8 @@ int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_
     auto* mo = reinterpret_cast<unsigned long long*>(mask_out);
 #define TEAL_ATT(BF, NTV, HDV) hipLaunchKernelGGL((decode_attention_kernel<BF, NTV, HDV>), grid, block, lds, st, q, r, pos, kc, vc, yo, mo, mask_tau, n_head, n_kv_head, max_seq, scale, g_phase)
 #define TEAL_ATT_HD(BF, NTV) do { if (head_dim == 128) TEAL_ATT(BF, NTV, 128); else TEAL_ATT(BF, NTV, 64); } while (0)
-    if (dtype == TEAL_BF16) { if (nt == 256) TEAL_ATT_HD(true, 256); else TEAL_ATT_HD(true, 1024); }
-    else { if (nt == 256) TEAL_ATT_HD(false, 256); else TEAL_ATT_HD(false, 1024); }
+    if (dtype == TEAL_BF16) TEAL_ATT_HD(true, 1024);
+    else TEAL_ATT_HD(false, 1024);
 #undef TEAL_ATT_HD
 #undef TEAL_ATT
     return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
