@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--model", default="7B", help="architecture (BASELINE configs[1] = Llama-2-7B)")
     ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--sparsity", type=float, default=0.5)
+    ap.add_argument("--prompt_tokens", type=int, default=6, help="prefill length (the headline config uses the reference's 6-token prompt)")
+    ap.add_argument("--att_split", type=int, default=0, help="override the engine's split-KV factor (A/B; 0 = automatic)")
     ap.add_argument("--mode", default="auto", choices=["auto", "engine", "dropin"],
                     help="engine = fused HIP decode step; dropin = reference-shaped torch modules + torch.ops.teal.*")
     ap.add_argument("--n_layer", type=int, default=None)
@@ -379,7 +381,7 @@ def main():
            "config": {"workload": f"Llama-2-{a.model} bs=1 decode, uniform {a.sparsity:.0%} sparsity, hipGraph-captured step"
                       if a.model == "7B" else f"{a.model} bs=1 decode, uniform {a.sparsity:.0%} sparsity",
                       "n_layer": cfg.n_layer, "dim": cfg.dim, "mode": mode, "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
-                      "prompt_tokens": 6}}
+                      "prompt_tokens": a.prompt_tokens}}
     out.update(info.get("report", {}))
     if rank == 0 and world == 1:
         out["roofline"] = roofline_engine_gateup(info["engine"], a) if mode == "engine" else roofline_dominant_kernel(model, a)

@@ -113,9 +113,10 @@ int teal_sparse_gateup_silu(const void* x, const void* w1T, const void* w3T, voi
 #define TEAL_IN_MASKED 3     /* x given together with its keep masks (one uint64 per 64 elements, bit i =
                               * element 64*c+i kept) as emitted by the producing launch: the consumer skips
                               * the compare/ballot phase.  The masks must be those of tau[0]. */
-#define TEAL_IN_ATTN_MERGE 4 /* x = attention output merged from the 4 split-KV partials per head written by
-                              * teal_decode_attention_split(nsplit = 4, no merge launch): x points at the fp32
-                              * partials [Z/head_dim][4][head_dim + 2]; att_head_dim = head_dim */
+#define TEAL_IN_ATTN_MERGE 4 /* x = attention output merged from the split-KV partials per head written by
+                              * teal_decode_attention_split(y = NULL, nsplit = 4 or 8): x points at the fp32
+                              * partials [Z/head_dim][nsplit][head_dim + 2]; att_head_dim = head_dim,
+                              * att_nsplit = nsplit (0 means 4); Z <= 16384 (nsplit 4) / 8192 (nsplit 8) */
 #define TEAL_OUT_ROUNDED 0   /* y rounded to dtype (runs the ordered slab reduce when split-K is used) */
 #define TEAL_OUT_SLABS 1     /* leave the fp32 split-K slabs for the next launch's RESID_NORM producer */
 #define TEAL_OUT_PAIR_SILU 2 /* nseg == 2 (gate, up of equal shape): every workgroup streams the same column tile
@@ -134,6 +135,7 @@ typedef struct teal_gemv_in {
     void* resid_out;          /* RESID_NORM, optional: updated residual [Z]; must not alias resid_in */
     const void* masks;        /* MASKED: uint64 [ceil(Z/64)] keep masks of x */
     int att_head_dim;         /* ATTN_MERGE: head_dim */
+    int att_nsplit;           /* ATTN_MERGE: partials per head, 4 or 8 (0 = 4) */
     int slabs_interleaved;    /* RESID_NORM: slabs are [Z][(nslabs+3)&~3] (as written by a producer with
                                * slabs_interleaved = 1) instead of planar [nslabs][Z]; nslabs <= 8 */
 } teal_gemv_in_t;
@@ -180,8 +182,8 @@ int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_
 int teal_decode_attention_split(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,
                                 void* y, void* mask_out, float mask_tau, int n_head, int n_kv_head, int head_dim,
                                 int max_seq, int nsplit, void* partials, size_t partials_bytes, int dtype, void* stream);
-/* y == NULL: only the partials are written (no merge launch); with nsplit == 4 a TEAL_IN_ATTN_MERGE wo
- * projection merges them in its own prologue — one launch less per layer, and 4 CUs per head pull the KV
+/* y == NULL: only the partials are written (no merge launch); with nsplit 4 or 8 a TEAL_IN_ATTN_MERGE wo
+ * projection merges them in its own prologue (nsplit 4 or 8) — one launch less per layer, and 4 CUs per head pull the KV
  * cache instead of one (a single CU sustains ~50 GB/s, which bounds the one-workgroup-per-head kernel). */
 
 /* Sampling step of the decode loop (gpt-fast/generate.py:49-66): logits / temperature, top-k filter

@@ -57,8 +57,9 @@ struct InSpec {
     const float* slabs;        // mode 1: [nslabs][Z]
     const void* norm_w;        // mode 1: RMSNorm weight [Z]
     void* resid_out;           // mode 1: updated residual, written by workgroup 0
-    const float* att;          // mode 4: attention partials [n_head][4][head_dim + 2] = {max, sum, o[head_dim]}
+    const float* att;          // mode 4: attention partials [n_head][att_ns][head_dim + 2] = {max, sum, o[head_dim]}
     int att_hd;                // mode 4: head_dim (64 or 128)
+    int att_ns;                // mode 4: partials per head (4 or 8)
     int slabs_il;              // mode 1: slabs are interleaved [Z][(nslabs + 3) & ~3] (one 16-byte load per element)
     const unsigned long long* masks;  // mode 3: keep masks (one per 64 activations) emitted by the producer
     float eps;
@@ -382,37 +383,46 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         // running maxima, sum, normalise, round once — the merge launch folded into the wo projection
         const int hd = p.in.att_hd, hs = hd + 2;
         // a wave's 64 consecutive elements lie in one head (head_dim 64 or 128, Z a multiple of it), so the
-        // per-split {max, sum} are wave-uniform per chunk: lane j fetches them for (chunk j/4, split j%4) in
-        // ONE load, turns them into the normalised weight e^(m - M) / L inside its quad, and the weights are
-        // broadcast with v_readlane — only the o[] values go through the vector memory pipe per element
-        static_assert(KR * 4 <= 64, "one lane per (chunk, split)");
-        const int kk = min(lane >> 2, KR - 1), qq = lane & 3;
-        const int mk = min(((kk / PER) * 64 + wave + (kk % PER) * WAVES) << 6, Z - 1);
-        const float2 st = *reinterpret_cast<const float2*>(p.in.att + ((size_t)(mk / hd) * 4 + qq) * hs);
-        float ov[KR][4];
+        // per-split {max, sum} are wave-uniform per chunk: lane j fetches them for (chunk j/NS, split j%NS) in
+        // ONE load, turns them into the normalised weight e^(m - M) / L inside its group of NS lanes (DPP), and
+        // the weights are broadcast with v_readlane — only the o[] values go through the vector memory pipe
+        auto merge = [&](auto ns_tag) {
+            constexpr int NS = decltype(ns_tag)::value;  // 4 or 8 partials per head
+            constexpr int KM = (KR * NS <= 64) ? KR : 64 / NS;  // host refuses Z beyond KM chunks per wave
+            const int kk = min(lane / NS, KM - 1), qq = lane % NS;
+            const int mk = min(((kk / PER) * 64 + wave + (kk % PER) * WAVES) << 6, Z - 1);
+            const float2 st = *reinterpret_cast<const float2*>(p.in.att + ((size_t)(mk / hd) * NS + qq) * hs);
+            float ov[KM][NS];
 #pragma unroll
-        for (int k = 0; k < KR; ++k) {
-            const int h = mcl[k] / hd, d = mcl[k] - h * hd;
-            const float* b = p.in.att + (size_t)h * 4 * hs + 2 + d;
+            for (int k = 0; k < KM; ++k) {
+                const int h = mcl[k] / hd, d = mcl[k] - h * hd;
+                const float* b = p.in.att + (size_t)h * NS * hs + 2 + d;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) ov[k][q] = b[q * hs];
-        }
-#define TEAL_QUAD(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
-        float M = fmaxf(st.x, TEAL_QUAD(st.x, 0xB1));  // quad_perm [1,0,3,2]
-        M = fmaxf(M, TEAL_QUAD(M, 0x4E));              // quad_perm [2,3,0,1]
-        const float f = st.y > 0.0f ? expf(st.x - M) : 0.0f;
-        float Ls = st.y * f;
-        Ls += TEAL_QUAD(Ls, 0xB1);
-        Ls += TEAL_QUAD(Ls, 0x4E);
-#undef TEAL_QUAD
-        const int cw = __float_as_int(f / Ls);
+                for (int q = 0; q < NS; ++q) ov[k][q] = b[q * hs];
+            }
+#define TEAL_DPPF(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
+            float M = fmaxf(st.x, TEAL_DPPF(st.x, 0xB1));  // quad_perm [1,0,3,2]
+            M = fmaxf(M, TEAL_DPPF(M, 0x4E));              // quad_perm [2,3,0,1]
+            if constexpr (NS == 8) M = fmaxf(M, TEAL_DPPF(M, 0x141));  // row_half_mirror: lane i <-> 7 - i
+            const float f = st.y > 0.0f ? expf(st.x - M) : 0.0f;
+            float Ls = st.y * f;
+            Ls += TEAL_DPPF(Ls, 0xB1);
+            Ls += TEAL_DPPF(Ls, 0x4E);
+            if constexpr (NS == 8) Ls += TEAL_DPPF(Ls, 0x141);
+#undef TEAL_DPPF
+            const int cw = __float_as_int(f / Ls);
 #pragma unroll
-        for (int k = 0; k < KR; ++k) {
-            float Os = 0.0f;
+            for (int k = 0; k < KM; ++k) {
+                float Os = 0.0f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) Os += ov[k][q] * __int_as_float(__builtin_amdgcn_readlane(cw, 4 * k + q));
-            xr[k] = float_to_bits<BF16>(Os);
-        }
+                for (int q = 0; q < NS; ++q) Os += ov[k][q] * __int_as_float(__builtin_amdgcn_readlane(cw, NS * k + q));
+                xr[k] = float_to_bits<BF16>(Os);
+            }
+#pragma unroll
+            for (int k = KM; k < KR; ++k) xr[k] = 0u;
+        };
+        if (p.in.att_ns == 8) merge(std::integral_constant<int, 8>{});
+        else merge(std::integral_constant<int, 4>{});
     } else if constexpr (MODE == 3) {
         // masks come from the producer (attention / gate|up epilogue): no compare, no ballot, and —
         // because nothing here depends on another wave — no barrier before the scatter either
@@ -986,12 +996,12 @@ __global__ __launch_bounds__(NT) void decode_attention_kernel(
 // merge kernel rescales and sums them, rounds once and emits the keep masks for the wo projection.
 // With one workgroup per head a 4k context would leave 224 CUs idle while 32 stream 2 MB each.
 // ------------------------------------------------------------------------------------------------
-template <bool BF16, int HD>
-__global__ __launch_bounds__(256) void decode_attention_split_kernel(
+template <bool BF16, int HD, int NT>
+__global__ __launch_bounds__(NT) void decode_attention_split_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ rope, const int* __restrict__ pos_ptr,
     uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache, float* __restrict__ partials,
     const int n_head, const int n_kv, const int max_seq, const int nsplit, const int chunk_max, const float scale) {
-    constexpr int NT = 256, NW = NT / 64, hd = HD, SL = HD / 8, RW = 64 / SL;
+    constexpr int NW = NT / 64, hd = HD, SL = HD / 8, RW = 64 / SL;
     extern __shared__ __align__(16) unsigned char smem[];
     float* qs = reinterpret_cast<float*>(smem);
     float* kn = qs + hd;
@@ -1761,7 +1771,11 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
             p.x = in->x;
             break;
         case TEAL_IN_ATTN_MERGE:
-            if (!in->x || (in->att_head_dim != 64 && in->att_head_dim != 128) || Z % in->att_head_dim) return TEAL_ERR_ARG;
+            if (!in->x || (in->att_head_dim != 64 && in->att_head_dim != 128) || Z % in->att_head_dim ||
+                (in->att_nsplit != 0 && in->att_nsplit != 4 && in->att_nsplit != 8))
+                return TEAL_ERR_ARG;
+            p.in.att_ns = in->att_nsplit ? in->att_nsplit : 4;
+            if (Z > (64 / p.in.att_ns) * 1024) return TEAL_ERR_SHAPE;  // one lane per (chunk, split)
             p.x = in->x;
             p.in.att = reinterpret_cast<const float*>(in->x);
             p.in.att_hd = in->att_head_dim;
@@ -1861,7 +1875,10 @@ int teal_decode_attention_split(const void* qkv, const void* rope, const int32_t
         return TEAL_ERR_SHAPE;
     if (partials_bytes < (size_t)n_head * nsplit * (head_dim + 2) * sizeof(float)) return TEAL_ERR_WORKSPACE;
     const int chunk_max = (max_seq + nsplit - 1) / nsplit;
-    const size_t lds = (size_t)(3 * head_dim + 8 + 4 * head_dim + chunk_max) * sizeof(float);
+    // bandwidth of one workgroup = bytes in flight / latency: long shares get 16 waves (the whole K and V
+    // share of up to 256 rows is requested up front), short ones 4 waves (cheaper barriers)
+    const int nt = chunk_max > 128 ? 1024 : 256;
+    const size_t lds = (size_t)(3 * head_dim + 2 * (nt / 64) + (nt / 64) * head_dim + chunk_max) * sizeof(float);
     if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const float scale = 1.0f / sqrtf((float)head_dim);
@@ -1870,10 +1887,12 @@ int teal_decode_attention_split(const void* qkv, const void* rope, const int32_t
     auto* kc = reinterpret_cast<uint16_t*>(k_cache);
     auto* vc = reinterpret_cast<uint16_t*>(v_cache);
     auto* pw = reinterpret_cast<float*>(partials);
-    const dim3 grid(n_head * nsplit), block(256);
-#define TEAL_ATTS(BF, HDV) hipLaunchKernelGGL((decode_attention_split_kernel<BF, HDV>), grid, block, lds, st, q, r, pos, kc, vc, pw, n_head, n_kv_head, max_seq, nsplit, chunk_max, scale)
-    if (dtype == TEAL_BF16) { if (head_dim == 128) TEAL_ATTS(true, 128); else TEAL_ATTS(true, 64); }
-    else { if (head_dim == 128) TEAL_ATTS(false, 128); else TEAL_ATTS(false, 64); }
+    const dim3 grid(n_head * nsplit), block(nt);
+#define TEAL_ATTS(BF, HDV, NTV) hipLaunchKernelGGL((decode_attention_split_kernel<BF, HDV, NTV>), grid, block, lds, st, q, r, pos, kc, vc, pw, n_head, n_kv_head, max_seq, nsplit, chunk_max, scale)
+#define TEAL_ATTS_NT(BF, HDV) do { if (nt == 1024) TEAL_ATTS(BF, HDV, 1024); else TEAL_ATTS(BF, HDV, 256); } while (0)
+    if (dtype == TEAL_BF16) { if (head_dim == 128) TEAL_ATTS_NT(true, 128); else TEAL_ATTS_NT(true, 64); }
+    else { if (head_dim == 128) TEAL_ATTS_NT(false, 128); else TEAL_ATTS_NT(false, 64); }
+#undef TEAL_ATTS_NT
 #undef TEAL_ATTS
     if (hipGetLastError() != hipSuccess) return TEAL_ERR_LAUNCH;
     if (!y) return TEAL_OK;  // partials only: the consumer merges (TEAL_IN_ATTN_MERGE)

@@ -37,7 +37,8 @@ class GemvIn(ctypes.Structure):  # teal_gemv_in_t
     _fields_ = [("mode", ctypes.c_int), ("x", ctypes.c_void_p), ("resid_in", ctypes.c_void_p),
                 ("row_index", ctypes.c_void_p), ("slabs", ctypes.c_void_p), ("nslabs", ctypes.c_int),
                 ("norm_weight", ctypes.c_void_p), ("eps", ctypes.c_float), ("resid_out", ctypes.c_void_p),
-                ("masks", ctypes.c_void_p), ("att_head_dim", ctypes.c_int), ("slabs_interleaved", ctypes.c_int)]
+                ("masks", ctypes.c_void_p), ("att_head_dim", ctypes.c_int), ("att_nsplit", ctypes.c_int),
+                ("slabs_interleaved", ctypes.c_int)]
 
 
 class GemvOut(ctypes.Structure):  # teal_gemv_out_t
@@ -70,7 +71,8 @@ class DecodeEngine:
     (`setup_caches`) are shared: prefill runs through the module path, decode through the engine.
     """
 
-    def __init__(self, model: Transformer, thresholds: List[Dict[str, float]], pair: Optional[bool] = None):
+    def __init__(self, model: Transformer, thresholds: List[Dict[str, float]], pair: Optional[bool] = None,
+                 att_split: int = 0):
         self.L = _lib.load()
         runtime.init()
         cfg = model.config
@@ -102,11 +104,20 @@ class DecodeEngine:
         self.rope = model.freqs_cis.contiguous()
         assert self.rope.dtype == dt and self.rope.shape[1:] == (hd // 2, 2)
         self.max_seq = model.max_seq_length
-        # long contexts: split every head's KV range over several workgroups (flash-decoding)
-        # attention: up to 2048 positions 4 workgroups per head write split-KV partials that the wo launch
-        # merges in its prologue (no extra launch); beyond that more splits + a merge launch
-        self.att_split = 4 if self.max_seq <= 2048 else min(16, max(2, (256 + cfg.n_head - 1) // cfg.n_head, (self.max_seq + 2047) // 2048))
-        self.att_fused_merge = self.att_split == 4 and dim <= 16384
+        # attention (flash-decoding): 4 or 8 workgroups per head write split-KV partials that the wo launch
+        # merges in its prologue (no extra launch); very long contexts / wide models: up to 16 splits + a
+        # merge launch.  att_split > 0 overrides (benchmark A/B).
+        if att_split:
+            self.att_split = int(att_split)
+        elif self.max_seq <= 1024:
+            self.att_split = 4
+        elif self.max_seq <= 4096 and dim <= 8192:
+            self.att_split = 8
+        elif self.max_seq <= 2048:
+            self.att_split = 4
+        else:
+            self.att_split = min(16, max(2, (256 + cfg.n_head - 1) // cfg.n_head, (self.max_seq + 2047) // 2048))
+        self.att_fused_merge = (self.att_split == 4 and dim <= 16384) or (self.att_split == 8 and dim <= 8192)
         self.att_ws = e(cfg.n_head * max(1, self.att_split) * (hd + 2), dtype=torch.float32)
         self.eps = float(cfg.norm_eps)
         self.n_wo = ctypes.c_int(0)
@@ -136,7 +147,7 @@ class DecodeEngine:
                            (wq, ldq, dim, kv, th["k"], self.qkv.data_ptr() + 2 * dim),
                            (wq, ldq, dim + kv, kv, th["v"], self.qkv.data_ptr() + 2 * (dim + kv))], TEAL_OUT_ROUNDED)
             if self.att_fused_merge:
-                k3_in = GemvIn(mode=TEAL_IN_ATTN_MERGE, x=self.att_ws.data_ptr(), att_head_dim=hd_)
+                k3_in = GemvIn(mode=TEAL_IN_ATTN_MERGE, x=self.att_ws.data_ptr(), att_head_dim=hd_, att_nsplit=self.att_split)
             elif self.pair:
                 k3_in = GemvIn(mode=TEAL_IN_MASKED, x=self.y_attn.data_ptr(), masks=self.y_mask.data_ptr())
             else:
@@ -277,17 +288,18 @@ def make_engine_stepper(model: Transformer, a):
     from . import generate as G
     dev = "cuda"
     ths = G.apply_sparsity(model, sparsity=a.sparsity, hist_path=None, greedy_lookup=None, synthetic=True)
-    prompt = torch.randint(0, model.config.vocab_size, (6,), device=dev, dtype=torch.int,
+    npr = int(getattr(a, "prompt_tokens", 6))
+    prompt = torch.randint(0, model.config.vocab_size, (npr,), device=dev, dtype=torch.int,
                            generator=torch.Generator(device=dev).manual_seed(7))
-    total = 6 + 2 * (a.warmup + a.steps) + 16
+    total = npr + 2 * (a.warmup + a.steps) + 16
     model.max_seq_length = -1
     model.setup_caches(max_batch_size=1, max_seq_length=min(total, model.config.block_size))
     with torch.no_grad():
-        logits = model(prompt.view(1, -1), torch.arange(0, 6, device=dev))  # prefill fills the shared KV caches
+        logits = model(prompt.view(1, -1), torch.arange(0, npr, device=dev))  # prefill fills the shared KV caches
         tok = G.sample(logits, temperature=0.8, top_k=200)[0]
-        eng = DecodeEngine(model, ths)
+        eng = DecodeEngine(model, ths, att_split=int(getattr(a, "att_split", 0)))
         eng.tok_buf.copy_(tok.view(1, 1))
-        eng.pos_buf.fill_(6)
+        eng.pos_buf.fill_(npr)
         graph = eng.capture_loop(0.8, 200)
 
     def step():

@@ -390,9 +390,11 @@ def test_engine_long_context_uses_split_attention():
         assert torch.allclose(a, b, atol=8e-3, rtol=8e-3), float((a - b).abs().max())
 
 
-@pytest.mark.parametrize("dtype,n_head,hd,pos", [(torch.float16, 32, 128, 200), (torch.bfloat16, 8, 64, 5),
-                                                 (torch.float16, 64, 128, 1900), (torch.float16, 16, 64, 0)])
-def test_attn_merge_producer_equals_merge_launch(dtype, n_head, hd, pos):
+@pytest.mark.parametrize("dtype,n_head,hd,pos,nsplit", [(torch.float16, 32, 128, 200, 4), (torch.bfloat16, 8, 64, 5, 4),
+                                                        (torch.float16, 64, 128, 1900, 4), (torch.float16, 16, 64, 0, 4),
+                                                        (torch.float16, 32, 128, 1500, 8), (torch.bfloat16, 64, 128, 3, 8),
+                                                        (torch.float16, 16, 64, 2047, 8)])
+def test_attn_merge_producer_equals_merge_launch(dtype, n_head, hd, pos, nsplit):
     """ATTN_MERGE: the wo launch merges the 4 split-KV partials itself; same projection as merge launch + GEMV."""
     from teal_amd import _lib, runtime
     from teal_amd.gpt_fast.engine import GemvIn, _out, TEAL_IN_ATTN_MERGE, TEAL_OUT_ROUNDED
@@ -400,7 +402,7 @@ def test_attn_merge_producer_equals_merge_launch(dtype, n_head, hd, pos):
     L = _lib.load()
     runtime.init()
     code = runtime.dtype_code(dtype)
-    n_kv, S, nsplit = n_head // 4, 2048, 4
+    n_kv, S = n_head // 4, 2048
     Z = n_head * hd
     N = 512
     g = torch.Generator(device=DEV).manual_seed(pos + hd)
@@ -424,7 +426,7 @@ def test_attn_merge_producer_equals_merge_launch(dtype, n_head, hd, pos):
     assert torch.equal(ws_a, ws_b)
     ws = runtime.reserve_workspace(Z, N)
     y = torch.zeros(N, device=DEV, dtype=dtype)
-    gin = GemvIn(mode=TEAL_IN_ATTN_MERGE, x=ws_b.data_ptr(), att_head_dim=hd)
+    gin = GemvIn(mode=TEAL_IN_ATTN_MERGE, x=ws_b.data_ptr(), att_head_dim=hd, att_nsplit=nsplit)
     gout = _out([(W.data_ptr(), N, 0, N, -1.0, y.data_ptr())], TEAL_OUT_ROUNDED)
     assert L.teal_fused_gemv(ctypes.byref(gin), ctypes.byref(gout), Z, code, ws.data_ptr(), ws.numel() * 4, None, st) == 0
     want = torch.matmul(y_att.float(), W.float().T).view(-1)
@@ -439,5 +441,6 @@ def test_attn_merge_producer_equals_merge_launch(dtype, n_head, hd, pos):
     want = torch.matmul(xs, W.float().T).view(-1)
     assert torch.allclose(y.float(), want, atol=4 * tol, rtol=4 * tol), float((y.float() - want).abs().max())
     # wrong head_dim is refused
-    bad = GemvIn(mode=TEAL_IN_ATTN_MERGE, x=ws_b.data_ptr(), att_head_dim=96)
-    assert L.teal_fused_gemv(ctypes.byref(bad), ctypes.byref(gout), Z, code, ws.data_ptr(), ws.numel() * 4, None, st) < 0
+    for bad in (GemvIn(mode=TEAL_IN_ATTN_MERGE, x=ws_b.data_ptr(), att_head_dim=96, att_nsplit=nsplit),
+                GemvIn(mode=TEAL_IN_ATTN_MERGE, x=ws_b.data_ptr(), att_head_dim=hd, att_nsplit=5)):
+        assert L.teal_fused_gemv(ctypes.byref(bad), ctypes.byref(gout), Z, code, ws.data_ptr(), ws.numel() * 4, None, st) < 0
