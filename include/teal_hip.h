@@ -93,6 +93,14 @@ int teal_sparse_qkv_gemv_ld(const void* x, const void* wT, int ld, void* y, floa
 
 /* y = x @ W^T with every row kept (prefill-free decode of un-sparsified layers, e.g. lm_head).
  * (kernels/sparse_gemv.py:301-307) */
+/* int8 weight-only variant of teal_sparse_qkv_gemv_ld (the reference ships int8 only for its
+ * dense path, gpt-fast/quantize.py:339-357, and lists quantised TEAL as missing, README.md:110).  wqT = int8 image of
+ * W^T, row-major [Z][ld] bytes (ld % 8 == 0, ld >= N); scale[N] in the activation dtype.  N_kv = 0, N_q = N: one
+ * threshold (tau_q). */
+int teal_sparse_qkv_gemv_i8(const void* x, const void* wqT, const void* scale, void* y, float tau_q, float tau_k,
+                            float tau_v, int Z, int N, int N_q, int N_kv, int ld, int dtype, void* ws, size_t ws_bytes,
+                            void* stream);
+
 int teal_dense_gemv(const void* x, const void* wT, void* y, int Z, int N, int dtype, void* ws,
                     size_t ws_bytes, void* stream);
 
@@ -155,6 +163,12 @@ typedef struct teal_gemv_out {
     float mask_tau;      /* PAIR_SILU: threshold of the consumer (the down projection) */
     int slabs_interleaved; /* SLABS: write slabs[col][slice] with row stride (nslabs+3)&~3 so that the consumer
                             * fetches every partial of an element with one 16-byte load */
+    int weight_bits;       /* 0 or 16: fp16/bf16 weights (the activation dtype); 8: int8 weight-only quantisation
+                            * (gpt-fast/quantize.py:339-357): w[i] = int8 image of W^T, row-major [Z][ld] BYTES, and
+                            * scale[i] = per-output-column scales in the activation dtype (element 0 = column col0[i]);
+                            * y = round(fp32(sum q*x) * fp32(scale)) — one rounding, where the reference's
+                            * F.linear(x, w.to(dtype)) * scales rounds twice */
+    const void* scale[3];  /* int8 only */
 } teal_gemv_out_t;
 
 /* One launch: [fused producer] -> mask + compaction -> gathered GEMV over every segment.

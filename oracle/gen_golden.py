@@ -294,6 +294,53 @@ def gen_hist_producer():
     print("  F7 find_histogram:", {k: tuple(v.shape) for k, v in hist.items()})
 
 
+def gen_int8():
+    """F8: the reference's int8 weight-only quantiser and module (gpt-fast/quantize.py:24-56, :339-357), run here:
+    q / scales of a seeded weight (incl. an all-zero row, a row whose extreme is negative, a row of tiny values),
+    and the module's forward on the TEAL-masked activation (x where fp32(|x|) > fp32(tau), else 0) — the
+    composition the int8 sparse GEMV implements.  `tiktoken` (absent here) is only imported by the reference's
+    tokenizer module; an empty stand-in lets quantize.py import."""
+    sys.modules.setdefault("tiktoken", types.ModuleType("tiktoken"))
+    tl = types.ModuleType("tiktoken.load")
+    tl.load_tiktoken_bpe = lambda *a, **k: {}
+    sys.modules.setdefault("tiktoken.load", tl)
+    gf = os.path.join(REF, "gpt-fast")
+    if gf not in sys.path:
+        sys.path.insert(0, gf)
+    import quantize as RQ  # type: ignore
+
+    out = {}
+    for tag, dtype, N, Z in (("f16", O.F16, 96, 256), ("bf16", O.BF16, 64, 192)):
+        tdt = torch.float16 if dtype == O.F16 else torch.bfloat16
+        wb = O.hash_uniform_c(N * Z, 401 + dtype, 0.08, dtype)  # [Z][N] image; the module wants [N, Z]
+        w = t16(wb, dtype).view(Z, N).T.contiguous().clone()
+        w[3] = 0                      # all-zero row -> scale clamps to eps
+        w[5] = -w[5].abs()            # extreme is negative
+        w[7] = w[7] * 1e-3            # tiny values
+        q, scales, _ = RQ.dynamically_quantize_per_channel(w.float(), -128, 127, torch.int8)
+        mod = RQ.WeightOnlyInt8Linear(Z, N)
+        mod.weight.copy_(q)
+        mod.scales = scales.to(tdt)   # WeightOnlyInt8QuantHandler stores scales in the model dtype (quantize.py:330)
+        xb = O.hash_uniform(Z, 402 + dtype, 2.0, dtype)
+        x = t16(xb, dtype).view(1, 1, Z)
+        tau = 0.7
+        keep = x.float().abs() > torch.tensor(tau, dtype=torch.float32)
+        xm = torch.where(keep, x, torch.zeros_like(x))
+        y = mod(xm)
+        yd = mod(x)
+        assert y.dtype == tdt
+        out[f"{tag}_w"] = w.view(torch.int16).numpy().view(np.uint16)
+        out[f"{tag}_q"] = q.numpy()
+        out[f"{tag}_scales_f32"] = scales.numpy()
+        out[f"{tag}_scales"] = scales.to(tdt).view(torch.int16).numpy().view(np.uint16)
+        out[f"{tag}_x"] = xb
+        out[f"{tag}_tau"] = np.float32(tau)
+        out[f"{tag}_y_masked"] = y.view(-1).view(torch.int16).numpy().view(np.uint16)
+        out[f"{tag}_y_dense"] = yd.view(-1).view(torch.int16).numpy().view(np.uint16)
+        print(f"  F8 int8 {tag}: N={N} Z={Z} kept={int(keep.sum())}")
+    np.savez_compressed(os.path.join(OUT, "kat_int8.npz"), **out)
+
+
 def copy_raw_data():
     for sub in ("mlp", "self_attn"):
         for layer in (0, 15):
@@ -325,6 +372,7 @@ def main():
         "gemv": lambda: gen_gemv_kats(inner, a.quick),
         "qkv": lambda: gen_qkv_kats(qkv_inner, a.quick),
         "hist_producer": gen_hist_producer,
+        "int8": gen_int8,
         "raw": copy_raw_data,
     }
     for name, fn in steps.items():

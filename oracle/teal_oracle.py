@@ -203,6 +203,55 @@ def truth64_np(x_bits, wT_bits, Z, N, tau, dtype=F16) -> np.ndarray:
     return (W[keep] * x[keep, None]).sum(axis=0)
 
 
+# ----------------------------------------------------------------------------------------
+# int8 weight-only quantisation (numpy; gpt-fast/quantize.py) — pinned by tests/golden/kat_int8.npz
+# ----------------------------------------------------------------------------------------
+def quantize_per_channel_np(w: np.ndarray):
+    """dynamically_quantize_per_channel(w.float(), -128, 127, int8) (quantize.py:24-56): per-row symmetric scale
+    = max(-min(row, 0), max(row, 0)) / 127.5 clamped to >= eps(fp32); q = clamp(round_half_even(w / scale)).
+    All in float32 like the reference.  Returns (int8 [N, Z], float32 scales [N])."""
+    x = np.asarray(w, dtype=np.float32)
+    eps = np.finfo(np.float32).eps
+    mn = np.minimum(x.min(axis=1), np.float32(0))
+    mx = np.maximum(x.max(axis=1), np.float32(0))
+    amax = np.maximum(-mn, mx).astype(np.float32)
+    scales = np.maximum(amax / np.float32(127.5), np.float32(eps)).astype(np.float32)
+    q = np.clip(np.round((x / scales[:, None]).astype(np.float32)), -128, 127).astype(np.int8)
+    return q, scales
+
+
+def int8_keep(x_bits, taus, dtype=F16):
+    """keep masks of the kernel rule per threshold (kernels/sparse_gemv.py:75)."""
+    x = from_bits(x_bits, dtype)
+    return [np.abs(x) > np.float32(t) for t in taus]
+
+
+def int8_truth64(x_bits, q, scale_bits, tq, tk=None, tv=None, N_q=None, N_kv=0, dtype=F16) -> np.ndarray:
+    """double-precision y[n] = scale[n] * sum_{m kept for n's column range} q[n, m] * x[m]  (q: int8 [N, Z])."""
+    N, Z = q.shape
+    if tk is None:
+        tk, tv, N_q, N_kv = tq, tq, N, 0
+    x = from_bits(x_bits, dtype).astype(np.float64)
+    sc = from_bits(scale_bits, dtype).astype(np.float64)
+    kq, kk, kv = int8_keep(x_bits, (tq, tk, tv), dtype)
+    y = np.empty(N, dtype=np.float64)
+    Q = q.astype(np.float64)
+    for lo, hi, k in ((0, N_q, kq), (N_q, N_q + N_kv, kk), (N_q + N_kv, N, kv)):
+        if hi > lo:
+            y[lo:hi] = (Q[lo:hi][:, k] @ x[k]) * sc[lo:hi]
+    return y
+
+
+def int8_ref_forward(x_bits, q, scale_bits, tau, dtype=F16) -> np.ndarray:
+    """WeightOnlyInt8Linear.forward (quantize.py:354) on the TEAL-masked activation, with the reference's two
+    roundings: y16 = round(F.linear(x_masked, q.to(dtype))), out = round(y16 * scale).  Returns 16-bit patterns."""
+    x = from_bits(x_bits, dtype).astype(np.float64)
+    keep = int8_keep(x_bits, (tau,), dtype)[0]
+    acc = q.astype(np.float64)[:, keep] @ x[keep]
+    y16 = from_bits(to_bits(acc.astype(np.float32), dtype), dtype)
+    return to_bits(y16 * from_bits(scale_bits, dtype), dtype)
+
+
 def fast_sparse_gemv(x_bits, wT_bits, tau, Z, N, dtype=F16) -> np.ndarray:
     """fp32-accumulate / round-once CPU port (OpenMP); the timed CPU baseline."""
     y = np.empty(N, dtype=np.uint16)

@@ -32,6 +32,7 @@
 namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kMaxSeg = 3;
@@ -46,6 +47,7 @@ struct Seg {
     int ncols;   // columns in the segment
     int tile0;   // first tile id of the segment
     int ws_off;  // column offset of the segment inside a workspace slab
+    const void* scale;  // int8 weights: per-output-column scale (activation dtype), element 0 = column col0
 };
 
 // fused activation producers: what the workgroup computes before the mask
@@ -79,6 +81,7 @@ struct Params {
     int swizzle;   // 1: XOR-swizzle tiles inside aligned groups of 8 (XCD decorrelation)
     int wl;        // 1: wave-local compaction (no cross-wave list, no barriers before the stream); cap = per-wave capacity
     int ws_il;     // 1: slabs written interleaved, ws[col * stride + slice], stride = (split + 3) & ~3
+    int w8;        // 1: weights are int8 (per-column scales in seg[].scale), 8 columns = 8 bytes per lane
     int pair;      // 1: seg[0] = gate, seg[1] = up over the SAME column tile; epilogue silu(g)*u -> seg[0].y
     unsigned long long* mask_out;  // pair: keep masks of the output vs mask_tau for the next launch (or null)
     float mask_tau;
@@ -123,6 +126,21 @@ __device__ __forceinline__ void fma8(float (&acc)[8], const u32x4 w, const float
         }
         acc[2 * j] = fmaf(lo, xv, acc[2 * j]);
         acc[2 * j + 1] = fmaf(hi, xv, acc[2 * j + 1]);
+    }
+}
+
+// int8 weights (weight-only quantisation, gpt-fast/quantize.py:339-357): 8 columns = 8 bytes per lane.  The
+// bytes are biased to unsigned (q ^ 0x80 = q + 128) so that each converts with ONE v_cvt_f32_ubyteN; the
+// bias is taken out once per column in the epilogue: sum q*x = sum (q+128)*x - 128 * sum x.
+template <bool BF16>
+__device__ __forceinline__ void fma8(float (&acc)[8], const u32x2 w, const float xv) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t q = w[j] ^ 0x80808080u;
+        acc[4 * j] = fmaf((float)(q & 0xFFu), xv, acc[4 * j]);
+        acc[4 * j + 1] = fmaf((float)((q >> 8) & 0xFFu), xv, acc[4 * j + 1]);
+        acc[4 * j + 2] = fmaf((float)((q >> 16) & 0xFFu), xv, acc[4 * j + 2]);
+        acc[4 * j + 3] = fmaf((float)(q >> 24), xv, acc[4 * j + 3]);
     }
 }
 
@@ -231,10 +249,12 @@ __device__ __forceinline__ int lane_rank(unsigned long long mask) {
 // ------------------------------------------------------------------------------------------------
 // The sparse GEMV.  grid = ntiles * split workgroups of WAVES*64 threads.
 // ------------------------------------------------------------------------------------------------
-template <int LPR, int WAVES, int U, bool BF16, int MODE, int KRT, bool PAIR>
+template <int LPR, int WAVES, int U, bool BF16, int MODE, int KRT, bool PAIR, bool W8 = false>
 __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p) {
     constexpr int RPW = 64 / LPR;  // rows a wave touches per load instruction
-    constexpr int BN = LPR * 8;    // columns per tile (16 B per lane)
+    constexpr int BN = LPR * 8;    // columns per tile (8 per lane: 16 B of fp16/bf16, 8 B of int8)
+    constexpr int WB = W8 ? 1 : 2;  // bytes per weight
+    using wvec = typename std::conditional<W8, u32x2, u32x4>::type;
     constexpr int T = WAVES * 64;
     constexpr int STRIDE = WAVES * RPW;  // list entries consumed per workgroup step
 
@@ -585,12 +605,12 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
     const int col = tcol0 + cl * 8;
     const bool col_ok = col < sg.ncols;  // ragged last tile
     const char* wp = reinterpret_cast<const char*>(sg.w) +
-                     ((size_t)(sg.col0 + (col_ok ? col : 0))) * 2;
-    const size_t ldb = (size_t)sg.ld * 2;
+                     ((size_t)(sg.col0 + (col_ok ? col : 0))) * WB;
+    const size_t ldb = (size_t)sg.ld * WB;
     // PAIR: the up-projection's tile (same columns) streamed with the same list
     const char* wp2 = PAIR ? reinterpret_cast<const char*>(p.seg[1].w) +
-                                 ((size_t)(p.seg[1].col0 + (col_ok ? col : 0))) * 2 : nullptr;
-    const size_t ldb2 = PAIR ? (size_t)p.seg[1].ld * 2 : 0;
+                                 ((size_t)(p.seg[1].col0 + (col_ok ? col : 0))) * WB : nullptr;
+    const size_t ldb2 = PAIR ? (size_t)p.seg[1].ld * WB : 0;
     // PAIR with two different thresholds (block-wise greedy): the list holds the union (smaller tau);
     // a row is dropped from one of the two products by zeroing its weights (exactly a masked load)
     const float tau_g = p.seg[0].tau, tau_u = PAIR ? p.seg[1].tau : 0.0f;
@@ -601,42 +621,64 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
     for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
 #pragma unroll
     for (int j = 0; j < (PAIR ? 8 : 1); ++j) acc2[j] = 0.0f;
+    float xs = 0.0f, xs2 = 0.0f;  // W8: sum of the activations multiplied into acc / acc2 (bias correction)
 
     if (col_ok) {
         const int STEP = U * estride;
         auto full = [&](const int e) { return e + (U - 1) * estride + RPW <= nloc; };
-        // issue the U (x2 for PAIR) 16-byte loads of one batch; nothing here waits
-        auto issue = [&](u32x4 (&w)[U], u32x4 (&w2)[PAIR ? U : 1], float (&xv)[U], const int e0) {
+        // issue the U (x2 for PAIR) 16-byte (int8: 8-byte) loads of one batch; nothing here waits
+        auto issue = [&](wvec (&w)[U], wvec (&w2)[PAIR ? U : 1], float (&xv)[U], const int e0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t ent = lp[e0 + u * estride + g];
                 xv[u] = bits_to_float(ent & 0xFFFFu, BF16);
                 w[u] = __builtin_nontemporal_load(
-                    reinterpret_cast<const u32x4*>(wp + (size_t)(ent >> 16) * ldb));
+                    reinterpret_cast<const wvec*>(wp + (size_t)(ent >> 16) * ldb));
                 if constexpr (PAIR)
                     w2[u] = __builtin_nontemporal_load(
-                        reinterpret_cast<const u32x4*>(wp2 + (size_t)(ent >> 16) * ldb2));
+                        reinterpret_cast<const wvec*>(wp2 + (size_t)(ent >> 16) * ldb2));
             }
         };
-        auto consume = [&](u32x4 (&w)[U], u32x4 (&w2)[PAIR ? U : 1], float (&xv)[U]) {
-            if (two_tau) {
+        auto consume = [&](wvec (&w)[U], wvec (&w2)[PAIR ? U : 1], float (&xv)[U]) {
+            if constexpr (W8) {
+                // int8 weights are always finite: a row dropped from one of the two products is dropped by
+                // zeroing its ACTIVATION for that product (which also keeps it out of the bias sum)
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const float ax = fabsf(xv[u]);
-                    const bool nanx = xv[u] != xv[u];
-                    if (!(ax > tau_g || nanx)) w[u] = (u32x4){0u, 0u, 0u, 0u};
-                    if constexpr (PAIR) if (!(ax > tau_u || nanx)) w2[u] = (u32x4){0u, 0u, 0u, 0u};
+                    float xg = xv[u], xu = xv[u];
+                    if (two_tau) {
+                        const float ax = fabsf(xv[u]);
+                        const bool nanx = xv[u] != xv[u];
+                        if (!(ax > tau_g || nanx)) xg = 0.0f;
+                        if (!(ax > tau_u || nanx)) xu = 0.0f;
+                    }
+                    fma8<BF16>(acc, w[u], xg);
+                    xs += xg;
+                    if constexpr (PAIR) {
+                        fma8<BF16>(acc2, w2[u], xu);
+                        xs2 += xu;
+                    }
                 }
-            }
+            } else {
+                if (two_tau) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                fma8<BF16>(acc, w[u], xv[u]);
-                if constexpr (PAIR) fma8<BF16>(acc2, w2[u], xv[u]);
+                    for (int u = 0; u < U; ++u) {
+                        const float ax = fabsf(xv[u]);
+                        const bool nanx = xv[u] != xv[u];
+                        if (!(ax > tau_g || nanx)) w[u] = wvec(0u);
+                        if constexpr (PAIR) if (!(ax > tau_u || nanx)) w2[u] = wvec(0u);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    fma8<BF16>(acc, w[u], xv[u]);
+                    if constexpr (PAIR) fma8<BF16>(acc2, w2[u], xv[u]);
+                }
             }
         };
         // two batches in flight per wave (software pipeline): the next batch's loads are issued before
         // the current batch is consumed, so a wave never sits with an empty memory queue
-        u32x4 wa[U], wb[U], w2a[PAIR ? U : 1], w2b[PAIR ? U : 1];
+        wvec wa[U], wb[U], w2a[PAIR ? U : 1], w2b[PAIR ? U : 1];
         float xa[U], xb[U];
         bool fa = full(eb);
         if (fa) issue(wa, w2a, xa, eb);
@@ -653,7 +695,8 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
             consume(wb, w2b, xb);
             eb = ebn;
         }
-        // tail: clamp the entry index, zero the contribution of clamped lanes
+        // tail: clamp the entry index, zero the contribution of clamped lanes (fp16/bf16: zero weights;
+        // int8: the zero activation alone does it, and it adds nothing to the bias sum)
         if (eb < nloc) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -661,14 +704,14 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
                 const bool ok = e < nloc;
                 const uint32_t ent = lp[ok ? e : nloc - 1];
                 xa[u] = ok ? bits_to_float(ent & 0xFFFFu, BF16) : 0.0f;
-                u32x4 t = __builtin_nontemporal_load(
-                    reinterpret_cast<const u32x4*>(wp + (size_t)(ent >> 16) * ldb));
-                if (!ok) t = (u32x4){0u, 0u, 0u, 0u};
+                wvec t = __builtin_nontemporal_load(
+                    reinterpret_cast<const wvec*>(wp + (size_t)(ent >> 16) * ldb));
+                if (!W8 && !ok) t = wvec(0u);
                 wa[u] = t;
                 if constexpr (PAIR) {
-                    u32x4 t2 = __builtin_nontemporal_load(
-                        reinterpret_cast<const u32x4*>(wp2 + (size_t)(ent >> 16) * ldb2));
-                    if (!ok) t2 = (u32x4){0u, 0u, 0u, 0u};
+                    wvec t2 = __builtin_nontemporal_load(
+                        reinterpret_cast<const wvec*>(wp2 + (size_t)(ent >> 16) * ldb2));
+                    if (!W8 && !ok) t2 = wvec(0u);
                     w2a[u] = t2;
                 }
             }
@@ -698,7 +741,31 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
             for (int j = 0; j < 8; ++j) r2[j] = acc2[j];
         }
     }
+    float* xsw = red + (PAIR ? 2 : 1) * WAVES * BN;  // W8: [2][WAVES] per-wave activation sums
+    if constexpr (W8) {
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+            xs += __shfl_xor(xs, off);
+            if constexpr (PAIR) xs2 += __shfl_xor(xs2, off);
+        }
+        if (lane == 0) {
+            xsw[wave] = col_ok ? xs : 0.0f;
+            if constexpr (PAIR) xsw[WAVES + wave] = col_ok ? xs2 : 0.0f;
+        }
+    }
     __syncthreads();
+    // W8: sum q*x = sum (q + 128)*x - 128 * sum x, then the per-column scale (quantize.py:354: the product is
+    // scaled AFTER the reduction; here in fp32 before the single rounding)
+    float bias = 0.0f, bias2 = 0.0f;
+    if constexpr (W8) {
+#pragma unroll
+        for (int wv = 0; wv < WAVES; ++wv) {
+            bias += xsw[wv];
+            if constexpr (PAIR) bias2 += xsw[WAVES + wv];
+        }
+        bias *= 128.0f;
+        bias2 *= 128.0f;
+    }
     if constexpr (PAIR) {
         // h = silu(gate) * up with the roundings of the unfused sequence (gpt-fast/model.py:258-259),
         // applied ONCE here instead of in every consumer workgroup; plus the keep masks of h against
@@ -714,6 +781,10 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
                 for (int wv = 0; wv < WAVES; ++wv) {
                     gs += red[wv * BN + tid];
                     us += red[(WAVES + wv) * BN + tid];
+                }
+                if constexpr (W8) {
+                    gs = (gs - bias) * bits_to_float(reinterpret_cast<const uint16_t*>(sg.scale)[c], BF16);
+                    us = (us - bias2) * bits_to_float(reinterpret_cast<const uint16_t*>(p.seg[1].scale)[c], BF16);
                 }
                 const float g16 = bits_to_float(float_to_bits<BF16>(gs), BF16);
                 const float u16 = bits_to_float(float_to_bits<BF16>(us), BF16);
@@ -733,6 +804,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
             float sum = 0.0f;
 #pragma unroll
             for (int wv = 0; wv < WAVES; ++wv) sum += red[wv * BN + t];
+            if constexpr (W8) sum = (sum - bias) * bits_to_float(reinterpret_cast<const uint16_t*>(sg.scale)[c], BF16);
             if (p.split == 1 && !p.to_ws) {
                 reinterpret_cast<uint16_t*>(sg.y)[c] = float_to_bits<BF16>(sum);
             } else if (p.ws_il) {
@@ -1367,7 +1439,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 size_t lds_bytes(int Z, int cap, int waves, int lpr, bool pair = false) {
     const int nch = (Z + 63) >> 6;
-    return (size_t)nch * 8 + 128 + (size_t)cap * 4 + (size_t)waves * lpr * 8 * 4 * (pair ? 2 : 1);
+    return (size_t)nch * 8 + 128 + (size_t)cap * 4 + (size_t)waves * lpr * 8 * 4 * (pair ? 2 : 1) + 128;  // + int8 bias sums
 }
 
 int count_tiles(const Params& p, int bn) {
@@ -1436,6 +1508,17 @@ Config pick_config(int Z, int ncols_total, int nseg_tiles_hint) {
 template <int LPR, int WAVES, int U, int MODE, int KRT, bool PAIR>
 hipError_t launch_gemv_k(const Params& p, int dtype, size_t lds, hipStream_t st) {
     const dim3 grid(p.ntiles * p.split), block(WAVES * 64);
+    if (p.w8) {  // int8 weights: production geometry only (16 waves, unroll 4, tiles up to 256 columns)
+        if constexpr (WAVES == 16 && U == 4 && LPR <= 32) {
+            if (dtype == TEAL_BF16)
+                hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, true, MODE, KRT, PAIR, true>), grid, block, lds, st, p);
+            else
+                hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, false, MODE, KRT, PAIR, true>), grid, block, lds, st, p);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     if (dtype == TEAL_BF16)
         hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, true, MODE, KRT, PAIR>), grid, block, lds, st, p);
     else
@@ -1517,7 +1600,12 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
         c.split = split;
         while ((size_t)((p.Z + c.split - 1) / c.split) * 4 > 40 * 1024 && c.split < kMaxSplit) ++c.split;
     }
-    if (p.in.mode != 0 || p.pair) {  // fused variants exist for 16-wave workgroups, unroll 4
+    if (p.w8) {  // int8: 8 bytes per lane, so a 128-byte row segment needs 16 lanes per row
+        if (c.lpr > 32) c.lpr = 32;
+        for (int i = 0; i < (p.pair ? 2 : p.nseg); ++i)
+            if (!p.seg[i].scale || (p.seg[i].ld & 7) || (p.seg[i].col0 & 7)) return TEAL_ERR_ARG;
+    }
+    if (p.in.mode != 0 || p.pair || p.w8) {  // fused / int8 variants exist for 16-wave workgroups, unroll 4
         c.waves = 16;
         c.unroll = 4;
         if ((p.in.mode == 1 || p.in.mode == 4) && p.Z > 16 * 64 * 16) return TEAL_ERR_SHAPE;  // register-resident producer
@@ -1725,6 +1813,34 @@ int teal_sparse_gemv(const void* x, const void* wT, void* y, float tau, int Z, i
     return teal_sparse_qkv_gemv(x, wT, y, tau, tau, tau, Z, N, N, 0, dtype, ws, ws_bytes, stream);
 }
 
+int teal_sparse_qkv_gemv_i8(const void* x, const void* wqT, const void* scale, void* y, float tau_q, float tau_k,
+                            float tau_v, int Z, int N, int N_q, int N_kv, int ld, int dtype, void* ws, size_t ws_bytes,
+                            void* stream) {
+    if (!scale || N_q <= 0 || N_kv < 0 || N_q + 2 * N_kv != N || ld < N) return TEAL_ERR_ARG;
+    if ((N_q & 7) || (N_kv & 7) || (ld & 7)) return TEAL_ERR_SHAPE;
+    int rc = check_common(x, wqT, y, Z, N, dtype);
+    if (rc != TEAL_OK) return rc;
+    teal_gemv_in_t in = {};
+    in.mode = TEAL_IN_PLAIN;
+    in.x = x;
+    teal_gemv_out_t out = {};
+    out.mode = TEAL_OUT_ROUNDED;
+    out.weight_bits = 8;
+    const float taus[3] = {tau_q, tau_k, tau_v};
+    const int col0[3] = {0, N_q, N_q + N_kv}, ncols[3] = {N_q, N_kv, N_kv};
+    out.nseg = N_kv > 0 ? 3 : 1;
+    for (int i = 0; i < out.nseg; ++i) {
+        out.w[i] = wqT;
+        out.ld[i] = ld;
+        out.col0[i] = col0[i];
+        out.ncols[i] = ncols[i];
+        out.tau[i] = taus[i];
+        out.y[i] = reinterpret_cast<uint16_t*>(y) + col0[i];
+        out.scale[i] = reinterpret_cast<const uint16_t*>(scale) + col0[i];
+    }
+    return teal_fused_gemv(&in, &out, Z, dtype, ws, ws_bytes, nullptr, stream);
+}
+
 int teal_dense_gemv(const void* x, const void* wT, void* y, int Z, int N, int dtype, void* ws,
                     size_t ws_bytes, void* stream) {
     // |x| > -inf keeps every finite and infinite activation; NaN propagates via nan_keeps.
@@ -1812,7 +1928,10 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
         p.seg[i].ld = out->ld[i];
         p.seg[i].col0 = out->col0[i];
         p.seg[i].ncols = out->ncols[i];
+        p.seg[i].scale = out->scale[i];
     }
+    if (out->weight_bits != 0 && out->weight_bits != 16 && out->weight_bits != 8) return TEAL_ERR_ARG;
+    p.w8 = out->weight_bits == 8 ? 1 : 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     Config used = {};
     int rc;

@@ -46,15 +46,20 @@ class GemvOut(ctypes.Structure):  # teal_gemv_out_t
                 ("col0", ctypes.c_int * 3), ("ncols", ctypes.c_int * 3), ("tau", ctypes.c_float * 3),
                 ("y", ctypes.c_void_p * 3), ("mode", ctypes.c_int), ("slabs", ctypes.c_void_p),
                 ("slabs_bytes", ctypes.c_size_t), ("mask_out", ctypes.c_void_p), ("mask_tau", ctypes.c_float),
-                ("slabs_interleaved", ctypes.c_int)]
+                ("slabs_interleaved", ctypes.c_int), ("weight_bits", ctypes.c_int), ("scale", ctypes.c_void_p * 3)]
 
 
 def _out(segs, mode, slabs: Optional[torch.Tensor] = None) -> GemvOut:
-    """segs: list of (weight_ptr, ld, col0, ncols, tau, y_ptr)."""
+    """segs: list of (weight_ptr, ld, col0, ncols, tau, y_ptr[, scale_ptr]); a scale pointer (per-column scales of
+    the segment, element 0 = column col0) marks int8 weights."""
     o = GemvOut()
     o.nseg = len(segs)
-    for i, (w, ld, col0, ncols, tau, y) in enumerate(segs):
+    for i, seg in enumerate(segs):
+        w, ld, col0, ncols, tau, y = seg[:6]
         o.w[i], o.ld[i], o.col0[i], o.ncols[i], o.tau[i], o.y[i] = w, ld, col0, ncols, tau, y
+        if len(seg) > 6 and seg[6]:
+            o.scale[i] = seg[6]
+            o.weight_bits = 8
     o.mode = mode
     if slabs is not None:
         o.slabs = slabs.data_ptr()
@@ -78,7 +83,11 @@ class DecodeEngine:
         cfg = model.config
         self.cfg, self.model = cfg, model
         dev = model.output.weight.device
-        dt = model.output.weight.dtype
+        dt = model.output.scales.dtype if hasattr(model.output, "scales") else model.output.weight.dtype
+        lins = [lin for layer in model.layers for lin in (layer.attention.wqkv, layer.attention.wo, layer.feed_forward.w1,
+                                                         layer.feed_forward.w3, layer.feed_forward.w2)] + [model.output]
+        self.int8 = lins[0].weight.dtype == torch.int8  # int8 weight-only projections (teal_amd/quantize.py)
+        assert all((lin.weight.dtype == torch.int8) == self.int8 for lin in lins), "mixed int8 / 16-bit linears"
         self.dtype, self.code = dt, runtime.dtype_code(dt)
         assert model.freqs_cis is not None, "call model.setup_caches() first"
         dim, inter, hd = cfg.dim, cfg.intermediate_size, cfg.head_dim
@@ -142,37 +151,44 @@ class DecodeEngine:
             k1_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=(m.tok_embeddings.weight.data_ptr() if i == 0 else A.data_ptr()),
                            slabs=(None if i == 0 else self.s_down.data_ptr()), nslabs=0, slabs_interleaved=1,
                            norm_weight=layer.attention_norm.weight.data_ptr(), eps=self.eps, resid_out=B.data_ptr())
+            es = 2  # bytes per activation / scale element
+
+            def sc(lin, col0=0):  # per-column scales of an int8 linear, from column col0 (None: 16-bit weights)
+                return lin.scales.data_ptr() + es * col0 if self.int8 else None
+
             wq, ldq = at.wqkv.weight.data_ptr(), at.wqkv.weight.stride(1)
-            k1_out = _out([(wq, ldq, 0, dim, th["q"], self.qkv.data_ptr()),
-                           (wq, ldq, dim, kv, th["k"], self.qkv.data_ptr() + 2 * dim),
-                           (wq, ldq, dim + kv, kv, th["v"], self.qkv.data_ptr() + 2 * (dim + kv))], TEAL_OUT_ROUNDED)
+            k1_out = _out([(wq, ldq, 0, dim, th["q"], self.qkv.data_ptr(), sc(at.wqkv)),
+                           (wq, ldq, dim, kv, th["k"], self.qkv.data_ptr() + 2 * dim, sc(at.wqkv, dim)),
+                           (wq, ldq, dim + kv, kv, th["v"], self.qkv.data_ptr() + 2 * (dim + kv), sc(at.wqkv, dim + kv))],
+                          TEAL_OUT_ROUNDED)
             if self.att_fused_merge:
                 k3_in = GemvIn(mode=TEAL_IN_ATTN_MERGE, x=self.att_ws.data_ptr(), att_head_dim=hd_, att_nsplit=self.att_split)
             elif self.pair:
                 k3_in = GemvIn(mode=TEAL_IN_MASKED, x=self.y_attn.data_ptr(), masks=self.y_mask.data_ptr())
             else:
                 k3_in = GemvIn(mode=TEAL_IN_PLAIN, x=self.y_attn.data_ptr())
-            k3_out = _out([(at.wo.weight.data_ptr(), at.wo.weight.stride(1), 0, dim, th["o"], None)], TEAL_OUT_SLABS, self.s_wo)
+            k3_out = _out([(at.wo.weight.data_ptr(), at.wo.weight.stride(1), 0, dim, th["o"], None, sc(at.wo))], TEAL_OUT_SLABS, self.s_wo)
             k4_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=B.data_ptr(), slabs=self.s_wo.data_ptr(), nslabs=0, slabs_interleaved=1,
                            norm_weight=layer.ffn_norm.weight.data_ptr(), eps=self.eps, resid_out=A.data_ptr())
-            k4_out = _out([(ff.w1.weight.data_ptr(), ff.w1.weight.stride(1), 0, inter, th["gate"], self.gu.data_ptr()),
-                           (ff.w3.weight.data_ptr(), ff.w3.weight.stride(1), 0, inter, th["up"], self.gu.data_ptr() + 2 * inter)], TEAL_OUT_ROUNDED)
+            k4_out = _out([(ff.w1.weight.data_ptr(), ff.w1.weight.stride(1), 0, inter, th["gate"], self.gu.data_ptr(), sc(ff.w1)),
+                           (ff.w3.weight.data_ptr(), ff.w3.weight.stride(1), 0, inter, th["up"], self.gu.data_ptr() + 2 * inter, sc(ff.w3))],
+                          TEAL_OUT_ROUNDED)
             if self.pair:
-                k4_out = _out([(ff.w1.weight.data_ptr(), ff.w1.weight.stride(1), 0, inter, th["gate"], self.h_mlp.data_ptr()),
-                               (ff.w3.weight.data_ptr(), ff.w3.weight.stride(1), 0, inter, th["up"], None)], TEAL_OUT_PAIR_SILU)
+                k4_out = _out([(ff.w1.weight.data_ptr(), ff.w1.weight.stride(1), 0, inter, th["gate"], self.h_mlp.data_ptr(), sc(ff.w1)),
+                               (ff.w3.weight.data_ptr(), ff.w3.weight.stride(1), 0, inter, th["up"], None, sc(ff.w3))], TEAL_OUT_PAIR_SILU)
                 k4_out.mask_out = self.h_mask.data_ptr()
                 k4_out.mask_tau = th["down"]
                 k5_in = GemvIn(mode=TEAL_IN_MASKED, x=self.h_mlp.data_ptr(), masks=self.h_mask.data_ptr())
             else:
                 k5_in = GemvIn(mode=TEAL_IN_SILU_MUL, x=self.gu.data_ptr())
-            k5_out = _out([(ff.w2.weight.data_ptr(), ff.w2.weight.stride(1), 0, dim, th["down"], None)], TEAL_OUT_SLABS, self.s_down)
+            k5_out = _out([(ff.w2.weight.data_ptr(), ff.w2.weight.stride(1), 0, dim, th["down"], None, sc(ff.w2))], TEAL_OUT_SLABS, self.s_down)
             kc, vc = at.kv_cache.k_cache, at.kv_cache.v_cache
             assert kc.is_contiguous() and kc.shape[0] == 1 and kc.shape[2] == self.max_seq
             self.stages.append((k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out, th["o"]))
         self.head_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=A.data_ptr(), slabs=self.s_down.data_ptr(), nslabs=0, slabs_interleaved=1,
                               norm_weight=m.norm.weight.data_ptr(), eps=self.eps, resid_out=None)
         self.head_out = _out([(m.output.weight.data_ptr(), m.output.weight.stride(1), 0, self.cfg.vocab_size, float("-inf"),
-                               self.logits.data_ptr())], TEAL_OUT_ROUNDED)
+                               self.logits.data_ptr(), m.output.scales.data_ptr() if self.int8 else None)], TEAL_OUT_ROUNDED)
 
     def _gemv(self, gin: GemvIn, gout: GemvOut, Z: int, nslabs_out=None):
         rc = self.L.teal_fused_gemv(ctypes.byref(gin), ctypes.byref(gout), Z, self.code, self.ws.data_ptr(),

@@ -164,6 +164,11 @@ def _sparse_attn_forward(self: Attention, x: Tensor, freqs_cis: Tensor, mask: Te
                          input_pos: Optional[Tensor] = None) -> Tensor:
     """gemv1 = teal::sparse_qkv_gemv, gemv2 = teal::sparse_gemv (prefill handled inside the ops)."""
     kv_size = self.n_local_heads * self.head_dim
+    if getattr(self, "int8", False):  # int8 weight-only projections: the ops take the scales next to the weight
+        qkv = self.gemv1(x, self.wqkv.weight, self.wqkv.scales, self.thresh_q, self.thresh_k, self.thresh_v,
+                         self.sparsity_bin, kv_size)
+        y = self._attend(qkv, freqs_cis, mask, input_pos)
+        return self.gemv2(y, self.wo.weight, self.wo.scales, self.thresh_o, self.sparsity_bin)
     qkv = self.gemv1(x, self.wqkv.weight, self.thresh_q, self.thresh_k, self.thresh_v, self.sparsity_bin, kv_size)
     y = self._attend(qkv, freqs_cis, mask, input_pos)
     return self.gemv2(y, self.wo.weight, self.thresh_o, self.sparsity_bin)
@@ -185,6 +190,10 @@ class FeedForward(nn.Module):
 
 
 def _sparse_ffn_forward(self: FeedForward, x: Tensor) -> Tensor:
+    if getattr(self, "int8", False):
+        gate = self.gemv1(x, self.w1.weight, self.w1.scales, self.thresh_gate, self.sparsity_bin)
+        up = self.gemv1(x, self.w3.weight, self.w3.scales, self.thresh_up, self.sparsity_bin)
+        return self.gemv2(F.silu(gate) * up, self.w2.weight, self.w2.scales, self.thresh_down, self.sparsity_bin)
     gate = self.gemv1(x, self.w1.weight, self.thresh_gate, self.sparsity_bin)
     up = self.gemv1(x, self.w3.weight, self.thresh_up, self.sparsity_bin)
     return self.gemv2(F.silu(gate) * up, self.w2.weight, self.thresh_down, self.sparsity_bin)
@@ -226,6 +235,8 @@ class Transformer(nn.Module):
         max_seq_length = find_multiple(max_seq_length, 8)
         self.max_seq_length, self.max_batch_size = max_seq_length, max_batch_size
         dtype, dev = self.output.weight.dtype, self.output.weight.device
+        if hasattr(self.output, "scales"):  # quantised layers carry the model dtype in their scales (gpt-fast/model.py:122-126)
+            dtype = self.output.scales.dtype
         c = self.config
         for b in self.layers:
             b.attention.kv_cache = KVCache(max_batch_size, max_seq_length, c.n_local_heads, c.head_dim, dtype).to(dev)

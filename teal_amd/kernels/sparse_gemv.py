@@ -21,7 +21,8 @@ from .. import _lib, runtime
 from .compile_wrapper import BaseKernel
 
 __all__ = ["splitk_sparse_gemv", "qkv_gemv", "dense_gemv", "sparse_gateup_silu", "compact",
-           "SparseGEMV", "SparseQKVGEMV", "DenseGEMV"]
+           "SparseGEMV", "SparseQKVGEMV", "DenseGEMV",
+           "qkv_gemv_int8", "splitk_sparse_gemv_int8", "SparseGEMVInt8", "SparseQKVGEMVInt8"]
 
 
 def _prep(x: torch.Tensor, weight: torch.Tensor):
@@ -108,6 +109,41 @@ def sparse_gateup_silu(x: torch.Tensor, w1: torch.Tensor, w3: torch.Tensor, thre
     return h
 
 
+def qkv_gemv_int8(x: torch.Tensor, weight: torch.Tensor, scales: torch.Tensor, threshold_q: float, threshold_k: float,
+                  threshold_v: float, sparsity_bin: int, kv_size: int) -> torch.Tensor:
+    """qkv_gemv on int8 weight-only-quantised weights: weight int8 [N, Z] column-major
+    (strides (1, ld)), scales [N] in x.dtype — the buffers of the reference's WeightOnlyInt8Linear
+    (gpt-fast/quantize.py:339-357), re-laid like the fp16 path.  y = (sparse(x) @ weight.T) * scales with one
+    rounding.  kv_size = 0: a single threshold (threshold_q)."""
+    N, Z = weight.shape
+    assert x.shape[2] == Z
+    assert weight.stride(1) > 1, "weight should be column major"
+    if not x.is_cuda or not weight.is_cuda or not scales.is_cuda:
+        raise RuntimeError("teal_amd sparse GEMV runs on the GPU only (HIP kernels; there is no CPU fallback)")
+    if weight.dtype != torch.int8 or weight.stride(0) != 1 or weight.stride(1) < N or weight.stride(1) % 8:
+        raise RuntimeError("int8 weight must be column-major int8: strides (1, ld) with ld >= N, ld % 8 == 0")
+    if scales.dtype != x.dtype or scales.numel() != N or not scales.is_contiguous():
+        raise TypeError("scales must be a contiguous [N] tensor in x.dtype")
+    B, S, _ = x.shape
+    if B * S != 1:
+        raise RuntimeError("qkv_gemv_int8 is the single-token path: x must be [1, 1, Z]")
+    x = x.contiguous()
+    L = _lib.load()
+    ws = runtime.workspace(x.device, int(L.teal_workspace_bytes(Z, N)))
+    y = torch.empty(B, S, N, device=x.device, dtype=x.dtype)
+    rc = L.teal_sparse_qkv_gemv_i8(x.data_ptr(), weight.data_ptr(), scales.data_ptr(), y.data_ptr(), float(threshold_q),
+                                   float(threshold_k), float(threshold_v), Z, N, N - 2 * kv_size, kv_size, weight.stride(1),
+                                   runtime.dtype_code(x.dtype), ws.data_ptr(), ws.numel() * 4, runtime.stream_ptr())
+    _lib.check(rc, "teal_sparse_qkv_gemv_i8")
+    return y
+
+
+def splitk_sparse_gemv_int8(x: torch.Tensor, weight: torch.Tensor, scales: torch.Tensor, threshold: float,
+                            sparsity_bin: int = 0) -> torch.Tensor:
+    t = float(threshold)
+    return qkv_gemv_int8(x, weight, scales, t, t, t, sparsity_bin, 0)
+
+
 def compact(x: torch.Tensor, threshold: float):
     """(ascending kept indices int32 [count], count) of float32(|x|) > float32(threshold) — the
     index set the GEMV consumes, exposed for bit-exact parity tests."""
@@ -163,3 +199,32 @@ class DenseGEMV(BaseKernel):
         if x.shape[1] == 1 and x.shape[0] == 1:
             return dense_gemv(x, W)
         return torch.matmul(x, W.T)
+
+
+def _int8_prefill(x: torch.Tensor, weight: torch.Tensor, scales: torch.Tensor) -> torch.Tensor:
+    # WeightOnlyInt8Linear.forward (gpt-fast/quantize.py:354)
+    return torch.matmul(x, weight.to(dtype=x.dtype).T) * scales
+
+
+class SparseGEMVInt8(BaseKernel):
+    def meta(self, hidden_states: torch.Tensor, weights: torch.Tensor, scales: torch.Tensor, threshold: float,
+             sparsity_bin: int) -> torch.Tensor:
+        return hidden_states.new_empty((hidden_states.size(0), hidden_states.size(1), weights.size(0)))
+
+    def forward(self, hidden_states: torch.Tensor, weights: torch.Tensor, scales: torch.Tensor, threshold: float,
+                sparsity_bin: int) -> torch.Tensor:
+        if hidden_states.shape[1] == 1 and hidden_states.shape[0] == 1:
+            return splitk_sparse_gemv_int8(hidden_states, weights, scales, threshold, sparsity_bin)
+        return _int8_prefill(hidden_states, weights, scales)
+
+
+class SparseQKVGEMVInt8(BaseKernel):
+    def meta(self, x: torch.Tensor, weight: torch.Tensor, scales: torch.Tensor, threshold_q: float, threshold_k: float,
+             threshold_v: float, sparsity_bin: int, kv_size: int) -> torch.Tensor:
+        return x.new_empty(x.shape[0], x.shape[1], weight.shape[0])
+
+    def forward(self, x: torch.Tensor, weight: torch.Tensor, scales: torch.Tensor, threshold_q: float, threshold_k: float,
+                threshold_v: float, sparsity_bin: int, kv_size: int) -> torch.Tensor:
+        if x.shape[1] == 1 and x.shape[0] == 1:
+            return qkv_gemv_int8(x, weight, scales, threshold_q, threshold_k, threshold_v, sparsity_bin, kv_size)
+        return _int8_prefill(x, weight, scales)

@@ -18,7 +18,7 @@ from typing import Dict, Optional, Sequence
 import torch
 
 from .distribution import Distribution, threshold_for_sparsity
-from .kernels.sparse_gemv import SparseGEMV, SparseQKVGEMV
+from .kernels.sparse_gemv import SparseGEMV, SparseGEMVInt8, SparseQKVGEMV, SparseQKVGEMVInt8
 from .utils import PROJS
 
 # projection -> (sub-directory, histogram key)   (gpt-fast/generate.py:278-287)
@@ -41,7 +41,7 @@ def layer_thresholds(layer_idx: int, hist_path: str, sparsities: Dict[str, Seque
 ROW_PAD = 64  # elements (128 B): see to_column_major
 
 
-def to_column_major(linear: torch.nn.Linear, pad: int = ROW_PAD) -> None:
+def to_column_major(linear: torch.nn.Module, pad: Optional[int] = None) -> None:
     """weight.data = weight.data.T.contiguous().T : shape stays [N, Z], memory becomes W^T [Z][ld]
     (gpt-fast/generate.py:296-317), here with a row stride ld = N + pad.
 
@@ -50,9 +50,12 @@ def to_column_major(linear: torch.nn.Linear, pad: int = ROW_PAD) -> None:
     channel group for every row; on MI355X one such group is ~25 % slower and the workgroups bound to it
     finish last.  ld = N + 64 rotates the residue row by row (measured: qkv 15.8 -> 13.7 us, gate 14.7 ->
     13.0 us per launch, profiles/r01_ld_padding.txt).  The reference's own contract only asks for
-    `weight.stride(1) > 1` (kernels/sparse_gemv.py:106), which a padded view satisfies."""
+    `weight.stride(1) > 1` (kernels/sparse_gemv.py:106), which a padded view satisfies.
+    int8 weights (quantize.WeightOnlyInt8Linear) get 128 pad elements: the same 128 bytes."""
     w = linear.weight.data
     N, Z = w.shape
+    if pad is None:
+        pad = ROW_PAD * 2 // w.element_size()
     ld = N + pad
     if w.stride(0) == 1 and w.stride(1) == ld:
         return
@@ -73,6 +76,12 @@ def monkeypatch_layer(layer_idx: int, layer, sparsity, hist_path: Optional[str],
             sparsities = {p: [sparsity] * n for p in PROJS}
         thresholds = layer_thresholds(layer_idx, hist_path, sparsities)
     ff, attn = layer.feed_forward, layer.attention
+    lins = (ff.w1, ff.w3, ff.w2, attn.wqkv, attn.wo)
+    int8 = [lin.weight.dtype == torch.int8 for lin in lins]
+    if any(int8):
+        if not all(int8):
+            raise ValueError("either all five projections of a block are int8 weight-only or none")
+        return _monkeypatch_layer_int8(layer, thresholds, device)
 
     ff.gemv1_kernel = SparseGEMV.initialize("sparse_gemv", device)
     ff.gemv1 = ff.gemv1_kernel.operator(True)
@@ -102,4 +111,29 @@ def monkeypatch_layer(layer_idx: int, layer, sparsity, hist_path: Optional[str],
     attn.apply_monkeypatch()
     if torch.cuda.is_available() and ff.w1.weight.is_cuda:
         torch.cuda.empty_cache()  # release the pre-relayout copies (generate.py:323); matters for 70B in 288 GB
+    return thresholds
+
+
+def _monkeypatch_layer_int8(layer, thresholds: Dict[str, float], device: str) -> Dict[str, float]:
+    """Same attribute bundle over int8 weight-only projections (quantize.quantize_model_int8): gemv1 / gemv2 are
+    teal::sparse_qkv_gemv_int8 / teal::sparse_gemv_int8, which take the `scales` buffer next to the weight."""
+    ff, attn = layer.feed_forward, layer.attention
+    ff.gemv1_kernel = SparseGEMVInt8.initialize("sparse_gemv_int8", device)
+    ff.gemv1 = ff.gemv1_kernel.operator(True)
+    ff.gemv2_kernel = SparseGEMVInt8.initialize("sparse_gemv_int8", device)
+    ff.gemv2 = ff.gemv2_kernel.operator(True)
+    ff.thresh_up, ff.thresh_gate, ff.thresh_down, ff.sparsity_bin = thresholds["up"], thresholds["gate"], thresholds["down"], 0
+    attn.gemv1_kernel = SparseQKVGEMVInt8.initialize("sparse_qkv_gemv_int8", device)
+    attn.gemv1 = attn.gemv1_kernel.operator(True)
+    attn.gemv2_kernel = SparseGEMVInt8.initialize("sparse_gemv_int8", device)
+    attn.gemv2 = attn.gemv2_kernel.operator(True)
+    attn.thresh_q, attn.thresh_k, attn.thresh_v, attn.thresh_o = (thresholds[k] for k in ("q", "k", "v", "o"))
+    attn.sparsity_bin = 0
+    for lin in (ff.w1, ff.w3, ff.w2, attn.wqkv, attn.wo):
+        to_column_major(lin)
+    ff.int8 = attn.int8 = True
+    ff.apply_monkeypatch()
+    attn.apply_monkeypatch()
+    if torch.cuda.is_available() and ff.w1.weight.is_cuda:
+        torch.cuda.empty_cache()
     return thresholds

@@ -128,3 +128,25 @@ def test_fast_port_within_tolerance_of_truth(oracle):
     Z, N, N_q, N_kv, dtype = (int(k[n]) for n in ("Z", "N", "N_q", "N_kv", "dtype"))
     y = oracle.fast_qkv_gemv(k["x"], k["wT"], float(k["tau_q"]), float(k["tau_k"]), float(k["tau_v"]), Z, N, N_q, N_kv, dtype)
     assert (np.abs(oracle.from_bits(y, dtype) - k["y_truth64"]) <= tolerance(oracle, k["y_truth64"], dtype)).all()
+
+
+@pytest.mark.parametrize("tag,dtype", [("f16", 0), ("bf16", 1)])
+def test_int8_quantiser_and_module_match_reference(oracle, golden_dir, tag, dtype):
+    """F8: the numpy restatement of the reference int8 quantiser is bit-exact (q, fp32 scales, scales in the model
+    dtype), and its forward restatement matches the reference module's output on the masked activation."""
+    k = np.load(os.path.join(golden_dir, "kat_int8.npz"))
+    w = oracle.from_bits(k[f"{tag}_w"], dtype)
+    q, sc = oracle.quantize_per_channel_np(w)
+    assert np.array_equal(q, k[f"{tag}_q"])
+    assert np.array_equal(sc.view(np.uint32), k[f"{tag}_scales_f32"].view(np.uint32))
+    assert np.array_equal(oracle.to_bits(sc, dtype), k[f"{tag}_scales"])
+    assert sc[3] == np.finfo(np.float32).eps and not q[3].any()           # all-zero row: eps scale, zero codes
+    assert q[5].min() == -127 or q[5].min() == -128                        # negative extreme maps to the low end
+    for key, tau in (("y_masked", float(k[f"{tag}_tau"])), ("y_dense", -1.0)):
+        got = oracle.from_bits(oracle.int8_ref_forward(k[f"{tag}_x"], q, k[f"{tag}_scales"], tau, dtype), dtype)
+        want = oracle.from_bits(k[f"{tag}_{key}"], dtype)
+        # the reference sums in fp32 in an unspecified order; the restatement sums in fp64: <= 1 ulp apart
+        assert np.all(np.abs(got - want) <= oracle.ulp16(np.maximum(np.abs(want), 1e-30), dtype)), key
+        assert np.mean(got == want) > 0.9, key
+        truth = oracle.int8_truth64(k[f"{tag}_x"], q, k[f"{tag}_scales"], tau, dtype=dtype)
+        assert np.all(np.abs(want - truth) <= 1e-3 * np.maximum(1, np.abs(truth)) + 2 * oracle.ulp16(truth, dtype))
