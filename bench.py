@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--sparsity", type=float, default=0.5)
     ap.add_argument("--prompt_tokens", type=int, default=6, help="prefill length (the headline config uses the reference's 6-token prompt)")
+    ap.add_argument("--weights", default="16bit", choices=["16bit", "int8"],
+                    help="int8 = weight-only int8 projections + lm_head (teal_amd/quantize.py); NOT the headline config")
+    ap.add_argument("--pair", type=int, default=None, help="engine: 1/0 force the fused gate|up PAIR launch on/off (A/B)")
+    ap.add_argument("--tuning", default="", help="lpr,waves,split,unroll override for every GEMV launch (A/B sweeps)")
     ap.add_argument("--att_split", type=int, default=0, help="override the engine's split-KV factor (A/B; 0 = automatic)")
     ap.add_argument("--mode", default="auto", choices=["auto", "engine", "dropin"],
                     help="engine = fused HIP decode step; dropin = reference-shaped torch modules + torch.ops.teal.*")
@@ -225,7 +229,8 @@ def roofline_engine_gateup(eng, a):
         nnz_g = int((x > k4_out.tau[0]).sum())
         nnz_u = int((x > k4_out.tau[1]).sum())
         out_bytes = (N * 2 + N // 8) if eng.pair else 2 * N * 2  # h (+ keep masks) vs gate|up
-        total_bytes += (nnz_g + nnz_u) * N * 2 + Z * 2 + ns * Z * 4 + Z * 2 + out_bytes
+        wbytes = 1 if eng.int8 else 2  # int8 weight-only: 1 byte per weight + the two scale vectors
+        total_bytes += (nnz_g + nnz_u) * N * wbytes + (2 * N * 2 if eng.int8 else 0) + Z * 2 + ns * Z * 4 + Z * 2 + out_bytes
         gin = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=B.data_ptr(), slabs=eng.s_wo.data_ptr(), nslabs=ns, slabs_interleaved=1,
                      norm_weight=m.layers[i].ffn_norm.weight.data_ptr(), eps=eng.eps, resid_out=None)
         launches.append((gin, k4_out))
@@ -264,7 +269,7 @@ def roofline_engine_gateup(eng, a):
         cfgv[3] = 4
     owned = ((Z + 63) // 64 + 15) // 16
     krt = 4 if owned <= 4 else (8 if owned <= 8 else 16)
-    kname = f"sparse_gemv_kernel<{cfgv[0]},16,{cfgv[3]},{'true' if eng.code else 'false'},1,{krt},{'true' if eng.pair else 'false'}>"
+    kname = f"sparse_gemv_kernel<{cfgv[0]},16,{cfgv[3]},{'true' if eng.code else 'false'},1,{krt},{'true' if eng.pair else 'false'}" + (",true>" if eng.int8 else ">")
     traffic, tsrc = pmc_traffic(kname)
     return {"bound": "hbm", "achieved": total_bytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": total_bytes / t / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
@@ -354,6 +359,10 @@ def main():
     from teal_amd import _lib
     _lib.load().teal_set_swizzle(a.swizzle)
     _lib.load().teal_set_wave_local(a.wave_local)
+    if a.tuning:
+        assert _lib.load().teal_set_tuning(*[int(v) for v in a.tuning.split(",")]) == 0
+    if a.pair is not None:
+        a.pair = bool(a.pair)
     dt = {"fp16": torch.float16, "bf16": torch.bfloat16}[a.precision]
     torch.manual_seed(1234)
     mode = a.mode
@@ -365,6 +374,11 @@ def main():
             mode = "dropin"
 
     model = G.build_synthetic_model(a.model, "cuda", dt, n_layer=a.n_layer)
+    if a.weights == "int8":
+        from teal_amd.quantize import quantize_model_int8
+        quantize_model_int8(model)
+        torch.cuda.empty_cache()
+        assert mode == "engine"
     cfg = model.config
     extra = {}
     if mode == "engine":
@@ -382,6 +396,10 @@ def main():
                       if a.model == "7B" else f"{a.model} bs=1 decode, uniform {a.sparsity:.0%} sparsity",
                       "n_layer": cfg.n_layer, "dim": cfg.dim, "mode": mode, "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
                       "prompt_tokens": a.prompt_tokens}}
+    if a.weights == "int8":
+        out["metric"] = out["metric"].replace("fp16", "int8-weight/fp16-activation")
+        out["dtype"] = out["dtype"] + " activations, int8 weights (per-channel scales)"
+        out["config"]["workload"] += ", int8 weight-only"
     out.update(info.get("report", {}))
     if rank == 0 and world == 1:
         out["roofline"] = roofline_engine_gateup(info["engine"], a) if mode == "engine" else roofline_dominant_kernel(model, a)
@@ -399,7 +417,7 @@ def main():
             dense_tps = max(20, a.steps // 2) / td
             out["dense_tokens_per_sec"] = dense_tps
             out["speedup_vs_dense"] = tps / dense_tps
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and a.weights != "int8":
             out["cpu_baseline"] = cpu_baseline(model, a)
     elif rank == 0:
         out["roofline"] = None

@@ -19,13 +19,16 @@ def main():
     runtime.init()
     L.teal_set_swizzle(int(os.environ.get("TEAL_SWIZZLE", "0")))
     model = G.build_synthetic_model("7B", "cuda", torch.float16, n_layer=6)
+    if os.environ.get("TEAL_WEIGHTS", "") == "int8":
+        from teal_amd.quantize import quantize_model_int8
+        quantize_model_int8(model)
     ths = G.apply_sparsity(model, sparsity=0.5, hist_path=None, greedy_lookup=None, synthetic=True)
     model.max_seq_length = -1
     model.setup_caches(1, 64)
     prompt = torch.randint(0, 32000, (6,), device="cuda", dtype=torch.int)
     with torch.no_grad():
         model(prompt.view(1, -1), torch.arange(6, device="cuda"))
-    eng = DecodeEngine(model, ths)
+    eng = DecodeEngine(model, ths, pair=(None if "TEAL_PAIR" not in os.environ else bool(int(os.environ["TEAL_PAIR"]))))
     tok = torch.tensor([[5]], device="cuda", dtype=torch.int)
     pos = torch.tensor([6], device="cuda", dtype=torch.int)
     for _ in range(3):

@@ -20,12 +20,20 @@ def main():
     dt = torch.float16
     cases = [("wo_7b", 4096, 4096, 0.5, 1), ("gate_7b", 4096, 11008, 0.5, 1), ("gateup_7b", 4096, 11008, 0.5, 2),
              ("down_7b", 11008, 4096, 0.5, 1), ("lmhead", 4096, 32000, 0.0, 1), ("wo_dense", 4096, 4096, 0.0, 1)]
+    int8 = os.environ.get("TEAL_WEIGHTS", "") == "int8"  # int8 weight-only variant of the single-matrix cases
+    if int8:
+        cases = [c for c in cases if c[4] == 1]
     for tag, Z, N, s, nmat in cases:
         g = torch.Generator(device="cuda").manual_seed(0)
         x = (torch.rand(1, 1, Z, device="cuda", generator=g) - 0.5).to(dt)
         tau = s / 2 if s > 0 else -1.0
         nbuf = max(2, int(1.1e9 / (Z * N * 2 * nmat)) + 1)
-        bufs = [[(torch.rand(Z, N, device="cuda", generator=g) - 0.5).to(dt) for _ in range(nmat)] for _ in range(nbuf)]
+        if int8:
+            nbuf = max(2, int(1.1e9 / (Z * N)) + 1)
+            bufs = [[torch.randint(-127, 128, (Z, N), device="cuda", generator=g, dtype=torch.int8)] for _ in range(nbuf)]
+            sc = torch.full((N,), 1e-3, device="cuda", dtype=dt)
+        else:
+            bufs = [[(torch.rand(Z, N, device="cuda", generator=g) - 0.5).to(dt) for _ in range(nmat)] for _ in range(nbuf)]
         ws = runtime.reserve_workspace(Z, N)
         y = torch.empty(N * nmat, device="cuda", dtype=dt)
         cfg = (ctypes.c_int * 5)()
@@ -38,7 +46,10 @@ def main():
             torch.cuda.synchronize()
             L.teal_set_phase_buffer(phase.data_ptr())
             b = bufs[it % nbuf]
-            if nmat == 1:
+            if int8:
+                rc = L.teal_sparse_qkv_gemv_i8(x.data_ptr(), b[0].data_ptr(), sc.data_ptr(), y.data_ptr(), tau, tau, tau, Z, N, N, 0, N, 0,
+                                               ws.data_ptr(), ws.numel() * 4, runtime.stream_ptr())
+            elif nmat == 1:
                 rc = L.teal_sparse_gemv(x.data_ptr(), b[0].data_ptr(), y.data_ptr(), tau, Z, N, 0, ws.data_ptr(), ws.numel() * 4, runtime.stream_ptr())
             else:
                 rc = L.teal_sparse_gateup_silu(x.data_ptr(), b[0].data_ptr(), b[1].data_ptr(), y.data_ptr(), tau, tau, Z, N, 0, ws.data_ptr(),
@@ -56,7 +67,7 @@ def main():
                          float((p[:, 2] - p[:, 6]).mean()) / 1e3])
         import numpy as np
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        np.save(os.path.join(ROOT, "gpurun_out", f"phase_{tag}.npy"), (phase.view(wgs, 8).cpu().numpy() - int(phase.view(wgs, 8)[:, 0].min())))
+        np.save(os.path.join(ROOT, "gpurun_out", f"phase_{tag}.npy"), (phase[: wgs * 8].view(wgs, 8).cpu().numpy() - int(phase[: wgs * 8].view(wgs, 8)[:, 0].min())))
         r = torch.tensor(rows).median(dim=0).values.tolist()
         print(f"[{tag}] cfg={list(cfg)} span(first start -> last end) median {sorted(spans)[len(spans) // 2]:.2f} us")
         print(f"    dispatch skew (last WG start) {r[0]:.2f} us; earliest WG end {r[6]:.2f} us")

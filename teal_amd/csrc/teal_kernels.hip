@@ -129,18 +129,24 @@ __device__ __forceinline__ void fma8(float (&acc)[8], const u32x4 w, const float
     }
 }
 
-// int8 weights (weight-only quantisation, gpt-fast/quantize.py:339-357): 8 columns = 8 bytes per lane.  The
-// bytes are biased to unsigned (q ^ 0x80 = q + 128) so that each converts with ONE v_cvt_f32_ubyteN; the
-// bias is taken out once per column in the epilogue: sum q*x = sum (q+128)*x - 128 * sum x.
+// int8 weights (weight-only quantisation, gpt-fast/quantize.py:339-357): 8 columns = 8 bytes per lane.
+// v_cvt_f32_ubyte is a quarter-rate conversion and made the kernel VALU-bound; instead each byte is turned
+// into an fp16 by v_perm_b32 alone: u = q ^ 0x80 (= q + 128, unsigned) under the exponent byte 0x64 is the
+// half 0x64uu = 1024 + u exactly, and the mixed-precision FMA (v_fma_mix_f32) consumes halves at full rate.
+// The constant 1024 + 128 = 1152 leaves once per column in the epilogue:
+//     sum q*x = sum (1152 + q)*x - 1152 * sum x      (costs ~4 of fp32's 24 bits; outputs carry 8-11)
+constexpr float kInt8Bias = 1152.0f;
 template <bool BF16>
 __device__ __forceinline__ void fma8(float (&acc)[8], const u32x2 w, const float xv) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const uint32_t q = w[j] ^ 0x80808080u;
-        acc[4 * j] = fmaf((float)(q & 0xFFu), xv, acc[4 * j]);
-        acc[4 * j + 1] = fmaf((float)((q >> 8) & 0xFFu), xv, acc[4 * j + 1]);
-        acc[4 * j + 2] = fmaf((float)((q >> 16) & 0xFFu), xv, acc[4 * j + 2]);
-        acc[4 * j + 3] = fmaf((float)(q >> 24), xv, acc[4 * j + 3]);
+        const f16x2 lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(0x64646464u, q, 0x04010400u));  // bytes 0, 1
+        const f16x2 hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(0x64646464u, q, 0x04030402u));  // bytes 2, 3
+        acc[4 * j] = fmaf((float)lo.x, xv, acc[4 * j]);
+        acc[4 * j + 1] = fmaf((float)lo.y, xv, acc[4 * j + 1]);
+        acc[4 * j + 2] = fmaf((float)hi.x, xv, acc[4 * j + 2]);
+        acc[4 * j + 3] = fmaf((float)hi.y, xv, acc[4 * j + 3]);
     }
 }
 
@@ -288,6 +294,15 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
 
     const uint16_t* __restrict__ x = reinterpret_cast<const uint16_t*>(p.x);
     stamp(p, 0);
+    // int8: the per-column scales are needed only in the epilogue, where a dependent global load would add a full
+    // (cold) memory round trip to every launch: thread t fetches the scale of tile column t right now
+    uint32_t scb = 0u, scb2 = 0u;
+    if constexpr (W8) {
+        if (tid < BN && tcol0 + tid < sg.ncols) {
+            scb = reinterpret_cast<const uint16_t*>(sg.scale)[tcol0 + tid];
+            if constexpr (PAIR) scb2 = reinterpret_cast<const uint16_t*>(p.seg[1].scale)[tcol0 + tid];
+        }
+    }
 
     // ---- phase A: one ballot per 64 activations -> masks[]; the activations a wave ballots stay
     //      in its registers for the scatter (chunk c is owned by wave c % WAVES).  KRT (template) is
@@ -754,7 +769,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         }
     }
     __syncthreads();
-    // W8: sum q*x = sum (q + 128)*x - 128 * sum x, then the per-column scale (quantize.py:354: the product is
+    // W8: sum q*x = sum (q + 1152)*x - 1152 * sum x (see fma8), then the per-column scale (quantize.py:354: the product is
     // scaled AFTER the reduction; here in fp32 before the single rounding)
     float bias = 0.0f, bias2 = 0.0f;
     if constexpr (W8) {
@@ -763,8 +778,8 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
             bias += xsw[wv];
             if constexpr (PAIR) bias2 += xsw[WAVES + wv];
         }
-        bias *= 128.0f;
-        bias2 *= 128.0f;
+        bias *= kInt8Bias;
+        bias2 *= kInt8Bias;
     }
     if constexpr (PAIR) {
         // h = silu(gate) * up with the roundings of the unfused sequence (gpt-fast/model.py:258-259),
@@ -783,8 +798,8 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
                     us += red[(WAVES + wv) * BN + tid];
                 }
                 if constexpr (W8) {
-                    gs = (gs - bias) * bits_to_float(reinterpret_cast<const uint16_t*>(sg.scale)[c], BF16);
-                    us = (us - bias2) * bits_to_float(reinterpret_cast<const uint16_t*>(p.seg[1].scale)[c], BF16);
+                    gs = (gs - bias) * bits_to_float(scb, BF16);
+                    us = (us - bias2) * bits_to_float(scb2, BF16);
                 }
                 const float g16 = bits_to_float(float_to_bits<BF16>(gs), BF16);
                 const float u16 = bits_to_float(float_to_bits<BF16>(us), BF16);
@@ -798,13 +813,14 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
             if (p.mask_out && lane == 0) p.mask_out[(tcol0 >> 6) + (tid >> 6)] = mk;
         }
     } else {
+        static_assert(BN <= T, "one epilogue pass: thread t owns tile column t (prefetched int8 scale)");
         for (int t = tid; t < BN; t += T) {
             const int c = tcol0 + t;
             if (c >= sg.ncols) break;
             float sum = 0.0f;
 #pragma unroll
             for (int wv = 0; wv < WAVES; ++wv) sum += red[wv * BN + t];
-            if constexpr (W8) sum = (sum - bias) * bits_to_float(reinterpret_cast<const uint16_t*>(sg.scale)[c], BF16);
+            if constexpr (W8) sum = (sum - bias) * bits_to_float(scb, BF16);  // t == tid: BN <= T, one pass
             if (p.split == 1 && !p.to_ws) {
                 reinterpret_cast<uint16_t*>(sg.y)[c] = float_to_bits<BF16>(sum);
             } else if (p.ws_il) {
@@ -1519,11 +1535,15 @@ hipError_t launch_gemv_k(const Params& p, int dtype, size_t lds, hipStream_t st)
             return hipErrorInvalidValue;
         }
     }
-    if (dtype == TEAL_BF16)
-        hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, true, MODE, KRT, PAIR>), grid, block, lds, st, p);
-    else
-        hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, false, MODE, KRT, PAIR>), grid, block, lds, st, p);
-    return hipGetLastError();
+    if constexpr (U == 4 || (MODE == 0 && !PAIR)) {  // 16-bit fused variants are built for unroll 4 only
+        if (dtype == TEAL_BF16)
+            hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, true, MODE, KRT, PAIR>), grid, block, lds, st, p);
+        else
+            hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, false, MODE, KRT, PAIR>), grid, block, lds, st, p);
+        return hipGetLastError();
+    } else {
+        return hipErrorInvalidValue;
+    }
 }
 
 // register-cache depth: smallest KRT with KRT * WAVES * 64 >= Z (16-wave production geometry);
@@ -1600,12 +1620,31 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
         c.split = split;
         while ((size_t)((p.Z + c.split - 1) / c.split) * 4 > 40 * 1024 && c.split < kMaxSplit) ++c.split;
     }
-    if (p.w8) {  // int8: 8 bytes per lane, so a 128-byte row segment needs 16 lanes per row
+    if (p.w8) {
+        // int8: 8 bytes per lane.  The stream is bound by cache-line REQUESTS per CU (measured: a 64-byte and a
+        // 128-byte row segment cost the same, ~3.2 ns per row and CU), so a row segment should be a whole 128-byte
+        // line = 16 lanes = 128 columns, as long as tiles x slices still cover most of the CUs
         if (c.lpr > 32) c.lpr = 32;
+        if (!g_override.lpr && !g_override.split && !p.pair && c.lpr < 16) {
+            const int ncu = g_num_cu > 0 ? g_num_cu : 256;
+            const int tiles = (total_cols + 127) / 128;
+            const int rounds = (((p.Z + 63) >> 6) + 15) / 16;
+            int split = 1;
+            if (to_ws) {  // slab output: the kept rows may be sliced (wave-local: <= rounds, interleaved slabs: <= 8)
+                split = ncu / tiles;
+                if (split > rounds) split = rounds;
+                if (split > 8) split = 8;
+                if (split < 1) split = 1;
+            }
+            if (tiles * split * 5 >= ncu * 3) {
+                c.lpr = 16;
+                c.split = split;
+            }
+        }
         for (int i = 0; i < (p.pair ? 2 : p.nseg); ++i)
             if (!p.seg[i].scale || (p.seg[i].ld & 7) || (p.seg[i].col0 & 7)) return TEAL_ERR_ARG;
     }
-    if (p.in.mode != 0 || p.pair || p.w8) {  // fused / int8 variants exist for 16-wave workgroups, unroll 4
+    if (p.in.mode != 0 || p.pair || p.w8) {  // fused / int8 variants exist for 16-wave workgroups
         c.waves = 16;
         c.unroll = 4;
         if ((p.in.mode == 1 || p.in.mode == 4) && p.Z > 16 * 64 * 16) return TEAL_ERR_SHAPE;  // register-resident producer

@@ -106,6 +106,8 @@ class DecodeEngine:
         self.h_mask = e((inter + 63) // 64, dtype=torch.int64)                 # keep masks of h_mlp vs tau_down
         # gate|up as one PAIR launch needs whole 64-column chunks and Z small enough for a single list
         can_pair = inter % 64 == 0 and dim % 64 == 0 and (dim + 1) * 4 <= 44 * 1024
+        if pair is None and self.int8:
+            pair = False  # int8 rows are half as long: the PAIR launch's 172 workgroups are request-bound
         self.pair = can_pair if pair is None else (bool(pair) and can_pair)
         self.s_wo, self.s_down = e(MAX_SLABS, dim, dtype=torch.float32), e(MAX_SLABS, dim, dtype=torch.float32)
         self.logits = e(1, 1, cfg.vocab_size)
@@ -313,7 +315,7 @@ def make_engine_stepper(model: Transformer, a):
     with torch.no_grad():
         logits = model(prompt.view(1, -1), torch.arange(0, npr, device=dev))  # prefill fills the shared KV caches
         tok = G.sample(logits, temperature=0.8, top_k=200)[0]
-        eng = DecodeEngine(model, ths, att_split=int(getattr(a, "att_split", 0)))
+        eng = DecodeEngine(model, ths, att_split=int(getattr(a, "att_split", 0)), pair=getattr(a, "pair", None))
         eng.tok_buf.copy_(tok.view(1, 1))
         eng.pos_buf.fill_(npr)
         graph = eng.capture_loop(0.8, 200)
