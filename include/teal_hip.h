@@ -196,6 +196,14 @@ int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_
 int teal_decode_attention_split(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,
                                 void* y, void* mask_out, float mask_tau, int n_head, int n_kv_head, int head_dim,
                                 int max_seq, int nsplit, void* partials, size_t partials_bytes, int dtype, void* stream);
+/* Same, with the qkv projection taken from the fp32 split-K slabs of a TEAL_OUT_SLABS launch (slabs_interleaved = 1,
+ * layout [col][(nslabs + 3) & ~3], nslabs <= 8): the kernel sums each element's partials in slice order and rounds
+ * once — exactly what the ordered reduce launch would have written — so a narrow (GQA) wqkv can be row-sliced over
+ * all CUs without a reduce launch between projection and attention. */
+int teal_decode_attention_split_slabs(const float* qkv_slabs, int qkv_nslabs, const void* rope, const int32_t* pos,
+                                      void* k_cache, void* v_cache, void* y, void* mask_out, float mask_tau, int n_head,
+                                      int n_kv_head, int head_dim, int max_seq, int nsplit, void* partials,
+                                      size_t partials_bytes, int dtype, void* stream);
 /* y == NULL: only the partials are written (no merge launch); with nsplit 4 or 8 a TEAL_IN_ATTN_MERGE wo
  * projection merges them in its own prologue (nsplit 4 or 8) — one launch less per layer, and 4 CUs per head pull the KV
  * cache instead of one (a single CU sustains ~50 GB/s, which bounds the one-workgroup-per-head kernel). */

@@ -1088,7 +1088,8 @@ template <bool BF16, int HD, int NT>
 __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ rope, const int* __restrict__ pos_ptr,
     uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache, float* __restrict__ partials,
-    const int n_head, const int n_kv, const int max_seq, const int nsplit, const int chunk_max, const float scale) {
+    const int n_head, const int n_kv, const int max_seq, const int nsplit, const int chunk_max, const float scale,
+    const float* __restrict__ qkv_slabs, const int qkv_nslabs) {
     constexpr int NW = NT / 64, hd = HD, SL = HD / 8, RW = 64 / SL;
     extern __shared__ __align__(16) unsigned char smem[];
     float* qs = reinterpret_cast<float*>(smem);
@@ -1130,14 +1131,24 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
         kreg[i] = *reinterpret_cast<const u32x4*>(kc + off);
         vreg[i] = *reinterpret_cast<const u32x4*>(vc + off);
     }
+    // element `col` of the qkv projection: the rounded vector, or (qkv_slabs) the fp32 split-K slabs of the
+    // projection launch, interleaved [col][(nslabs + 3) & ~3], summed in slice order and rounded once here —
+    // a narrow (GQA) wqkv can then be row-sliced over all CUs without a reduce launch in between
+    auto qkv_at = [&](const uint16_t* base, const int i) -> uint16_t {
+        if (!qkv_slabs) return base[i];
+        const float* sp = qkv_slabs + (size_t)((base - qkv) + i) * ((qkv_nslabs + 3) & ~3);
+        float a = 0.0f;
+        for (int q = 0; q < qkv_nslabs; ++q) a += sp[q];
+        return float_to_bits<BF16>(a);
+    };
     if (tid < hd / 2) {
         const float c = bits_to_float(rope[((size_t)pos * (hd / 2) + tid) * 2], BF16);
         const float sn = bits_to_float(rope[((size_t)pos * (hd / 2) + tid) * 2 + 1], BF16);
-        const float q0 = bits_to_float(qh[2 * tid], BF16), q1 = bits_to_float(qh[2 * tid + 1], BF16);
+        const float q0 = bits_to_float(qkv_at(qh, 2 * tid), BF16), q1 = bits_to_float(qkv_at(qh, 2 * tid + 1), BF16);
         qs[2 * tid] = bits_to_float(float_to_bits<BF16>(q0 * c - q1 * sn), BF16);
         qs[2 * tid + 1] = bits_to_float(float_to_bits<BF16>(q1 * c + q0 * sn), BF16);
         if (has_new) {
-            const float k0 = bits_to_float(kh[2 * tid], BF16), k1 = bits_to_float(kh[2 * tid + 1], BF16);
+            const float k0 = bits_to_float(qkv_at(kh, 2 * tid), BF16), k1 = bits_to_float(qkv_at(kh, 2 * tid + 1), BF16);
             const uint16_t ka = float_to_bits<BF16>(k0 * c - k1 * sn), kb = float_to_bits<BF16>(k1 * c + k0 * sn);
             kn[2 * tid] = bits_to_float(ka, BF16);
             kn[2 * tid + 1] = bits_to_float(kb, BF16);
@@ -1148,7 +1159,7 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
         }
     } else if (has_new && tid >= 128 && tid < 128 + hd) {
         const int d = tid - 128;
-        const uint16_t vb = vh[d];
+        const uint16_t vb = qkv_at(vh, d);
         vn[d] = bits_to_float(vb, BF16);
         if (h % rep == 0) vc[(size_t)pos * hd + d] = vb;
     }
@@ -2023,10 +2034,12 @@ int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_
     return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
 }
 
-int teal_decode_attention_split(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,
-                                void* y, void* mask_out, float mask_tau, int n_head, int n_kv_head, int head_dim,
-                                int max_seq, int nsplit, void* partials, size_t partials_bytes, int dtype, void* stream) {
-    if (!qkv || !rope || !pos || !k_cache || !v_cache || !partials) return TEAL_ERR_ARG;
+static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv_nslabs, const void* rope, const int32_t* pos,
+                                void* k_cache, void* v_cache, void* y, void* mask_out, float mask_tau, int n_head,
+                                int n_kv_head, int head_dim, int max_seq, int nsplit, void* partials, size_t partials_bytes,
+                                int dtype, void* stream) {
+    if ((!qkv && !qkv_slabs) || !rope || !pos || !k_cache || !v_cache || !partials) return TEAL_ERR_ARG;
+    if (qkv_slabs && (qkv_nslabs < 1 || qkv_nslabs > 8 || !aligned16(qkv_slabs))) return TEAL_ERR_ARG;
     if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
     if ((head_dim != 64 && head_dim != 128) || n_head <= 0 || n_kv_head <= 0 || n_head % n_kv_head || max_seq <= 0 ||
         nsplit < 1 || nsplit > 64)
@@ -2046,7 +2059,7 @@ int teal_decode_attention_split(const void* qkv, const void* rope, const int32_t
     auto* vc = reinterpret_cast<uint16_t*>(v_cache);
     auto* pw = reinterpret_cast<float*>(partials);
     const dim3 grid(n_head * nsplit), block(nt);
-#define TEAL_ATTS(BF, HDV, NTV) hipLaunchKernelGGL((decode_attention_split_kernel<BF, HDV, NTV>), grid, block, lds, st, q, r, pos, kc, vc, pw, n_head, n_kv_head, max_seq, nsplit, chunk_max, scale)
+#define TEAL_ATTS(BF, HDV, NTV) hipLaunchKernelGGL((decode_attention_split_kernel<BF, HDV, NTV>), grid, block, lds, st, q, r, pos, kc, vc, pw, n_head, n_kv_head, max_seq, nsplit, chunk_max, scale, qkv_slabs, qkv_nslabs)
 #define TEAL_ATTS_NT(BF, HDV) do { if (nt == 1024) TEAL_ATTS(BF, HDV, 1024); else TEAL_ATTS(BF, HDV, 256); } while (0)
     if (dtype == TEAL_BF16) { if (head_dim == 128) TEAL_ATTS_NT(true, 128); else TEAL_ATTS_NT(true, 64); }
     else { if (head_dim == 128) TEAL_ATTS_NT(false, 128); else TEAL_ATTS_NT(false, 64); }
@@ -2061,6 +2074,23 @@ int teal_decode_attention_split(const void* qkv, const void* rope, const int32_t
     else
         hipLaunchKernelGGL((decode_attention_merge_kernel<false>), dim3(n_head), dim3(128), 0, st, pw, yo, mo, mask_tau, head_dim, nsplit);
     return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
+}
+
+int teal_decode_attention_split(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,
+                                void* y, void* mask_out, float mask_tau, int n_head, int n_kv_head, int head_dim,
+                                int max_seq, int nsplit, void* partials, size_t partials_bytes, int dtype, void* stream) {
+    if (!qkv) return TEAL_ERR_ARG;
+    return attention_split_impl(qkv, nullptr, 0, rope, pos, k_cache, v_cache, y, mask_out, mask_tau, n_head, n_kv_head,
+                                head_dim, max_seq, nsplit, partials, partials_bytes, dtype, stream);
+}
+
+int teal_decode_attention_split_slabs(const float* qkv_slabs, int qkv_nslabs, const void* rope, const int32_t* pos,
+                                      void* k_cache, void* v_cache, void* y, void* mask_out, float mask_tau, int n_head,
+                                      int n_kv_head, int head_dim, int max_seq, int nsplit, void* partials,
+                                      size_t partials_bytes, int dtype, void* stream) {
+    if (!qkv_slabs) return TEAL_ERR_ARG;
+    return attention_split_impl(nullptr, qkv_slabs, qkv_nslabs, rope, pos, k_cache, v_cache, y, mask_out, mask_tau, n_head,
+                                n_kv_head, head_dim, max_seq, nsplit, partials, partials_bytes, dtype, stream);
 }
 
 int teal_decode_attention(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,

@@ -110,6 +110,7 @@ class DecodeEngine:
             pair = False  # int8 rows are half as long: the PAIR launch's 172 workgroups are request-bound
         self.pair = can_pair if pair is None else (bool(pair) and can_pair)
         self.s_wo, self.s_down = e(MAX_SLABS, dim, dtype=torch.float32), e(MAX_SLABS, dim, dtype=torch.float32)
+        self.s_qkv = e(8, self.nqkv, dtype=torch.float32)  # wqkv split-K slabs, summed by the attention launch
         self.logits = e(1, 1, cfg.vocab_size)
         self.ws = runtime.reserve_workspace(max(dim, inter), max(self.nqkv, inter, cfg.vocab_size))
         self.rope = model.freqs_cis.contiguous()
@@ -133,6 +134,7 @@ class DecodeEngine:
         self.eps = float(cfg.norm_eps)
         self.n_wo = ctypes.c_int(0)
         self.n_down = ctypes.c_int(0)
+        self.n_qkv = ctypes.c_int(0)
         self.rng_state = torch.tensor([1234, 0], dtype=torch.int64, device=dev)  # {seed, draw counter}
         self._seed, self._calls = 1234, 0
         self.token = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -159,10 +161,12 @@ class DecodeEngine:
                 return lin.scales.data_ptr() + es * col0 if self.int8 else None
 
             wq, ldq = at.wqkv.weight.data_ptr(), at.wqkv.weight.stride(1)
-            k1_out = _out([(wq, ldq, 0, dim, th["q"], self.qkv.data_ptr(), sc(at.wqkv)),
-                           (wq, ldq, dim, kv, th["k"], self.qkv.data_ptr() + 2 * dim, sc(at.wqkv, dim)),
-                           (wq, ldq, dim + kv, kv, th["v"], self.qkv.data_ptr() + 2 * (dim + kv), sc(at.wqkv, dim + kv))],
-                          TEAL_OUT_ROUNDED)
+            k1_segs = [(wq, ldq, 0, dim, th["q"], self.qkv.data_ptr(), sc(at.wqkv)),
+                       (wq, ldq, dim, kv, th["k"], self.qkv.data_ptr() + 2 * dim, sc(at.wqkv, dim)),
+                       (wq, ldq, dim + kv, kv, th["v"], self.qkv.data_ptr() + 2 * (dim + kv), sc(at.wqkv, dim + kv))]
+            # split attention: the projection writes fp32 slabs that the attention launch sums itself, so a narrow
+            # (GQA) wqkv is row-sliced over all CUs without a reduce launch in between
+            k1_out = _out(k1_segs, TEAL_OUT_SLABS, self.s_qkv) if self.att_split else _out(k1_segs, TEAL_OUT_ROUNDED)
             if self.att_fused_merge:
                 k3_in = GemvIn(mode=TEAL_IN_ATTN_MERGE, x=self.att_ws.data_ptr(), att_head_dim=hd_, att_nsplit=self.att_split)
             elif self.pair:
@@ -210,14 +214,15 @@ class DecodeEngine:
                 k1_in.row_index = tok_ptr
             else:
                 k1_in.nslabs = self.n_down.value
-            self._gemv(k1_in, k1_out, self.dim)
+            self._gemv(k1_in, k1_out, self.dim, self.n_qkv if self.att_split else None)
             ymask = self.y_mask.data_ptr() if self.pair else None
             if self.att_split:
-                rc = self.L.teal_decode_attention_split(self.qkv.data_ptr(), self.rope.data_ptr(), pos_ptr, kc.data_ptr(), vc.data_ptr(),
-                                                        None if self.att_fused_merge else self.y_attn.data_ptr(), ymask, tau_o,
-                                                        cfg.n_head, cfg.n_local_heads,
-                                                        cfg.head_dim, self.max_seq, self.att_split, self.att_ws.data_ptr(),
-                                                        self.att_ws.numel() * 4, self.code, self._stream)
+                rc = self.L.teal_decode_attention_split_slabs(self.s_qkv.data_ptr(), self.n_qkv.value, self.rope.data_ptr(), pos_ptr,
+                                                              kc.data_ptr(), vc.data_ptr(),
+                                                              None if self.att_fused_merge else self.y_attn.data_ptr(), ymask, tau_o,
+                                                              cfg.n_head, cfg.n_local_heads, cfg.head_dim, self.max_seq,
+                                                              self.att_split, self.att_ws.data_ptr(), self.att_ws.numel() * 4,
+                                                              self.code, self._stream)
             else:
                 rc = self.L.teal_decode_attention_masked(self.qkv.data_ptr(), self.rope.data_ptr(), pos_ptr, kc.data_ptr(), vc.data_ptr(),
                                                          self.y_attn.data_ptr(), ymask, tau_o, cfg.n_head, cfg.n_local_heads,

@@ -444,3 +444,41 @@ def test_attn_merge_producer_equals_merge_launch(dtype, n_head, hd, pos, nsplit)
     for bad in (GemvIn(mode=TEAL_IN_ATTN_MERGE, x=ws_b.data_ptr(), att_head_dim=96, att_nsplit=nsplit),
                 GemvIn(mode=TEAL_IN_ATTN_MERGE, x=ws_b.data_ptr(), att_head_dim=hd, att_nsplit=5)):
         assert L.teal_fused_gemv(ctypes.byref(bad), ctypes.byref(gout), Z, code, ws.data_ptr(), ws.numel() * 4, None, st) < 0
+
+
+@pytest.mark.parametrize("dtype,nslabs", [(torch.float16, 1), (torch.bfloat16, 2), (torch.float16, 5), (torch.float16, 8)])
+def test_attention_from_qkv_slabs_equals_rounded_qkv(dtype, nslabs):
+    """teal_decode_attention_split_slabs sums the projection's split-K slabs itself: same bits as reducing first."""
+    from teal_amd import _lib, runtime
+    from teal_amd.gpt_fast.model import precompute_freqs_cis
+    L = _lib.load()
+    runtime.init()
+    code = runtime.dtype_code(dtype)
+    n_head, n_kv, hd, S, nsplit, pos = 8, 2, 128, 512, 4, 77
+    n = (n_head + 2 * n_kv) * hd
+    g = torch.Generator(device=DEV).manual_seed(nslabs)
+    stride = (nslabs + 3) & ~3
+    slabs = torch.zeros(n, stride, device=DEV, dtype=torch.float32)
+    slabs[:, :nslabs] = torch.randn(n, nslabs, device=DEV, generator=g) * 0.3
+    slabs[:, nslabs:] = 7.0  # padding lanes of the interleaved layout must be ignored
+    acc = torch.zeros(n, device=DEV, dtype=torch.float32)
+    for s_ in range(nslabs):  # slice order, fp32
+        acc = acc + slabs[:, s_]
+    qkv = acc.to(dtype)
+    kc = (torch.randn(n_kv, S, hd, device=DEV, generator=g) * 0.5).to(dtype)
+    vc = (torch.randn(n_kv, S, hd, device=DEV, generator=g) * 0.5).to(dtype)
+    rope = precompute_freqs_cis(S, hd, 10000, dtype).to(DEV).contiguous()
+    p = torch.tensor([pos], device=DEV, dtype=torch.int32)
+    kc2, vc2 = kc.clone(), vc.clone()
+    ws_a = torch.zeros(n_head * nsplit * (hd + 2), device=DEV, dtype=torch.float32)
+    ws_b = torch.zeros_like(ws_a)
+    st = runtime.stream_ptr()
+    assert L.teal_decode_attention_split(qkv.data_ptr(), rope.data_ptr(), p.data_ptr(), kc.data_ptr(), vc.data_ptr(), None, None, 0.0,
+                                         n_head, n_kv, hd, S, nsplit, ws_a.data_ptr(), ws_a.numel() * 4, code, st) == 0
+    assert L.teal_decode_attention_split_slabs(slabs.data_ptr(), nslabs, rope.data_ptr(), p.data_ptr(), kc2.data_ptr(), vc2.data_ptr(),
+                                               None, None, 0.0, n_head, n_kv, hd, S, nsplit, ws_b.data_ptr(), ws_b.numel() * 4,
+                                               code, st) == 0
+    assert torch.equal(ws_a, ws_b) and torch.equal(kc, kc2) and torch.equal(vc, vc2)
+    assert L.teal_decode_attention_split_slabs(slabs.data_ptr(), 9, rope.data_ptr(), p.data_ptr(), kc2.data_ptr(), vc2.data_ptr(),
+                                               None, None, 0.0, n_head, n_kv, hd, S, nsplit, ws_b.data_ptr(), ws_b.numel() * 4,
+                                               code, st) < 0
