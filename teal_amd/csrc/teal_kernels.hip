@@ -79,6 +79,8 @@ struct Params {
     int cap;       // LDS list capacity (entries)
     int to_ws;     // 1: always write fp32 slabs (an epilogue kernel follows)
     int swizzle;   // 1: XOR-swizzle tiles inside aligned groups of 8 (XCD decorrelation)
+    int sl;        // wave-local + element-wise producer: the register cache holds only this slice's rounds
+    int krt;       // wave-local: register-cache depth to launch (4, 8 or 16)
     int wl;        // 1: wave-local compaction (no cross-wave list, no barriers before the stream); cap = per-wave capacity
     int ws_il;     // 1: slabs written interleaved, ws[col * stride + slice], stride = (split + 3) & ~3
     int w8;        // 1: weights are int8 (per-column scales in seg[].scale), 8 columns = 8 bytes per lane
@@ -313,11 +315,16 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
     constexpr int GREG = KR / PER;   // groups of 64 chunks covered by the register cache
     // PAIR: the list is the union of the two keep sets (smaller threshold); see the stream loop
     const float tau = PAIR ? fminf(p.seg[0].tau, p.seg[1].tau) : sg.tau;
+    // register k of wave w caches chunk w + WAVES * k (round k of the wave).  Slice-local (wave-local compaction
+    // with an element-wise producer): a workgroup only ever needs the rounds of ITS slice, so register k caches
+    // round slice + k * split instead — 1/split of the loads, and vectors up to split * 16 rounds fit the cache
+    const int kbase = p.sl ? slice : 0, kstep = p.sl ? p.split : 1;
+    auto chunk_of = [&](const int k) { return wave + WAVES * (kbase + k * kstep); };
     uint32_t xr[KR];
     int mcl[KR];  // clamped element index of (k, lane)
 #pragma unroll
     for (int k = 0; k < KR; ++k)
-        mcl[k] = min((((k / PER) * 64 + wave + (k % PER) * WAVES) << 6) + lane, Z - 1);
+        mcl[k] = min((chunk_of(k) << 6) + lane, Z - 1);
     // activation of element m after the fused producer (modes 0 and 2 are element-wise)
     auto load_act = [&](const int m) -> uint32_t {
         if constexpr (MODE == 2) {
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         float ss = 0.0f;
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
-            const int m = (((k / PER) * 64 + wave + (k % PER) * WAVES) << 6) + lane;
+            const int m = (chunk_of(k) << 6) + lane;
             float r = bits_to_float(rb[k], BF16);
             if (p.in.nslabs > 0) {
                 const float yv = bits_to_float(float_to_bits<BF16>(sacc[k]), BF16);
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         uint16_t* rout = reinterpret_cast<uint16_t*>(p.in.resid_out);
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
-            const int m = (((k / PER) * 64 + wave + (k % PER) * WAVES) << 6) + lane;
+            const int m = (chunk_of(k) << 6) + lane;
             const float xn = bits_to_float(float_to_bits<BF16>(rv[k] * rstd), BF16);
             xr[k] = (m < Z) ? (uint32_t)float_to_bits<BF16>(xn * bits_to_float(wb[k], BF16)) : 0u;
             if (rout && blockIdx.x == 0 && m < Z) rout[m] = float_to_bits<BF16>(rv[k]);
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
             constexpr int NS = decltype(ns_tag)::value;  // 4 or 8 partials per head
             constexpr int KM = (KR * NS <= 64) ? KR : 64 / NS;  // host refuses Z beyond KM chunks per wave
             const int kk = min(lane / NS, KM - 1), qq = lane % NS;
-            const int mk = min(((kk / PER) * 64 + wave + (kk % PER) * WAVES) << 6, Z - 1);
+            const int mk = min(chunk_of(kk) << 6, Z - 1);
             const float2 st = *reinterpret_cast<const float2*>(p.in.att + ((size_t)(mk / hd) * NS + qq) * hs);
             float ov[KM][NS];
 #pragma unroll
@@ -472,7 +479,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         }
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
-            const int m = (((k / PER) * 64 + wave + (k % PER) * WAVES) << 6) + lane;
+            const int m = (chunk_of(k) << 6) + lane;
             const float gt = bits_to_float(gb[k], BF16);
             const float sl = bits_to_float(float_to_bits<BF16>(gt / (1.0f + expf(-gt))), BF16);
             xr[k] = (m < Z) ? (uint32_t)float_to_bits<BF16>(sl * bits_to_float(ub[k], BF16)) : 0u;
@@ -497,14 +504,14 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         if constexpr (MODE == 3) {
 #pragma unroll
             for (int k = 0; k < KR; ++k) {
-                const int c = (k / PER) * 64 + wave + (k % PER) * WAVES;
+                const int c = chunk_of(k);
                 mk[k] = (c < nch) ? gmask[c] : 0ull;
             }
         }
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
-            const int c = (k / PER) * 64 + wave + (k % PER) * WAVES;
-            const bool own = (kmod == slice) && (c < nch);
+            const int c = chunk_of(k);
+            const bool own = (p.sl || kmod == slice) && (c < nch);
             kmod = (kmod + 1 == p.split) ? 0 : kmod + 1;
             if (own) {
                 unsigned long long mask;
@@ -1562,7 +1569,7 @@ hipError_t launch_gemv_k(const Params& p, int dtype, size_t lds, hipStream_t st)
 template <int LPR, int WAVES, int U, int MODE, bool PAIR>
 hipError_t launch_gemv_m(const Params& p, int dtype, size_t lds, hipStream_t st) {
     if constexpr (WAVES == 16) {
-        const int owned = (((p.Z + 63) >> 6) + WAVES - 1) / WAVES;
+        const int owned = p.krt ? p.krt : (((p.Z + 63) >> 6) + WAVES - 1) / WAVES;
         if (owned <= 4) return launch_gemv_k<LPR, WAVES, U, MODE, 4, PAIR>(p, dtype, lds, st);
         if (owned <= 8) return launch_gemv_k<LPR, WAVES, U, MODE, 8, PAIR>(p, dtype, lds, st);
         return launch_gemv_k<LPR, WAVES, U, MODE, 16, PAIR>(p, dtype, lds, st);
@@ -1630,6 +1637,9 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
         if (split < 1) split = 1;
         c.split = split;
         while ((size_t)((p.Z + c.split - 1) / c.split) * 4 > 40 * 1024 && c.split < kMaxSplit) ++c.split;
+        // a long vector can force more slices than CUs / tiles (LDS list capacity): then fill whole rounds of
+        // workgroups (Llama-2-70B down, Z = 28672: 128 tiles x 3 slices = 1.5 rounds -> x 4 = 2 full rounds)
+        while (tiles * c.split > ncu && (tiles * c.split) % ncu != 0 && c.split < 8) ++c.split;
     }
     if (p.w8) {
         // int8: 8 bytes per lane.  The stream is bound by cache-line REQUESTS per CU (measured: a 64-byte and a
@@ -1685,13 +1695,21 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
     p.ws_ld = off;
     p.cap = (p.Z + c.split - 1) / c.split + 1;
     p.wl = 0;
+    p.sl = 0;
+    p.krt = 0;
     if (g_wave_local && c.waves == 16) {
         const int nch = (p.Z + 63) >> 6;
-        const int owned = (nch + 15) / 16;
-        const int krt = owned <= 4 ? 4 : (owned <= 8 ? 8 : 16);
-        const int capw = ((krt + c.split - 1) / c.split) * 64;  // entries one wave can own
-        if (owned <= krt && c.split <= owned && (size_t)16 * capw * 4 <= 40 * 1024) {
+        const int owned = (nch + 15) / 16;  // rounds of 16 chunks
+        // element-wise producers (everything but the RMSNorm, which needs the whole vector in every workgroup)
+        // cache only the rounds of the workgroup's slice
+        const bool slice_local = p.in.mode != 1 && c.split > 1;
+        const int need = slice_local ? (owned + c.split - 1) / c.split : owned;
+        const int krt = need <= 4 ? 4 : (need <= 8 ? 8 : 16);
+        const int capw = (slice_local ? need : (krt + c.split - 1) / c.split) * 64;  // entries one wave can own
+        if (need <= krt && c.split <= owned && (size_t)16 * capw * 4 <= 40 * 1024) {
             p.wl = 1;
+            p.sl = slice_local ? 1 : 0;
+            p.krt = krt;
             p.cap = capw;
         }
     }
