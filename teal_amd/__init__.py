@@ -1,7 +1,11 @@
 """teal_amd — MI355X-native (gfx950) implementation of TEAL's activation-sparsity decode hot path.
 
 Layout:
-  csrc/teal_kernels.hip   hand-written HIP kernels + the C ABI (include/teal_hip.h)
+  csrc/                   hand-written HIP for gfx950 behind the C ABI of include/teal_hip.h:
+                          teal_gemv_kernel.h (sparse GEMV template), teal_gemv_w{16,8}_{f16,bf16}.hip (instantiations),
+                          teal_attention.hip (decode attention + sampler), teal_kernels.hip (host logic + GEMV ABI)
+  quantize.py             int8 weight-only quantiser / module (feeds the int8 sparse GEMV)
+  hf.py, calibrate.py     HF-transformers plugin surface; calibration producers
   _lib.py                 hipcc build + ctypes loader of libteal_hip.so (no CPU fallback)
   kernels/                reference-shaped operator boundary: splitk_sparse_gemv, qkv_gemv,
                           SparseGEMV / SparseQKVGEMV (torch.ops.teal.*)

@@ -5,15 +5,22 @@ raises.  `build()` cross-compiles for gfx950 with hipcc (works without a GPU pre
 """
 from __future__ import annotations
 
+import concurrent.futures
 import ctypes
+import glob
 import os
 import shutil
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-SRC = os.path.join(_PKG, "csrc", "teal_kernels.hip")
+CSRC = os.path.join(_PKG, "csrc")
+# translation units: host logic + GEMV ABI, attention + sampler, and the GEMV kernel instantiations split by
+# (weight width, activation dtype) so that they compile in parallel
+SOURCES = ("teal_kernels.hip", "teal_attention.hip", "teal_gemv_w16_f16.hip", "teal_gemv_w16_bf16.hip",
+           "teal_gemv_w8_f16.hip", "teal_gemv_w8_bf16.hip")
 INCLUDE = os.path.join(_ROOT, "include")
+OBJ_DIR = os.path.join(CSRC, "_obj")
 LIB_PATH = os.path.join(_PKG, "libteal_hip.so")
 
 # every symbol include/teal_hip.h declares
@@ -34,12 +41,30 @@ def _hipcc() -> str:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -> teal_amd/libteal_hip.so (in-tree, travels with the repo)."""
-    deps = [SRC, os.path.join(INCLUDE, "teal_hip.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    """hipcc --offload-arch=gfx950 -> teal_amd/libteal_hip.so (in-tree, travels with the repo).
+    One `hipcc -c` per translation unit, in parallel, then one link."""
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(INCLUDE, "teal_hip.h")]
+    srcs = [os.path.join(CSRC, f) for f in SOURCES]
+    newest_header = max(os.path.getmtime(h) for h in headers)
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in srcs + headers):
         return LIB_PATH
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed",
-           f"-I{INCLUDE}", SRC, "-o", LIB_PATH + ".tmp"]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", f"-I{INCLUDE}", f"-I{CSRC}"]
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_header):
+            return obj
+        cmd = [hipcc, *flags, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1,0 +1,685 @@
+// teal_attention.hip — batch-1 decode attention (single-workgroup and split-KV / flash-decoding forms) and the
+// fused top-k sampler, with their C-ABI entry points (include/teal_hip.h).
+//   gpt-fast/model.py:170-186   RoPE + kv_cache.update + SDPA at S = 1   -> decode_attention*_kernel
+//   gpt-fast/generate.py:49-66  logits_to_probs + multinomial_sample_one -> sample_topk_kernel
+#include "teal_common.h"
+
+namespace teal {
+
+// ------------------------------------------------------------------------------------------------
+// Single-token attention over a static KV cache (the step between gemv1 and gemv2 of
+// gpt-fast/model.py:163-190): RoPE on q and the new k, KV-cache append, softmax(q K^T / sqrt(d)) V.
+// One workgroup (256 threads) per query head; GQA by head group.  Rounding points follow the
+// reference's fp16/bf16 tensors: rotated q/k, scores, probabilities and the output are rounded to
+// dtype; accumulation is fp32.
+// ------------------------------------------------------------------------------------------------
+template <bool BF16, int NT, int HD>
+__global__ __launch_bounds__(NT) void decode_attention_kernel(
+    const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ rope, const int* __restrict__ pos_ptr,
+    uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache, uint16_t* __restrict__ y,
+    unsigned long long* __restrict__ mask_out, const float mask_tau,
+    const int n_head, const int n_kv, const int max_seq, const float scale, unsigned long long* __restrict__ phase) {
+    constexpr int NW = NT / 64;
+    constexpr int hd = HD;
+    auto stamp_a = [&](const int i) { if (phase && threadIdx.x == 0) phase[(size_t)blockIdx.x * 8 + i] = wall_clock64(); };
+    stamp_a(0);
+    constexpr int SL = HD / 8;   // 16-byte slices per row (16 for hd=128, 8 for hd=64)
+    constexpr int RW = 64 / SL;  // V rows per wave step (4 or 8)
+    constexpr int VPF = 256 / (NW * RW) > 0 ? 256 / (NW * RW) : 1;  // V steps prefetched: the first 256 rows (hd=128)
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* qs = reinterpret_cast<float*>(smem);  // [hd] rotated q
+    float* kn = qs + hd;                         // [hd] rotated new k
+    float* vn = kn + hd;                         // [hd] new v
+    float* red = vn + hd;                        // [2 * NW] block reductions
+    float* part = red + 2 * NW;                  // [NW][hd] per-wave partial outputs
+    float* sc = part + NW * hd;                  // [max_seq] scores / probabilities
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x;
+    const int rep = n_head / n_kv;
+    const int kvh = h / rep;
+    const int pos = pos_ptr[0];
+    const int dim = n_head * hd, kvs = n_kv * hd;
+    const uint16_t* qh = qkv + (size_t)h * hd;
+    const uint16_t* kh = qkv + dim + (size_t)kvh * hd;
+    const uint16_t* vh = qkv + dim + kvs + (size_t)kvh * hd;
+    uint16_t* kc = k_cache + (size_t)kvh * max_seq * hd;
+    uint16_t* vc = v_cache + (size_t)kvh * max_seq * hd;
+
+    // ---- everything that only depends on `pos` is requested first: this thread's cached K row and
+    //      its V slices are in flight while q/k are rotated (one memory round trip instead of three)
+    // (lane = (row-in-wave rw, 16-byte slice ds): a wave reads 64/SL whole rows = 1 KiB contiguous per load)
+    const int ds = lane % SL, rw = lane / SL;
+    u32x4 kreg[VPF], vreg[VPF];
+#pragma unroll
+    for (int i = 0; i < VPF; ++i) {
+        const int t = wave * RW + rw + i * NW * RW;
+        kreg[i] = *reinterpret_cast<const u32x4*>(kc + (size_t)(t < pos ? t : 0) * hd + ds * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < VPF; ++i) {
+        const int t = wave * RW + rw + i * NW * RW;
+        vreg[i] = *reinterpret_cast<const u32x4*>(vc + (size_t)(t < pos ? t : 0) * hd + ds * 8);
+    }
+
+    // RoPE on interleaved pairs (model.py apply_rotary_emb), table rows are (cos, sin) in dtype
+    if (tid < hd / 2) {
+        const float c = bits_to_float(rope[((size_t)pos * (hd / 2) + tid) * 2], BF16);
+        const float sn = bits_to_float(rope[((size_t)pos * (hd / 2) + tid) * 2 + 1], BF16);
+        const float q0 = bits_to_float(qh[2 * tid], BF16), q1 = bits_to_float(qh[2 * tid + 1], BF16);
+        const float k0 = bits_to_float(kh[2 * tid], BF16), k1 = bits_to_float(kh[2 * tid + 1], BF16);
+        const uint16_t qa = float_to_bits<BF16>(q0 * c - q1 * sn), qb = float_to_bits<BF16>(q1 * c + q0 * sn);
+        const uint16_t ka = float_to_bits<BF16>(k0 * c - k1 * sn), kb = float_to_bits<BF16>(k1 * c + k0 * sn);
+        qs[2 * tid] = bits_to_float(qa, BF16);
+        qs[2 * tid + 1] = bits_to_float(qb, BF16);
+        kn[2 * tid] = bits_to_float(ka, BF16);
+        kn[2 * tid + 1] = bits_to_float(kb, BF16);
+        if (h % rep == 0) {  // one writer per KV head
+            kc[(size_t)pos * hd + 2 * tid] = ka;
+            kc[(size_t)pos * hd + 2 * tid + 1] = kb;
+        }
+    } else if (tid >= 128 && tid < 128 + hd) {
+        const int d = tid - 128;
+        const uint16_t vb = vh[d];
+        vn[d] = bits_to_float(vb, BF16);
+        if (h % rep == 0) vc[(size_t)pos * hd + d] = vb;
+    }
+    __syncthreads();
+    stamp_a(1);
+
+    // scores: each lane multiplies its 8-dim slice, the SL lanes of a row are summed with DPP; the new
+    // token's own key comes from LDS, not from the cache line being written
+    float qv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qv[j] = qs[ds * 8 + j];
+    float lmax = -INFINITY;
+    auto score_row = [&](const int t, const u32x4 w) {
+        float a = 0.0f;
+        if (t == pos) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += qv[j] * kn[ds * 8 + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a += qv[2 * j] * bits_to_float(w[j] & 0xFFFFu, BF16);
+                a += qv[2 * j + 1] * bits_to_float(w[j] >> 16, BF16);
+            }
+        }
+        a = row_slices_sum<SL>(a);
+        const float sv = bits_to_float(float_to_bits<BF16>(a * scale), BF16);
+        if (t <= pos) {
+            if (ds == 0) sc[t] = sv;
+            lmax = fmaxf(lmax, sv);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < VPF; ++i) score_row(wave * RW + rw + i * NW * RW, kreg[i]);
+    for (int tb = VPF * NW * RW; tb <= pos; tb += NW * RW) {  // beyond the prefetched rows (wave-uniform trip count)
+        const int t = tb + wave * RW + rw;
+        const u32x4 w = *reinterpret_cast<const u32x4*>(kc + (size_t)(t < pos ? t : 0) * hd + ds * 8);
+        score_row(t, w);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, d));
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    stamp_a(2);
+    float mx = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w]);
+    float lsum = 0.0f;
+    for (int t = tid; t <= pos; t += NT) {
+        const float e = expf(sc[t] - mx);
+        sc[t] = e;
+        lsum += e;
+    }
+    lsum = wave_sum_f(lsum);
+    if (lane == 0) red[NW + wave] = lsum;
+    __syncthreads();
+    stamp_a(3);
+    float tot = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += red[NW + w];
+    const float inv = 1.0f / tot;
+
+    // output: 16-byte slices of V rows; lane = (row-in-wave rw, 8-dim slice ds)
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.0f;
+    auto accum = [&](const int t, const u32x4 w) {
+        const float pr = bits_to_float(float_to_bits<BF16>(sc[t] * inv), BF16);
+        if (t == pos) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += pr * vn[ds * 8 + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[2 * j] += pr * bits_to_float(w[j] & 0xFFFFu, BF16);
+                o[2 * j + 1] += pr * bits_to_float(w[j] >> 16, BF16);
+            }
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < VPF; ++i) {
+        const int t = wave * RW + rw + i * NW * RW;
+        if (t <= pos) accum(t, vreg[i]);
+    }
+#pragma unroll 4
+    for (int t = wave * RW + rw + VPF * NW * RW; t <= pos; t += NW * RW) {
+        const u32x4 w = (t < pos) ? *reinterpret_cast<const u32x4*>(vc + (size_t)t * hd + ds * 8) : (u32x4){0u, 0u, 0u, 0u};
+        accum(t, w);
+    }
+    for (int off = SL; off < 64; off <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += __shfl_xor(o[j], off);
+    }
+    if (lane < SL) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[wave * hd + lane * 8 + j] = o[j];
+    }
+    __syncthreads();
+    stamp_a(4);
+    if (tid < hd) {  // whole waves (hd = 64 or 128)
+        float acc = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) acc += part[w * hd + tid];
+        const uint16_t yb = float_to_bits<BF16>(acc);
+        y[(size_t)h * hd + tid] = yb;
+        if (mask_out) {  // keep masks of y for the wo projection (TEAL_IN_MASKED consumer)
+            const float yv = bits_to_float(yb, BF16);
+            const unsigned long long mk = __ballot(keep_rule(yv, mask_tau) || (yv != yv));
+            if (lane == 0) mask_out[((size_t)h * hd + tid) >> 6] = mk;
+        }
+    }
+    stamp_a(5);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Long contexts: split the cached positions of a head over `nsplit` workgroups (flash-decoding).
+// Each workgroup produces an un-normalised partial {running max m, sum l, o[hd]} over its range; the
+// merge kernel rescales and sums them, rounds once and emits the keep masks for the wo projection.
+// With one workgroup per head a 4k context would leave 224 CUs idle while 32 stream 2 MB each.
+// ------------------------------------------------------------------------------------------------
+template <bool BF16, int HD, int NT>
+__global__ __launch_bounds__(NT) void decode_attention_split_kernel(
+    const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ rope, const int* __restrict__ pos_ptr,
+    uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache, float* __restrict__ partials,
+    const int n_head, const int n_kv, const int max_seq, const int nsplit, const int chunk_max, const float scale,
+    const float* __restrict__ qkv_slabs, const int qkv_nslabs) {
+    constexpr int NW = NT / 64, hd = HD, SL = HD / 8, RW = 64 / SL;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* qs = reinterpret_cast<float*>(smem);
+    float* kn = qs + hd;
+    float* vn = kn + hd;
+    float* red = vn + hd;            // [2 * NW]
+    float* part = red + 2 * NW;      // [NW][hd]
+    float* sc = part + NW * hd;      // [chunk_max]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+    const int rep = n_head / n_kv, kvh = h / rep;
+    const int pos = pos_ptr[0], n = pos + 1;
+    const int chunk = (n + nsplit - 1) / nsplit;
+    const int t0 = sp * chunk, t1 = min(n, t0 + chunk);
+    float* out = partials + (size_t)blockIdx.x * (hd + 2);
+    if (t0 >= t1) {  // empty range (short sequence, many splits)
+        if (tid < hd) out[2 + tid] = 0.0f;
+        if (tid == 0) { out[0] = -INFINITY; out[1] = 0.0f; }
+        return;
+    }
+    const bool has_new = (t1 == n);  // this workgroup's range ends with the token being decoded
+    const int dim = n_head * hd, kvs = n_kv * hd;
+    const uint16_t* qh = qkv + (size_t)h * hd;
+    const uint16_t* kh = qkv + dim + (size_t)kvh * hd;
+    const uint16_t* vh = qkv + dim + kvs + (size_t)kvh * hd;
+    uint16_t* kc = k_cache + (size_t)kvh * max_seq * hd;
+    uint16_t* vc = v_cache + (size_t)kvh * max_seq * hd;
+    // lanes = (row rw, 16-byte slice ds): a wave load covers RW whole cache rows (coalesced).  The cached
+    // rows depend only on pos, not on this step's q: the first PF row groups of K AND V are requested
+    // before anything else, so their latency hides behind the q/rope loads, the rope and both barriers.
+    const int ds = lane % SL, rw = lane / SL;
+    constexpr int PF = 4, STEP = NW * RW;
+    const int trow = t0 + wave * RW + rw;
+    u32x4 kreg[PF], vreg[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+        const int t = trow + i * STEP;
+        const size_t off = (size_t)((t < t1 && t != pos) ? t : t0) * hd + ds * 8;
+        kreg[i] = *reinterpret_cast<const u32x4*>(kc + off);
+        vreg[i] = *reinterpret_cast<const u32x4*>(vc + off);
+    }
+    // element `col` of the qkv projection: the rounded vector, or (qkv_slabs) the fp32 split-K slabs of the
+    // projection launch, interleaved [col][(nslabs + 3) & ~3], summed in slice order and rounded once here —
+    // a narrow (GQA) wqkv can then be row-sliced over all CUs without a reduce launch in between
+    auto qkv_at = [&](const uint16_t* base, const int i) -> uint16_t {
+        if (!qkv_slabs) return base[i];
+        const float* sp = qkv_slabs + (size_t)((base - qkv) + i) * ((qkv_nslabs + 3) & ~3);
+        float a = 0.0f;
+        for (int q = 0; q < qkv_nslabs; ++q) a += sp[q];
+        return float_to_bits<BF16>(a);
+    };
+    if (tid < hd / 2) {
+        const float c = bits_to_float(rope[((size_t)pos * (hd / 2) + tid) * 2], BF16);
+        const float sn = bits_to_float(rope[((size_t)pos * (hd / 2) + tid) * 2 + 1], BF16);
+        const float q0 = bits_to_float(qkv_at(qh, 2 * tid), BF16), q1 = bits_to_float(qkv_at(qh, 2 * tid + 1), BF16);
+        qs[2 * tid] = bits_to_float(float_to_bits<BF16>(q0 * c - q1 * sn), BF16);
+        qs[2 * tid + 1] = bits_to_float(float_to_bits<BF16>(q1 * c + q0 * sn), BF16);
+        if (has_new) {
+            const float k0 = bits_to_float(qkv_at(kh, 2 * tid), BF16), k1 = bits_to_float(qkv_at(kh, 2 * tid + 1), BF16);
+            const uint16_t ka = float_to_bits<BF16>(k0 * c - k1 * sn), kb = float_to_bits<BF16>(k1 * c + k0 * sn);
+            kn[2 * tid] = bits_to_float(ka, BF16);
+            kn[2 * tid + 1] = bits_to_float(kb, BF16);
+            if (h % rep == 0) {
+                kc[(size_t)pos * hd + 2 * tid] = ka;
+                kc[(size_t)pos * hd + 2 * tid + 1] = kb;
+            }
+        }
+    } else if (has_new && tid >= 128 && tid < 128 + hd) {
+        const int d = tid - 128;
+        const uint16_t vb = qkv_at(vh, d);
+        vn[d] = bits_to_float(vb, BF16);
+        if (h % rep == 0) vc[(size_t)pos * hd + d] = vb;
+    }
+    __syncthreads();
+    float qv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qv[j] = qs[ds * 8 + j];
+    float lmax = -INFINITY;
+    auto score_row = [&](const int t, const u32x4 w) {
+        float a = 0.0f;
+        if (t == pos) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += qv[j] * kn[ds * 8 + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a += qv[2 * j] * bits_to_float(w[j] & 0xFFFFu, BF16);
+                a += qv[2 * j + 1] * bits_to_float(w[j] >> 16, BF16);
+            }
+        }
+        a = row_slices_sum<SL>(a);
+        const float sv = bits_to_float(float_to_bits<BF16>(a * scale), BF16);
+        if (t < t1) {
+            if (ds == 0) sc[t - t0] = sv;
+            lmax = fmaxf(lmax, sv);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+        if (t0 + i * STEP < t1) score_row(trow + i * STEP, kreg[i]);  // workgroup-uniform guard
+#pragma unroll 4
+    for (int tb = t0 + PF * STEP; tb < t1; tb += STEP) {
+        const int t = tb + wave * RW + rw;
+        score_row(t, *reinterpret_cast<const u32x4*>(kc + (size_t)((t < t1 && t != pos) ? t : t0) * hd + ds * 8));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, d));
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    float mx = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w]);
+    float lsum = 0.0f;
+    for (int t = t0 + tid; t < t1; t += NT) {
+        const float e = expf(sc[t - t0] - mx);
+        sc[t - t0] = e;
+        lsum += e;
+    }
+    lsum = wave_sum_f(lsum);
+    if (lane == 0) red[NW + wave] = lsum;
+    __syncthreads();
+    float tot = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += red[NW + w];
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.0f;
+    auto pv_row = [&](const int t, const u32x4 w) {
+        const float pr = sc[t - t0];
+        if (t == pos) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += pr * vn[ds * 8 + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[2 * j] += pr * bits_to_float(w[j] & 0xFFFFu, BF16);
+                o[2 * j + 1] += pr * bits_to_float(w[j] >> 16, BF16);
+            }
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+        if (trow + i * STEP < t1) pv_row(trow + i * STEP, vreg[i]);
+#pragma unroll 4
+    for (int t = trow + PF * STEP; t < t1; t += STEP) pv_row(t, *reinterpret_cast<const u32x4*>(vc + (size_t)t * hd + ds * 8));
+    for (int off = SL; off < 64; off <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += __shfl_xor(o[j], off);
+    }
+    if (lane < SL) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[wave * hd + lane * 8 + j] = o[j];
+    }
+    __syncthreads();
+    if (tid < hd) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) acc += part[w * hd + tid];
+        out[2 + tid] = acc;
+    }
+    if (tid == 0) { out[0] = mx; out[1] = tot; }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(128) void decode_attention_merge_kernel(const float* __restrict__ partials,
+                                                                     uint16_t* __restrict__ y,
+                                                                     unsigned long long* __restrict__ mask_out,
+                                                                     const float mask_tau, const int hd, const int nsplit) {
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const float* p = partials + (size_t)h * nsplit * (hd + 2);
+    if (tid >= hd) return;  // hd = 64 or 128: whole waves
+    float M = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, p[(size_t)s * (hd + 2)]);
+    float L = 0.0f, O = 0.0f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float* ps = p + (size_t)s * (hd + 2);
+        if (ps[1] > 0.0f) {
+            const float f = expf(ps[0] - M);
+            L += ps[1] * f;
+            O += ps[2 + tid] * f;
+        }
+    }
+    const uint16_t yb = float_to_bits<BF16>(O / L);
+    y[(size_t)h * hd + tid] = yb;
+    if (mask_out) {
+        const float yv = bits_to_float(yb, BF16);
+        const unsigned long long mk = __ballot(keep_rule(yv, mask_tau) || (yv != yv));
+        if (lane == 0) mask_out[((size_t)h * hd + tid) >> 6] = mk;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused sampler (gpt-fast/generate.py:49-66): logits / T -> keep the top-k -> softmax -> exponential-
+// race multinomial (argmax p_i / q_i, q_i ~ Exp(1)), no host sync.  One workgroup; the k-th largest
+// logit is found EXACTLY by a two-pass radix select on the 16-bit keys (ties at the pivot are all
+// kept, as `logits < pivot -> -inf` does).  Randomness: counter-based hash of (seed, draw counter,
+// index); the draw counter lives on the device and is bumped by the kernel, so hipGraph replays
+// draw fresh numbers.  Token streams are not pinned by the reference (they depend on torch's RNG).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t order_key16(uint32_t b, bool bf16) {
+    (void)bf16;  // fp16 and bf16 share sign-magnitude ordering
+    return (b & 0x8000u) ? (~b & 0xFFFFu) : (b | 0x8000u);
+}
+
+__device__ __forceinline__ uint32_t hash3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ (c + 0x165667B1u) * 0xC2B2AE3Du;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+// sel[0] = the bin b (counted from the top) in which the `need`-th largest key falls, sel[1] = its rank
+// inside that bin.  hist[256] -> suffix counts by a Hillis-Steele scan (all threads must call this).
+__device__ __forceinline__ void select_bin(const unsigned int* hist, unsigned int* suf, unsigned int* sel,
+                                           const unsigned int need, const int tid) {
+    if (tid < 256) suf[tid] = hist[tid];
+    __syncthreads();
+#pragma unroll
+    for (int d = 1; d < 256; d <<= 1) {
+        const unsigned int v = (tid < 256 && tid + d < 256) ? suf[tid + d] : 0u;
+        __syncthreads();
+        if (tid < 256) suf[tid] += v;
+        __syncthreads();
+    }
+    if (tid < 256) {
+        const unsigned int above = tid < 255 ? suf[tid + 1] : 0u;  // keys in strictly higher bins
+        if (suf[tid] >= need && above < need) { sel[0] = (unsigned int)tid; sel[1] = need - above; }
+    }
+    if (tid == 0 && suf[0] < need) { sel[0] = 0u; sel[1] = need; }  // fewer keys than requested: keep all
+    __syncthreads();
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(1024) void sample_topk_kernel(const uint16_t* __restrict__ logits, const int V,
+                                                            const int top_k, const float inv_temp,
+                                                            unsigned long long* __restrict__ rng_state,
+                                                            int* __restrict__ token_out, int* __restrict__ pos_inout,
+                                                            int* __restrict__ history, const int history_len) {
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned int whist[16][256];  // per-wave sub-histograms: logits cluster in a few bins, a single
+                                             // shared histogram serialises on LDS atomics
+    __shared__ float fred[16];
+    __shared__ int ired[16];
+    __shared__ unsigned int sel[2];
+    __shared__ unsigned int suf[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool filter = top_k > 0 && top_k < V;
+    const int V8 = V >> 3;  // 16-byte vectors (vocab sizes are multiples of 8; the tail is handled scalar)
+    const u32x4* lv = reinterpret_cast<const u32x4*>(logits);
+    uint32_t pivot_key = 0;  // keep keys >= pivot_key
+    float mx = -INFINITY;
+    for (int i = tid; i < 16 * 256; i += 1024) (&whist[0][0])[i] = 0;
+    __syncthreads();
+    // pass 1: high-byte histogram of the order-preserving 16-bit keys + global max
+    for (int i = tid; i < V8; i += 1024) {
+        const u32x4 w = lv[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t lo = w[j] & 0xFFFFu, hi = w[j] >> 16;
+            mx = fmaxf(mx, fmaxf(bits_to_float(lo, BF16), bits_to_float(hi, BF16)));
+            if (filter) {
+                atomicAdd(&whist[wave][order_key16(lo, BF16) >> 8], 1u);
+                atomicAdd(&whist[wave][order_key16(hi, BF16) >> 8], 1u);
+            }
+        }
+    }
+    for (int i = (V8 << 3) + tid; i < V; i += 1024) {
+        mx = fmaxf(mx, bits_to_float(logits[i], BF16));
+        if (filter) atomicAdd(&whist[wave][order_key16(logits[i], BF16) >> 8], 1u);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    if (lane == 0) fred[wave] = mx;
+    __syncthreads();
+    if (tid < 256) {
+        unsigned int a = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) a += whist[w][tid];
+        hist[tid] = a;
+    }
+    __syncthreads();
+    mx = fred[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, fred[w]);
+    if (filter) {
+        // suffix counts over the 256 bins (parallel scan), then the bin holding the top_k-th key
+        select_bin(hist, suf, sel, (unsigned int)top_k, tid);
+        __syncthreads();
+        const unsigned int hb = sel[0], need2 = sel[1];
+        __syncthreads();
+        for (int i = tid; i < 16 * 256; i += 1024) (&whist[0][0])[i] = 0;
+        __syncthreads();
+        // pass 2: low-byte histogram inside the selected high-byte bin
+        for (int i = tid; i < V8; i += 1024) {
+            const u32x4 w = lv[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t k0 = order_key16(w[j] & 0xFFFFu, BF16), k1 = order_key16(w[j] >> 16, BF16);
+                if ((k0 >> 8) == hb) atomicAdd(&whist[wave][k0 & 0xFFu], 1u);
+                if ((k1 >> 8) == hb) atomicAdd(&whist[wave][k1 & 0xFFu], 1u);
+            }
+        }
+        for (int i = (V8 << 3) + tid; i < V; i += 1024) {
+            const uint32_t k = order_key16(logits[i], BF16);
+            if ((k >> 8) == hb) atomicAdd(&whist[wave][k & 0xFFu], 1u);
+        }
+        __syncthreads();
+        if (tid < 256) {
+            unsigned int a = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) a += whist[w][tid];
+            hist[tid] = a;
+        }
+        __syncthreads();
+        select_bin(hist, suf, sel, need2, tid);
+        if (tid == 0) sel[0] = (hb << 8) | sel[0];
+        __syncthreads();
+        pivot_key = sel[0];
+    }
+    // exponential race: argmax_i exp((x_i - max)/T) / q_i  over the kept set (the softmax
+    // normaliser is common to all i and cannot change the argmax)
+    const uint32_t seed = (uint32_t)rng_state[0], ctr = (uint32_t)rng_state[1];
+    float best = -1.0f;
+    int besti = 0x7FFFFFFF;
+    auto consider = [&](const uint32_t b, const int i) {
+        if (filter && order_key16(b, BF16) < pivot_key) return;
+        const float pnum = expf((bits_to_float(b, BF16) - mx) * inv_temp);
+        const float u = ((float)(hash3(seed, ctr, (uint32_t)i) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float scv = pnum / (-logf(u));
+        if (scv > best || (scv == best && i < besti)) { best = scv; besti = i; }
+    };
+    for (int i = tid; i < V8; i += 1024) {
+        const u32x4 w = lv[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            consider(w[j] & 0xFFFFu, i * 8 + 2 * j);
+            consider(w[j] >> 16, i * 8 + 2 * j + 1);
+        }
+    }
+    for (int i = (V8 << 3) + tid; i < V; i += 1024) consider(logits[i], i);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float ob = __shfl_xor(best, d);
+        const int oi = __shfl_xor(besti, d);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    __syncthreads();
+    if (lane == 0) { fred[wave] = best; ired[wave] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (fred[w] > best || (fred[w] == best && ired[w] < besti)) { best = fred[w]; besti = ired[w]; }
+        token_out[0] = besti;
+        const unsigned long long c = rng_state[1];
+        if (history && (long long)c < (long long)history_len) history[c] = besti;
+        rng_state[1] = c + 1ull;
+        if (pos_inout) pos_inout[0] = pos_inout[0] + 1;
+    }
+}
+
+
+}  // namespace teal
+
+using namespace teal;
+
+extern "C" {
+
+int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,
+                                 void* y, void* mask_out, float mask_tau, int n_head, int n_kv_head, int head_dim,
+                                 int max_seq, int dtype, void* stream) {
+    if (!qkv || !rope || !pos || !k_cache || !v_cache || !y) return TEAL_ERR_ARG;
+    if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
+    if ((head_dim != 64 && head_dim != 128) || n_head <= 0 || n_kv_head <= 0 || n_head % n_kv_head || max_seq <= 0)
+        return TEAL_ERR_SHAPE;
+    // 16 waves per head: a wave load covers whole cache rows, one pass covers 1024 positions
+    const int nt = 1024;
+    const size_t lds = (size_t)(3 * head_dim + 2 * (nt / 64) + (nt / 64) * head_dim + max_seq) * sizeof(float);
+    if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    const dim3 grid(n_head), block(nt);
+    auto* q = reinterpret_cast<const uint16_t*>(qkv);
+    auto* r = reinterpret_cast<const uint16_t*>(rope);
+    auto* kc = reinterpret_cast<uint16_t*>(k_cache);
+    auto* vc = reinterpret_cast<uint16_t*>(v_cache);
+    auto* yo = reinterpret_cast<uint16_t*>(y);
+    auto* mo = reinterpret_cast<unsigned long long*>(mask_out);
+#define TEAL_ATT(BF, NTV, HDV) hipLaunchKernelGGL((decode_attention_kernel<BF, NTV, HDV>), grid, block, lds, st, q, r, pos, kc, vc, yo, mo, mask_tau, n_head, n_kv_head, max_seq, scale, g_phase)
+#define TEAL_ATT_HD(BF, NTV) do { if (head_dim == 128) TEAL_ATT(BF, NTV, 128); else TEAL_ATT(BF, NTV, 64); } while (0)
+    if (dtype == TEAL_BF16) TEAL_ATT_HD(true, 1024);
+    else TEAL_ATT_HD(false, 1024);
+#undef TEAL_ATT_HD
+#undef TEAL_ATT
+    return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
+}
+
+static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv_nslabs, const void* rope, const int32_t* pos,
+                                void* k_cache, void* v_cache, void* y, void* mask_out, float mask_tau, int n_head,
+                                int n_kv_head, int head_dim, int max_seq, int nsplit, void* partials, size_t partials_bytes,
+                                int dtype, void* stream) {
+    if ((!qkv && !qkv_slabs) || !rope || !pos || !k_cache || !v_cache || !partials) return TEAL_ERR_ARG;
+    if (qkv_slabs && (qkv_nslabs < 1 || qkv_nslabs > 8 || !aligned16(qkv_slabs))) return TEAL_ERR_ARG;
+    if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
+    if ((head_dim != 64 && head_dim != 128) || n_head <= 0 || n_kv_head <= 0 || n_head % n_kv_head || max_seq <= 0 ||
+        nsplit < 1 || nsplit > 64)
+        return TEAL_ERR_SHAPE;
+    if (partials_bytes < (size_t)n_head * nsplit * (head_dim + 2) * sizeof(float)) return TEAL_ERR_WORKSPACE;
+    const int chunk_max = (max_seq + nsplit - 1) / nsplit;
+    // bandwidth of one workgroup = bytes in flight / latency: long shares get 16 waves (the whole K and V
+    // share of up to 256 rows is requested up front), short ones 4 waves (cheaper barriers)
+    const int nt = chunk_max > 128 ? 1024 : 256;
+    const size_t lds = (size_t)(3 * head_dim + 2 * (nt / 64) + (nt / 64) * head_dim + chunk_max) * sizeof(float);
+    if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    auto* q = reinterpret_cast<const uint16_t*>(qkv);
+    auto* r = reinterpret_cast<const uint16_t*>(rope);
+    auto* kc = reinterpret_cast<uint16_t*>(k_cache);
+    auto* vc = reinterpret_cast<uint16_t*>(v_cache);
+    auto* pw = reinterpret_cast<float*>(partials);
+    const dim3 grid(n_head * nsplit), block(nt);
+#define TEAL_ATTS(BF, HDV, NTV) hipLaunchKernelGGL((decode_attention_split_kernel<BF, HDV, NTV>), grid, block, lds, st, q, r, pos, kc, vc, pw, n_head, n_kv_head, max_seq, nsplit, chunk_max, scale, qkv_slabs, qkv_nslabs)
+#define TEAL_ATTS_NT(BF, HDV) do { if (nt == 1024) TEAL_ATTS(BF, HDV, 1024); else TEAL_ATTS(BF, HDV, 256); } while (0)
+    if (dtype == TEAL_BF16) { if (head_dim == 128) TEAL_ATTS_NT(true, 128); else TEAL_ATTS_NT(true, 64); }
+    else { if (head_dim == 128) TEAL_ATTS_NT(false, 128); else TEAL_ATTS_NT(false, 64); }
+#undef TEAL_ATTS_NT
+#undef TEAL_ATTS
+    if (hipGetLastError() != hipSuccess) return TEAL_ERR_LAUNCH;
+    if (!y) return TEAL_OK;  // partials only: the consumer merges (TEAL_IN_ATTN_MERGE)
+    auto* yo = reinterpret_cast<uint16_t*>(y);
+    auto* mo = reinterpret_cast<unsigned long long*>(mask_out);
+    if (dtype == TEAL_BF16)
+        hipLaunchKernelGGL((decode_attention_merge_kernel<true>), dim3(n_head), dim3(128), 0, st, pw, yo, mo, mask_tau, head_dim, nsplit);
+    else
+        hipLaunchKernelGGL((decode_attention_merge_kernel<false>), dim3(n_head), dim3(128), 0, st, pw, yo, mo, mask_tau, head_dim, nsplit);
+    return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
+}
+
+int teal_decode_attention_split(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,
+                                void* y, void* mask_out, float mask_tau, int n_head, int n_kv_head, int head_dim,
+                                int max_seq, int nsplit, void* partials, size_t partials_bytes, int dtype, void* stream) {
+    if (!qkv) return TEAL_ERR_ARG;
+    return attention_split_impl(qkv, nullptr, 0, rope, pos, k_cache, v_cache, y, mask_out, mask_tau, n_head, n_kv_head,
+                                head_dim, max_seq, nsplit, partials, partials_bytes, dtype, stream);
+}
+
+int teal_decode_attention_split_slabs(const float* qkv_slabs, int qkv_nslabs, const void* rope, const int32_t* pos,
+                                      void* k_cache, void* v_cache, void* y, void* mask_out, float mask_tau, int n_head,
+                                      int n_kv_head, int head_dim, int max_seq, int nsplit, void* partials,
+                                      size_t partials_bytes, int dtype, void* stream) {
+    if (!qkv_slabs) return TEAL_ERR_ARG;
+    return attention_split_impl(nullptr, qkv_slabs, qkv_nslabs, rope, pos, k_cache, v_cache, y, mask_out, mask_tau, n_head,
+                                n_kv_head, head_dim, max_seq, nsplit, partials, partials_bytes, dtype, stream);
+}
+
+int teal_decode_attention(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,
+                          void* y, int n_head, int n_kv_head, int head_dim, int max_seq, int dtype, void* stream) {
+    return teal_decode_attention_masked(qkv, rope, pos, k_cache, v_cache, y, nullptr, 0.0f, n_head, n_kv_head, head_dim,
+                                        max_seq, dtype, stream);
+}
+
+int teal_sample_topk(const void* logits, int vocab, int dtype, int top_k, float temperature, void* rng_state,
+                     int32_t* token_out, int32_t* pos_inout, int32_t* history, int history_len, void* stream) {
+    if (!logits || !rng_state || !token_out || vocab <= 0) return TEAL_ERR_ARG;
+    if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
+    if (!aligned16(logits)) return TEAL_ERR_ALIGN;
+    const float inv_temp = 1.0f / fmaxf(temperature, 1e-5f);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    auto* lg = reinterpret_cast<const uint16_t*>(logits);
+    auto* rs = reinterpret_cast<unsigned long long*>(rng_state);
+    if (dtype == TEAL_BF16)
+        hipLaunchKernelGGL((sample_topk_kernel<true>), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len);
+    else
+        hipLaunchKernelGGL((sample_topk_kernel<false>), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len);
+    return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
+}
+
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+// teal_common.h — types, launch parameters and device helpers shared by the translation units of
+// libteal_hip.so (gfx950 / CDNA4, wave64).  Internal header: the public boundary is include/teal_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "teal_hip.h"
+
+namespace teal {
+
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kMaxSeg = 3;
+constexpr int kMaxSplit = 32;
+
+
+struct Seg {
+    const void* w;  // weight image of this segment: row-major [Z][ld]
+    void* y;        // output of this segment (element 0 = first column of the segment)
+    float tau;
+    int ld;      // row stride in elements
+    int col0;    // first column of the segment inside a weight row
+    int ncols;   // columns in the segment
+    int tile0;   // first tile id of the segment
+    int ws_off;  // column offset of the segment inside a workspace slab
+    const void* scale;  // int8 weights: per-output-column scale (activation dtype), element 0 = column col0
+};
+
+// fused activation producers: what the workgroup computes before the mask
+struct InSpec {
+    int mode;                  // 0 plain x; 1 residual + slabs -> RMSNorm; 2 silu(gate) * up
+    int nslabs;                // mode 1: fp32 slabs to fold into the residual
+    const void* resid_in;      // mode 1: residual stream [Z] (or a table when row_index is set)
+    const int* row_index;      // mode 1: optional device int: resid_in += row_index[0] * Z
+    const float* slabs;        // mode 1: [nslabs][Z]
+    const void* norm_w;        // mode 1: RMSNorm weight [Z]
+    void* resid_out;           // mode 1: updated residual, written by workgroup 0
+    const float* att;          // mode 4: attention partials [n_head][att_ns][head_dim + 2] = {max, sum, o[head_dim]}
+    int att_hd;                // mode 4: head_dim (64 or 128)
+    int att_ns;                // mode 4: partials per head (4 or 8)
+    int slabs_il;              // mode 1: slabs are interleaved [Z][(nslabs + 3) & ~3] (one 16-byte load per element)
+    const unsigned long long* masks;  // mode 3: keep masks (one per 64 activations) emitted by the producer
+    float eps;
+};
+
+struct Params {
+    InSpec in;
+    const void* x;
+    float* ws;  // [split][ws_ld] fp32 partial slabs
+    int Z;
+    int nseg;
+    int ntiles;
+    int split;
+    int ws_ld;
+    int cap;       // LDS list capacity (entries)
+    int to_ws;     // 1: always write fp32 slabs (an epilogue kernel follows)
+    int swizzle;   // 1: XOR-swizzle tiles inside aligned groups of 8 (XCD decorrelation)
+    int sl;        // wave-local + element-wise producer: the register cache holds only this slice's rounds
+    int krt;       // wave-local: register-cache depth to launch (4, 8 or 16)
+    int wl;        // 1: wave-local compaction (no cross-wave list, no barriers before the stream); cap = per-wave capacity
+    int ws_il;     // 1: slabs written interleaved, ws[col * stride + slice], stride = (split + 3) & ~3
+    int w8;        // 1: weights are int8 (per-column scales in seg[].scale), 8 columns = 8 bytes per lane
+    int pair;      // 1: seg[0] = gate, seg[1] = up over the SAME column tile; epilogue silu(g)*u -> seg[0].y
+    unsigned long long* mask_out;  // pair: keep masks of the output vs mask_tau for the next launch (or null)
+    float mask_tau;
+    unsigned long long* phase;  // optional: per-workgroup phase timestamps (teal_set_phase_buffer)
+    Seg seg[kMaxSeg];
+};
+
+
+struct Config {
+    int lpr, waves, split, unroll;
+};
+
+// process-global tuning state (teal_kernels.hip)
+extern int g_num_cu;
+extern Config g_override;
+extern unsigned long long* g_phase;
+extern int g_swizzle;
+extern int g_wave_local;
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// GEMV launchers, one translation unit per (weight width, activation dtype) so that the ~290 kernel
+// instantiations compile in parallel: teal_gemv_{w16,w8}_{f16,bf16}.hip
+hipError_t launch_gemv_w16_f16(const Params& p, size_t lds, const Config& c, hipStream_t st);
+hipError_t launch_gemv_w16_bf16(const Params& p, size_t lds, const Config& c, hipStream_t st);
+hipError_t launch_gemv_w8_f16(const Params& p, size_t lds, const Config& c, hipStream_t st);
+hipError_t launch_gemv_w8_bf16(const Params& p, size_t lds, const Config& c, hipStream_t st);
+
+__device__ __forceinline__ float bits_to_float(uint32_t b16, bool bf16) {
+    if (bf16) return __uint_as_float(b16 << 16);
+    _Float16 h = __builtin_bit_cast(_Float16, (uint16_t)b16);
+    return (float)h;
+}
+
+template <bool BF16>
+__device__ __forceinline__ uint16_t float_to_bits(float f) {
+    if (BF16) {
+        uint32_t u = __float_as_uint(f);
+        if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    }
+    _Float16 h = (_Float16)f;  // v_cvt_f16_f32, round-to-nearest-even
+    return __builtin_bit_cast(uint16_t, h);
+}
+
+// keep rule of the reference kernel: float32(|x|) > float32(tau)  (kernels/sparse_gemv.py:75)
+__device__ __forceinline__ bool keep_rule(float v, float tau) { return fabsf(v) > tau; }
+
+
+// wave64 inclusive scan: 4 DPP row_shr steps inside each row of 16 lanes, then the three row totals
+// are folded in through SGPRs (v_readlane) — no LDS traffic, unlike __shfl_up (ds_bpermute).
+__device__ __forceinline__ int wave_incl_scan(int v, const int lane) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    const int t0 = __builtin_amdgcn_readlane(v, 15);
+    const int t1 = __builtin_amdgcn_readlane(v, 31);
+    const int t2 = __builtin_amdgcn_readlane(v, 47);
+    return v + (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0);
+}
+
+// sum of a float over the 64 lanes of a wave (result valid in every lane)
+__device__ __forceinline__ float wave_sum_f(float v) {
+    auto shr = [](float a, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    v += shr(v, std::integral_constant<int, 0x111>{});
+    v += shr(v, std::integral_constant<int, 0x112>{});
+    v += shr(v, std::integral_constant<int, 0x114>{});
+    v += shr(v, std::integral_constant<int, 0x118>{});
+    const int iv = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 15)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 31)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 47)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 63));
+}
+
+// sum over the SL (16 or 8) consecutive lanes that hold the 16-byte slices of one K/V row
+template <int SL>
+__device__ __forceinline__ float row_slices_sum(float v) {
+    if constexpr (SL == 16) {  // one DPP row: rotate-and-add, every lane ends with the total
+        auto ror = [](float a, auto ctrl) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), decltype(ctrl)::value, 0xf, 0xf, false));
+        };
+        v += ror(v, std::integral_constant<int, 0x128>{});  // row_ror:8
+        v += ror(v, std::integral_constant<int, 0x124>{});  // row_ror:4
+        v += ror(v, std::integral_constant<int, 0x122>{});  // row_ror:2
+        v += ror(v, std::integral_constant<int, 0x121>{});  // row_ror:1
+        return v;
+    } else {
+#pragma unroll
+        for (int d = 1; d < SL; d <<= 1) v += __shfl_xor(v, d);
+        return v;
+    }
+}
+
+
+__device__ __forceinline__ int lane_rank(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+
+}  // namespace teal
