@@ -269,7 +269,7 @@ def roofline_engine_gateup(eng, a):
         cfgv[3] = 4
     owned = ((Z + 63) // 64 + 15) // 16
     krt = 4 if owned <= 4 else (8 if owned <= 8 else 16)
-    kname = f"sparse_gemv_kernel<{cfgv[0]},16,{cfgv[3]},{'true' if eng.code else 'false'},1,{krt},{'true' if eng.pair else 'false'}" + (",true>" if eng.int8 else ">")
+    kname = f"sparse_gemv_kernel<{cfgv[0]},16,{cfgv[3]},{'true' if eng.code else 'false'},1,{krt},{'true' if eng.pair else 'false'},{'true' if eng.int8 else 'false'}>"
     traffic, tsrc = pmc_traffic(kname)
     return {"bound": "hbm", "achieved": total_bytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": total_bytes / t / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
