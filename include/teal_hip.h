@@ -179,7 +179,8 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
 /* Single-token attention between gemv1 and gemv2 (gpt-fast/model.py:170-186): RoPE(q, k_new) with the
  * (cos, sin) table rope[max_pos][head_dim/2][2], KV-cache append at *pos, softmax(q K^T / sqrt(d)) V.
  * qkv = [q | k | v] as produced by the fused wqkv GEMV; caches are [n_kv_head][max_seq][head_dim];
- * y = [n_head * head_dim].  head_dim 64 or 128. */
+ * y = [n_head * head_dim].  head_dim 64 or 128.  A position >= max_seq is clamped to the last cache slot (no
+ * out-of-bounds write; the output of such a step is meaningless). */
 int teal_decode_attention(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,
                           void* y, int n_head, int n_kv_head, int head_dim, int max_seq, int dtype, void* stream);
 

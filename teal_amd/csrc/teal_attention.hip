@@ -37,7 +37,9 @@ __global__ __launch_bounds__(NT) void decode_attention_kernel(
     const int h = blockIdx.x;
     const int rep = n_head / n_kv;
     const int kvh = h / rep;
-    const int pos = pos_ptr[0];
+    // a position past the cache (a caller decoding more tokens than it allocated) must not write out of bounds:
+    // it is clamped to the last slot — the output is then meaningless, the memory stays intact
+    const int pos = min(max(pos_ptr[0], 0), max_seq - 1);
     const int dim = n_head * hd, kvs = n_kv * hd;
     const uint16_t* qh = qkv + (size_t)h * hd;
     const uint16_t* kh = qkv + dim + (size_t)kvh * hd;
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
     const int rep = n_head / n_kv, kvh = h / rep;
-    const int pos = pos_ptr[0], n = pos + 1;
+    const int pos = min(max(pos_ptr[0], 0), max_seq - 1), n = pos + 1;  // clamped: never writes past the cache
     const int chunk = (n + nsplit - 1) / nsplit;
     const int t0 = sp * chunk, t1 = min(n, t0 + chunk);
     float* out = partials + (size_t)blockIdx.x * (hd + 2);

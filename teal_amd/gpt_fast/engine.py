@@ -324,8 +324,17 @@ def make_engine_stepper(model: Transformer, a):
         eng.tok_buf.copy_(tok.view(1, 1))
         eng.pos_buf.fill_(npr)
         graph = eng.capture_loop(0.8, 200)
+    # capture_loop replays the step a few times: read back where the stream stands
+    state = {"pos": int(eng.pos_buf.item())}
+    max_seq = eng.max_seq
 
     def step():
+        # a run longer than the model's context (block_size) wraps back to the end of the prompt instead of
+        # stepping past the KV cache; every step still attends over the positions it is at
+        if state["pos"] + 1 >= max_seq:
+            eng.pos_buf.fill_(npr)
+            state["pos"] = npr
         graph.replay()
+        state["pos"] += 1
 
     return step, {"thresholds": ths, "engine": eng}

@@ -322,7 +322,8 @@ def main(args) -> Dict:
     torch.manual_seed(1234)
     model_size = _get_model_size(model)
     decoder = GraphedDecoder(model, args.compile, args.temperature, args.top_k)
-    if args.engine:
+    use_engine = args.engine or (args.compile and thresholds is not None and not getattr(args, "no_engine", False))
+    if use_engine:
         assert thresholds is not None, "--engine needs thresholds (--hist_path or --synthetic)"
         decoder = EngineDecoder(model, thresholds, args.compile, args.temperature, args.top_k)
     tps = []
@@ -354,7 +355,7 @@ def main(args) -> Dict:
     mean = sum(tps) / max(1, len(tps))
     print(f"Average tokens/sec: {mean:.2f}")
     print(f"Memory used: {torch.cuda.max_memory_reserved() / 1e9:.02f} GB")
-    return {"tokens_per_sec": tps, "mean_tokens_per_sec": mean, "thresholds": thresholds}
+    return {"tokens_per_sec": tps, "mean_tokens_per_sec": mean, "thresholds": thresholds, "decoder": type(decoder).__name__}
 
 
 def build_parser() -> argparse.ArgumentParser:
@@ -378,7 +379,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--n_layer", type=int, default=None, help="override the layer count (synthetic smoke runs)")
     p.add_argument("--dense", action="store_true", help="do not monkeypatch: dense baseline")
     p.add_argument("--report_kept", action="store_true", help="print the achieved kept fraction per projection")
-    p.add_argument("--engine", action="store_true", help="fused HIP decode step (teal_amd/gpt_fast/engine.py)")
+    p.add_argument("--engine", action="store_true", help="fused HIP decode step (teal_amd/gpt_fast/engine.py); implied by --compile "
+                   "when thresholds are installed")
+    p.add_argument("--no_engine", action="store_true", help="with --compile: capture the reference-shaped module path "
+                   "(torch.ops.teal.* + eager glue) instead of the fused engine")
     return p
 
 

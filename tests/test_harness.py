@@ -142,13 +142,14 @@ def test_sparse_thresholds_reduce_rows_read():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [["--engine"], [], ["--engine", "--precision", "bf16"], ["--engine", "--sparsity", "0.0"]])
+@pytest.mark.parametrize("extra", [["--engine"], [], ["--no_engine"], ["--precision", "bf16"], ["--engine", "--sparsity", "0.0"]])
 def test_generate_main_synthetic_cli(extra):
     """the reference-shaped CLI end to end on a tiny synthetic model: load -> monkeypatch -> capture ->
     timed samples, through the fused engine and through the module path."""
     args = G.build_parser().parse_args(["--synthetic", "tiny-test", "--sparsity", "0.5", "--compile", "--num_samples", "2",
                                         "--max_new_tokens", "16", "--top_k", "50", "--report_kept"] + extra)
     res = G.main(args)
+    assert res["decoder"] == ("GraphedDecoder" if "--no_engine" in extra else "EngineDecoder")  # --compile implies the fused engine
     assert len(res["tokens_per_sec"]) == 2 and all(t > 0 for t in res["tokens_per_sec"])
     assert res["thresholds"] is not None and len(res["thresholds"]) == 2
 
