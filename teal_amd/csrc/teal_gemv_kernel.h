@@ -6,6 +6,20 @@
 //   kernels/sparse_gemv.py:152-194  qkv_kernel                  -> sparse_gemv_kernel<> (3 segments)
 //   kernels/sparse_gemv.py:8-12     init_to_zero("Y") memset    -> gone (no accumulation into Y)
 //   kernels/sparse_gemv.py:83       fp16 tl.atomic_add split-K  -> fp32 slabs + ordered reduce
+//
+// Design (DESIGN.md §3.1 has the long form):
+//   * One 16-wave workgroup = one column tile (LPR lanes x 8 columns = BN) x one slice of the kept rows.
+//   * Producer (MODE): the activation is loaded — or computed: residual + slabs -> RMSNorm, silu(gate)*up,
+//     split-KV attention merge — into registers, all loads in flight before the first use.
+//   * Mask + compaction, wave-local: a wave ballots its own 64-element chunks (fp32(|x|) > fp32(tau), strict;
+//     kernels/sparse_gemv.py:75) and writes the surviving (row:16 | x:16) pairs into its private LDS list
+//     (rank = mbcnt of the ballot).  No cross-wave scan, no barrier before the first weight load.  Fallback for
+//     vectors beyond the register cache: masks -> LDS, DPP prefix scan, one workgroup-wide list, even shares.
+//   * Stream: a wave walks its list 64/LPR rows at a time; a lane issues U independent non-temporal 16-byte
+//     (int8: 8-byte) loads, two batches in flight, fp32 accumulators; no LDS staging (a GEMV has no reuse).
+//   * Reduce: shuffle across the row groups of a wave, LDS across waves in fixed order; one rounding, or an
+//     fp32 slab per slice summed in slice order by the consumer.  No atomics: bit-reproducible.
+//   * HBM-bound skinny GEMV: no MFMA on purpose (north_star).
 #pragma once
 #include "teal_common.h"
 

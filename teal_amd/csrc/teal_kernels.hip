@@ -1,25 +1,15 @@
-// teal_kernels.hip — hand-written HIP kernels (gfx950 / CDNA4, wave64) for TEAL's
-// activation-sparsity decode hot path, behind the C ABI of include/teal_hip.h.
+// teal_kernels.hip — host side of libteal_hip.so: launch-geometry choice (pick_config / run_gemv), the C-ABI
+// entry points of the sparse GEMV (include/teal_hip.h), and the small kernels around it (ordered split-K
+// reduce, gate|up epilogue, standalone compaction).  gfx950 / CDNA4, wave64.
+//
+//   teal_gemv_kernel.h          the sparse GEMV kernel template (the hot kernel; design notes there)
+//   teal_gemv_w*_*.hip          its instantiations, one translation unit per (weight width, dtype)
+//   teal_attention.hip          decode attention + fused sampler and their entry points
 //
 // Replaces (reference tree FasterDecoding/TEAL @ 2024-10-22):
-//   kernels/sparse_gemv.py:50-83    splitk_sparse_gemv_kernel   -> sparse_gemv_kernel<>
-//   kernels/sparse_gemv.py:152-194  qkv_kernel                  -> sparse_gemv_kernel<> (3 segments)
-//   kernels/sparse_gemv.py:8-12     init_to_zero("Y") memset    -> gone (no accumulation into Y)
-//   kernels/sparse_gemv.py:83       fp16 tl.atomic_add split-K  -> fp32 slabs + ordered reduce
-//
-// Design (DESIGN.md has the long form):
-//   * One workgroup = one column tile (LPR lanes x 16 B = BN columns) x one even share of the
-//     kept-row list.  Each workgroup re-derives the kept list itself: a wave64 ballot per 64
-//     activations, a prefix sum over the ballot popcounts in LDS, then the (row, x) pairs of its
-//     share are scattered into an LDS list in ascending row order.  Because shares are cut from the
-//     compacted list (not from the raw Z range) every workgroup streams the same number of rows.
-//   * Main loop: each wave walks the LDS list RPW = 64/LPR rows at a time; a lane issues U
-//     independent 16-byte non-temporal loads (weights are read exactly once per token) before the
-//     first FMA, fp32 accumulators, no LDS staging of weights (GEMV has no reuse).
-//   * Reduction: shuffle across the RPW row groups of a wave, LDS across waves (fixed order),
-//     fp32 slab per K-slice, second tiny kernel sums slabs in slice order and rounds once.
-//     No atomics anywhere: bit-reproducible, and bf16 needs no special path.
-//   * HBM-bound skinny GEMV: no MFMA on purpose (north_star).
+//   kernels/sparse_gemv.py:87-142   splitk_sparse_gemv (host wrapper, autotune, grid)  -> run_gemv
+//   kernels/sparse_gemv.py:196-237  qkv_gemv                                           -> teal_sparse_qkv_gemv*
+//   kernels/sparse_gemv.py:8-12     init_to_zero("Y") pre-hook memset                  -> gone
 #include "teal_common.h"
 
 namespace teal {
