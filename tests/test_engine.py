@@ -294,14 +294,20 @@ def test_interleaved_slabs_equal_planar():
     assert torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
 
 
-@pytest.mark.parametrize("name,dtype,n_layer", [("7B", torch.float16, 2), ("llama-3-8b", torch.bfloat16, 1)])
-def test_engine_matches_module_path_full_width(name, dtype, n_layer):
+@pytest.mark.parametrize("name,dtype,n_layer,int8", [("7B", torch.float16, 2, False), ("llama-3-8b", torch.bfloat16, 1, False),
+                                                     ("7B", torch.float16, 2, True), ("llama-3-8b", torch.bfloat16, 1, True)])
+def test_engine_matches_module_path_full_width(name, dtype, n_layer, int8):
     """real layer widths (MHA 4096/11008 and GQA 4096/14336 with the 128k vocabulary), every row kept so
-    that no threshold can flip: fused engine vs unfused module path over a few tokens."""
+    that no threshold can flip: fused engine vs unfused module path over a few tokens — 16-bit and int8
+    weight-only weights (the int8 launch geometry differs: 128-column tiles, sliced wqkv, no PAIR)."""
     from teal_amd.gpt_fast import generate as G
     from teal_amd.gpt_fast.engine import DecodeEngine
+    from teal_amd.quantize import quantize_model_int8
     ref = G.build_synthetic_model(name, DEV, dtype, seed=5, n_layer=n_layer)
     eng_m = G.build_synthetic_model(name, DEV, dtype, seed=5, n_layer=n_layer)
+    if int8:
+        quantize_model_int8(ref)
+        quantize_model_int8(eng_m)
     ths = G.apply_sparsity(ref, sparsity=0.0, hist_path=None, greedy_lookup=None, synthetic=True)
     G.apply_sparsity(eng_m, sparsity=0.0, hist_path=None, greedy_lookup=None, synthetic=True)
     V = ref.config.vocab_size
@@ -318,7 +324,7 @@ def test_engine_matches_module_path_full_width(name, dtype, n_layer):
             a = ref(tok, pos).float().view(-1)
             b = eng(tok, pos).float().view(-1)
             scale = float(a.abs().max())
-            tol = (4e-3 if dtype == torch.float16 else 4e-2) * max(1.0, scale)
+            tol = (4e-3 if dtype == torch.float16 else 4e-2) * max(1.0, scale) * (2.0 if int8 else 1.0)
             assert float((a - b).abs().max()) <= tol, (step, float((a - b).abs().max()), scale)
             tok = a.argmax().view(1, 1).to(torch.int)
     del ref, eng_m, eng
