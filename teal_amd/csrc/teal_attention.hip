@@ -417,24 +417,30 @@ __device__ __forceinline__ uint32_t hash3(uint32_t a, uint32_t b, uint32_t c) {
     return h;
 }
 
-// sel[0] = the bin b (counted from the top) in which the `need`-th largest key falls, sel[1] = its rank
-// inside that bin.  hist[256] -> suffix counts by a Hillis-Steele scan (all threads must call this).
+// sel[0] = the bin b in which the `need`-th largest key falls, sel[1] = its rank inside that bin.  One wave does
+// it without workgroup barriers (lane l owns bins 4l..4l+3, suffix sums over lanes by shuffles): the Hillis-Steele
+// scan over 1024 threads it replaces cost 18 barriers per call, and barriers were most of this kernel's time.
+// All threads must call this; hist[] must be complete (barrier before), sel[] is valid after the trailing barrier.
 __device__ __forceinline__ void select_bin(const unsigned int* hist, unsigned int* suf, unsigned int* sel,
                                            const unsigned int need, const int tid) {
-    if (tid < 256) suf[tid] = hist[tid];
-    __syncthreads();
+    (void)suf;
+    if (tid < 64) {
+        const unsigned int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+        const unsigned int own = h0 + h1 + h2 + h3;
+        unsigned int incl = own;  // keys in this lane's bins and all higher lanes'
 #pragma unroll
-    for (int d = 1; d < 256; d <<= 1) {
-        const unsigned int v = (tid < 256 && tid + d < 256) ? suf[tid + d] : 0u;
-        __syncthreads();
-        if (tid < 256) suf[tid] += v;
-        __syncthreads();
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int t = (unsigned int)__shfl_down((int)incl, d);
+            if (tid + d < 64) incl += t;
+        }
+        // keys in strictly higher bins, for each of the four bins (highest first)
+        const unsigned int a3 = incl - own, a2 = a3 + h3, a1 = a2 + h2, a0 = a1 + h1;
+        if (a3 + h3 >= need && a3 < need) { sel[0] = 4u * tid + 3u; sel[1] = need - a3; }
+        if (a2 + h2 >= need && a2 < need) { sel[0] = 4u * tid + 2u; sel[1] = need - a2; }
+        if (a1 + h1 >= need && a1 < need) { sel[0] = 4u * tid + 1u; sel[1] = need - a1; }
+        if (a0 + h0 >= need && a0 < need) { sel[0] = 4u * tid; sel[1] = need - a0; }
+        if (tid == 0 && incl < need) { sel[0] = 0u; sel[1] = need; }  // fewer keys than requested: keep all
     }
-    if (tid < 256) {
-        const unsigned int above = tid < 255 ? suf[tid + 1] : 0u;  // keys in strictly higher bins
-        if (suf[tid] >= need && above < need) { sel[0] = (unsigned int)tid; sel[1] = need - above; }
-    }
-    if (tid == 0 && suf[0] < need) { sel[0] = 0u; sel[1] = need; }  // fewer keys than requested: keep all
     __syncthreads();
 }
 
