@@ -11,8 +11,12 @@
  *   teal_compact           <- kernels/sparse_gemv.py:75      idx = tl.abs(x0) > threshold
  *                             (exposed standalone so index sets can be tested bit-exactly)
  *   teal_dense_gemv        <- kernels/sparse_gemv.py:301-307 DenseGEMV / torch.matmul(x, W.T) at S == 1
- *   teal_sparse_gateup_silu, teal_rmsnorm, ...  (fusions either side of the path, SURVEY §8(f) rank 1;
- *                             gpt-fast/model.py:258-259,158-161,289-291)
+ *   teal_sparse_gateup_silu <- gpt-fast/model.py:258-259       silu(gemv1(x, w1)) * gemv1(x, w3)
+ *   teal_fused_gemv        <- gpt-fast/model.py:158-161,289-291 residual adds + RMSNorm, :258-259 silu * up,
+ *                             folded into the GEMV launch as producers
+ *   teal_decode_attention* <- gpt-fast/model.py:170-186       RoPE, kv_cache.update, SDPA at S == 1
+ *   teal_sample_topk       <- gpt-fast/generate.py:49-66      logits_to_probs + multinomial_sample_one
+ *   teal_sparse_qkv_gemv_i8 <- gpt-fast/quantize.py:339-357   WeightOnlyInt8Linear.forward on the masked x
  *
  * Conventions
  *   - extern "C", plain pointers and sizes, no C++/torch types, no exceptions across the boundary.
@@ -21,7 +25,7 @@
  *     device properties cached by teal_init()).
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Every call is
  *     asynchronous, allocation-free and hipGraph-capture safe.
- *   - dtype: 0 = fp16, 1 = bf16 (x, weights and y share it).
+ *   - dtype: 0 = fp16, 1 = bf16 (x, weights and y share it; int8 weights carry scales in that dtype).
  *   - Weight layout: the reference's "column major" weight[N, Z] with strides (1, N), i.e. the
  *     memory image is W^T row-major [Z][N]: element (m, n) at wT[m * N + n]
  *     (kernels/sparse_gemv.py:68,106).  N % 8 == 0 (16-byte rows), 1 <= Z <= 65536.
