@@ -240,3 +240,41 @@ def test_oracle_is_not_reachable_from_the_product_package():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, fn)).read()
                 assert "teal_oracle" not in src and "from oracle" not in src and "import oracle" not in src, fn
+
+
+@pytest.mark.parametrize("tag,dt", [("f16", torch.float16), ("bf16", torch.bfloat16)])
+def test_int8_quantiser_module_match_reference_fixture(golden_dir, tag, dt):
+    """teal_amd.quantize (host logic, CPU): same codes / scales as the reference quantiser and the same dense
+    forward as its WeightOnlyInt8Linear on the captured inputs (tests/golden/kat_int8.npz, F8)."""
+    import os
+    from teal_amd.quantize import WeightOnlyInt8Linear, is_int8, quantize_model_int8, quantize_per_channel
+    k = np.load(os.path.join(golden_dir, "kat_int8.npz"))
+    w = torch.from_numpy(k[f"{tag}_w"].view(np.int16).copy()).view(dt)
+    q, s = quantize_per_channel(w)
+    assert np.array_equal(q.numpy(), k[f"{tag}_q"])
+    assert np.array_equal(s.numpy().view(np.uint32), k[f"{tag}_scales_f32"].view(np.uint32))
+    lin = torch.nn.Linear(w.shape[1], w.shape[0], bias=False, dtype=dt)
+    lin.weight.data = w
+    m = WeightOnlyInt8Linear.from_linear(lin)
+    assert np.array_equal(m.scales.view(torch.int16).numpy().view(np.uint16), k[f"{tag}_scales"])
+    x = torch.from_numpy(k[f"{tag}_x"].view(np.int16).copy()).view(dt).view(1, 1, -1)
+    y = m(x).view(-1)
+    want = torch.from_numpy(k[f"{tag}_y_dense"].view(np.int16).copy()).view(dt)
+    assert torch.equal(y, want)  # same torch ops as the reference module on the same CPU
+    # quantize_model_int8 swaps every Linear (projections and lm_head), nothing else
+    box = torch.nn.Sequential(torch.nn.Linear(16, 8, bias=False, dtype=dt), torch.nn.LayerNorm(8), torch.nn.Linear(8, 24, bias=False, dtype=dt))
+    quantize_model_int8(box)
+    assert is_int8(box[0]) and is_int8(box[2]) and isinstance(box[1], torch.nn.LayerNorm)
+    assert box[0].weight.dtype == torch.int8 and box[0].scales.dtype == dt
+
+
+def test_to_column_major_int8_pads_128_bytes():
+    from teal_amd.monkeypatch import to_column_major
+    from teal_amd.quantize import WeightOnlyInt8Linear
+    lin = torch.nn.Linear(64, 40, bias=False, dtype=torch.float16)
+    m = WeightOnlyInt8Linear.from_linear(lin)
+    before = m.weight.clone()
+    to_column_major(m)
+    assert m.weight.shape == (40, 64) and m.weight.stride() == (1, 40 + 128) and torch.equal(m.weight, before)
+    to_column_major(lin)
+    assert lin.weight.stride() == (1, 40 + 64)
