@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Phase stamps of the fused sampler (register-resident window-select kernel; teal_set_phase_buffer).
+Benchmark utility (GPU box)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from teal_amd import _lib, runtime  # noqa: E402
+
+L = _lib.load()
+runtime.init()
+names = ["load + keys + max", "window select", "race over kept", "final reduce"]
+for V, dt, code in ((32000, torch.float16, 0), (128256, torch.bfloat16, 1)):
+    g = torch.Generator(device="cuda").manual_seed(1)
+    state = torch.tensor([1234, 0], dtype=torch.int64, device="cuda")
+    tok = torch.zeros(1, dtype=torch.int32, device="cuda")
+    phase = torch.zeros(64, dtype=torch.int64, device="cuda")
+    rows = []
+    for it in range(12):
+        logits = (torch.randn(V, device="cuda", generator=g) * 2.5).to(dt)  # fresh logits: cold in L2 like after lm_head
+        torch.cuda.synchronize()
+        L.teal_set_phase_buffer(phase.data_ptr())
+        assert L.teal_sample_topk(logits.data_ptr(), V, code, 200, 0.8, state.data_ptr(), tok.data_ptr(), None, None, 0, runtime.stream_ptr()) == 0
+        torch.cuda.synchronize()
+        L.teal_set_phase_buffer(None)
+        p = phase[:5].cpu().double() * 10.0 / 1e3
+        rows.append([(p[i + 1] - p[i]).item() for i in range(4)])
+    med = torch.tensor(rows[2:]).median(dim=0).values.tolist()
+    print(f"V={V}: total {sum(med):.2f} us")
+    for n, v in zip(names, med):
+        print(f"    {n:28s} {v:6.2f} us")

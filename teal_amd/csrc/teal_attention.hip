@@ -573,6 +573,179 @@ __global__ __launch_bounds__(1024) void sample_topk_kernel(const uint16_t* __res
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Register-resident sampler for vocab % 8 == 0, vocab <= NV * 8192 (Llama-2: NV = 4, Llama-3: NV = 16).
+// Phase stamps of the generic kernel above (scripts/sampler_phase.py): its time is the high-byte histogram
+// pass — every key does an LDS atomic, and bf16 logits fall into 4-5 of the 256 high-byte bins (sign + 7
+// exponent bits), so the atomics serialise: 45 of 72 us at vocab 128256 — plus dependent global loads in
+// every pass and in the last thread's epilogue.  Here:
+//   * every thread loads its NV vectors ONCE and keeps the order-preserving keys in registers;
+//   * the k-th largest key is found in a WINDOW below the maximum: bin = (kmax - key) >> SH for the keys
+//     within 256 << SH of kmax, everything further away does no atomic at all.  The top-k of a peaked
+//     distribution sits within ~2 octaves of the maximum (SH = 0 for bf16, 3 for fp16), i.e. a few per cent of
+//     the vocabulary, spread over 256 bins.  If the window holds fewer than k keys it is widened (SH += 3, up
+//     to 8 where it covers every key) and the pass repeated; a bin wider than one key is resolved by a second
+//     histogram of the low SH bits of its (few) members.  Exact: same pivot, ties kept, same tokens as the
+//     generic kernel (tests/test_engine.py).
+// ------------------------------------------------------------------------------------------------
+template <bool BF16, int NV>
+__global__ __launch_bounds__(1024) void sample_topk_window_kernel(const uint16_t* __restrict__ logits, const int V,
+                                                                   const int top_k, const float inv_temp,
+                                                                   unsigned long long* __restrict__ rng_state,
+                                                                   int* __restrict__ token_out, int* __restrict__ pos_inout,
+                                                                   int* __restrict__ history, const int history_len,
+                                                                   unsigned long long* __restrict__ phase) {
+    auto stamp_s = [&](const int i) { if (phase && threadIdx.x == 0) phase[i] = wall_clock64(); };
+    stamp_s(0);
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned int whist[16][256];
+    __shared__ float fred[16];
+    __shared__ int ired[16];
+    __shared__ unsigned int sel[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool filter = top_k > 0 && top_k < V;
+    const int V8 = V >> 3;
+    const u32x4* lv = reinterpret_cast<const u32x4*>(logits);
+    u32x4 kv[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) kv[v] = lv[min(v * 1024 + tid, V8 - 1)];
+    // everything the epilogue needs from memory is requested now, not by the last thread at the very end
+    const unsigned long long seed64 = rng_state[0], ctr64 = rng_state[1];
+    const int pos0 = pos_inout ? pos_inout[0] : 0;
+    for (int i = tid; i < 16 * 256; i += 1024) (&whist[0][0])[i] = 0;
+    uint32_t kmax = 0u;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const bool ok = v * 1024 + tid < V8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t k0 = order_key16(kv[v][j] & 0xFFFFu, BF16), k1 = order_key16(kv[v][j] >> 16, BF16);
+            kv[v][j] = ok ? (k0 | (k1 << 16)) : 0u;  // vectors past the vocabulary: key 0, never considered (index check)
+            kmax = ok ? max(kmax, max(k0, k1)) : kmax;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d));
+    if (lane == 0) ired[wave] = (int)kmax;
+    __syncthreads();
+    kmax = (uint32_t)ired[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) kmax = max(kmax, (uint32_t)ired[w]);
+    auto key_bits = [](const uint32_t k) -> uint32_t { return (k & 0x8000u) ? (k ^ 0x8000u) : (~k & 0xFFFFu); };  // order_key16^-1
+    const float mx = bits_to_float(key_bits(kmax), BF16);
+    stamp_s(1);
+    auto merge_hist = [&]() {  // whist[16][256] -> hist[256]; barriers on both sides
+        __syncthreads();
+        if (tid < 256) {
+            unsigned int a = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) a += whist[w][tid];
+            hist[tid] = a;
+        }
+        __syncthreads();
+    };
+    uint32_t pivot_key = 0u;  // keep keys >= pivot_key
+    if (filter) {
+        for (int sh = BF16 ? 0 : 3;; sh += 3) {
+            if (sh > 8) sh = 8;  // 256 << 8 covers every key
+            // window pass: bin 255 = kmax, bin 255 - d = keys (d << sh) .. below it
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (v * 1024 + tid < V8) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t d0 = (kmax - (kv[v][j] & 0xFFFFu)) >> sh, d1 = (kmax - (kv[v][j] >> 16)) >> sh;
+                        if (d0 < 256u) atomicAdd(&whist[wave][255u - d0], 1u);
+                        if (d1 < 256u) atomicAdd(&whist[wave][255u - d1], 1u);
+                    }
+                }
+            }
+            merge_hist();
+            unsigned int inwin = 0;  // keys inside the window (workgroup-uniform)
+            {
+                unsigned int a = (tid < 256) ? hist[tid] : 0u;
+                a = (unsigned int)wave_sum_f((float)a);  // <= 131072: exact in fp32
+                if (lane == 0) fred[wave] = (float)a;
+                __syncthreads();
+                inwin = (unsigned int)(fred[0] + fred[1] + fred[2] + fred[3]);
+            }
+            if (inwin >= (unsigned int)top_k || sh == 8) {
+                select_bin(hist, nullptr, sel, (unsigned int)top_k, tid);
+                const unsigned int d = 255u - sel[0], need2 = sel[1];
+                __syncthreads();
+                if (sh == 0) {
+                    pivot_key = kmax - d;
+                } else {
+                    // resolve the bin: histogram of the low `sh` bits of its members (bin 255 = largest key)
+                    for (int i = tid; i < 16 * 256; i += 1024) (&whist[0][0])[i] = 0;
+                    __syncthreads();
+                    const uint32_t lowmask = (1u << sh) - 1u;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        if (v * 1024 + tid < V8) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const uint32_t e0 = kmax - (kv[v][j] & 0xFFFFu), e1 = kmax - (kv[v][j] >> 16);
+                                if ((e0 >> sh) == d) atomicAdd(&whist[wave][255u - (e0 & lowmask)], 1u);
+                                if ((e1 >> sh) == d) atomicAdd(&whist[wave][255u - (e1 & lowmask)], 1u);
+                            }
+                        }
+                    }
+                    merge_hist();
+                    select_bin(hist, nullptr, sel, need2, tid);
+                    pivot_key = kmax - ((d << sh) | (255u - sel[0]));
+                    __syncthreads();
+                }
+                break;
+            }
+            for (int i = tid; i < 16 * 256; i += 1024) (&whist[0][0])[i] = 0;  // widen the window and count again
+            __syncthreads();
+        }
+    }
+    stamp_s(2);
+    // exponential race over the kept set (see sample_topk_kernel)
+    const uint32_t seed = (uint32_t)seed64, ctr = (uint32_t)ctr64;
+    float best = -1.0f;
+    int besti = 0x7FFFFFFF;
+    auto consider = [&](const uint32_t key, const int i) {
+        if (key < pivot_key) return;
+        const float pnum = expf((bits_to_float(key_bits(key), BF16) - mx) * inv_temp);
+        const float u = ((float)(hash3(seed, ctr, (uint32_t)i) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float scv = pnum / (-logf(u));
+        if (scv > best || (scv == best && i < besti)) { best = scv; besti = i; }
+    };
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int i = v * 1024 + tid;
+        if (i < V8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                consider(kv[v][j] & 0xFFFFu, i * 8 + 2 * j);
+                consider(kv[v][j] >> 16, i * 8 + 2 * j + 1);
+            }
+        }
+    }
+    stamp_s(3);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float ob = __shfl_xor(best, d);
+        const int oi = __shfl_xor(besti, d);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    __syncthreads();
+    if (lane == 0) { fred[wave] = best; ired[wave] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (fred[w] > best || (fred[w] == best && ired[w] < besti)) { best = fred[w]; besti = ired[w]; }
+        token_out[0] = besti;
+        if (history && (long long)ctr64 < (long long)history_len) history[ctr64] = besti;
+        rng_state[1] = ctr64 + 1ull;
+        if (pos_inout) pos_inout[0] = pos0 + 1;
+    }
+    stamp_s(4);
+}
+
 }  // namespace teal
 
 using namespace teal;
@@ -682,10 +855,18 @@ int teal_sample_topk(const void* logits, int vocab, int dtype, int top_k, float 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     auto* lg = reinterpret_cast<const uint16_t*>(logits);
     auto* rs = reinterpret_cast<unsigned long long*>(rng_state);
-    if (dtype == TEAL_BF16)
-        hipLaunchKernelGGL((sample_topk_kernel<true>), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len);
-    else
-        hipLaunchKernelGGL((sample_topk_kernel<false>), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len);
+#define TEAL_SAMPLE(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len)
+#define TEAL_SAMPLE_W(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len, g_phase)
+    const bool bf = dtype == TEAL_BF16;
+    if ((vocab & 7) == 0 && vocab <= 4 * 8192) {  // register-resident keys, window select: 4 vectors per thread
+        if (bf) TEAL_SAMPLE_W((sample_topk_window_kernel<true, 4>)); else TEAL_SAMPLE_W((sample_topk_window_kernel<false, 4>));
+    } else if ((vocab & 7) == 0 && vocab <= 16 * 8192) {  // 16 vectors per thread (Llama-3's 128256)
+        if (bf) TEAL_SAMPLE_W((sample_topk_window_kernel<true, 16>)); else TEAL_SAMPLE_W((sample_topk_window_kernel<false, 16>));
+    } else {  // any size: two full radix passes over memory
+        if (bf) TEAL_SAMPLE((sample_topk_kernel<true>)); else TEAL_SAMPLE((sample_topk_kernel<false>));
+    }
+#undef TEAL_SAMPLE
+#undef TEAL_SAMPLE_W
     return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
 }
 

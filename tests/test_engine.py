@@ -488,3 +488,47 @@ def test_attention_from_qkv_slabs_equals_rounded_qkv(dtype, nslabs):
     assert L.teal_decode_attention_split_slabs(slabs.data_ptr(), 9, rope.data_ptr(), p.data_ptr(), kc2.data_ptr(), vc2.data_ptr(),
                                                None, None, 0.0, n_head, n_kv, hd, S, nsplit, ws_b.data_ptr(), ws_b.numel() * 4,
                                                code, st) < 0
+
+
+@pytest.mark.parametrize("dtype,V,law", [(torch.float16, 32000, "normal"), (torch.bfloat16, 128256, "normal"), (torch.float16, 50304, "normal"),
+                                         (torch.bfloat16, 4096, "normal"), (torch.float16, 32000, "flat"), (torch.bfloat16, 32000, "flat"),
+                                         (torch.float16, 32000, "spike")])
+def test_sampler_window_and_radix_kernels_pick_the_same_tokens(dtype, V, law):
+    """vocab % 8 == 0 runs the register-resident window-select kernel, V + 4 (logit -inf appended) the generic radix
+    kernel: same pivot, same kept set, same counter-based random numbers -> identical tokens.  `flat` (uniform over
+    +-100, large k) forces the window to widen; `spike` has one dominant logit; ties at the pivot are kept."""
+    from teal_amd import _lib, runtime
+    L = _lib.load()
+    runtime.init()
+    code = runtime.dtype_code(dtype)
+    g = torch.Generator(device=DEV).manual_seed(V)
+    if law == "normal":
+        base = (torch.randn(V, device=DEV, generator=g) * 3).to(dtype)
+        base[100:140] = base.float().max().to(dtype)          # a tie at the top: top_k = 20 must keep all of it
+    elif law == "flat":
+        base = ((torch.rand(V, device=DEV, generator=g) - 0.5) * 200).to(dtype)
+    else:
+        base = (torch.randn(V, device=DEV, generator=g) * 0.01).to(dtype)
+        base[777] = 60.0
+    padded = torch.cat([base, torch.full((4,), float("-inf"), device=DEV, dtype=dtype)])
+    tok = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for top_k, temp in ((200, 0.8), (20, 1.0), (1, 1.0), (0, 1.0), (5000, 2.0), (V - 1, 1.5)):
+        outs = []
+        for logits, n in ((base, V), (padded, V + 4)):
+            state = torch.tensor([1234, 0], dtype=torch.int64, device=DEV)
+            pos = torch.tensor([11], dtype=torch.int32, device=DEV)
+            hist = torch.full((64,), -1, dtype=torch.int32, device=DEV)
+            seq = []
+            for _ in range(24):
+                assert L.teal_sample_topk(logits.data_ptr(), n, code, top_k, temp, state.data_ptr(), tok.data_ptr(), pos.data_ptr(),
+                                          hist.data_ptr(), 64, runtime.stream_ptr()) == 0
+                seq.append(int(tok.item()))
+            assert int(state[1]) == 24 and int(pos[0]) == 11 + 24 and hist[:24].tolist() == seq
+            outs.append(seq)
+        assert outs[0] == outs[1], (top_k, outs[0][:8], outs[1][:8])
+        assert max(outs[0]) < V
+        if top_k == 20 and law == "normal":
+            tied = set(torch.nonzero(base == base.float().max().to(dtype)).view(-1).tolist())
+            assert len(tied) >= 40 and set(outs[0]) <= tied and len(set(outs[0])) > 10
+        if law == "spike" and top_k in (1, 20, 200):
+            assert set(outs[0]) == {777}
