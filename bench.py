@@ -209,7 +209,6 @@ def roofline_engine_gateup(eng, a):
     w1/w3 and thresholds (2.9 GB of distinct weights >> 256 MB Infinity Cache), timed with HIP events
     on the launch stream.  Algorithmic bytes: kept rows of both matrices + the producer's inputs
     (residual, slabs, norm weight) + the gate|up output."""
-    import torch.nn.functional as F
     from teal_amd import runtime
     from teal_amd.gpt_fast.engine import GemvIn, TEAL_IN_RESID_NORM
     m, cfg = eng.model, eng.cfg

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Phase timing of the fused engine launches (RESID_NORM / SILU_MUL producers) on 7B shapes.
 Benchmark utility (GPU box)."""
-import ctypes
 import os
 import sys
 

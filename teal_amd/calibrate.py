@@ -24,7 +24,7 @@ import argparse
 import csv
 import os
 from copy import deepcopy
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 import torch.nn.functional as F

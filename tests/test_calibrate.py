@@ -1,7 +1,6 @@
 """Calibration producers: histogram builder pinned against the reference's own
 ActivationModule.find_histogram (fixture F7), file formats, and the greedy optimiser's behaviour."""
 import csv
-import os
 
 import numpy as np
 import torch

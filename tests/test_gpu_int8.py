@@ -1,7 +1,6 @@
 """GPU: int8 weight-only sparse GEMV against the oracle's double-precision truth, the
 reference module's output captured in tests/golden/kat_int8.npz, and — for the fused decode engine — against the
 unfused int8 module path."""
-import ctypes
 import os
 
 import numpy as np
