@@ -104,10 +104,16 @@ def main():
             assert rc == 0
 
         ms = graph_times(sparse, 32, 9)
+
+        def sparse_resident(i, tau=tau):  # the SAME 33-117 MB matrix every launch: served by the 256 MB Infinity Cache
+            sparse(0, tau)
+
+        ms_res = graph_times(sparse_resident, 32, 9)
         algo = nnz * N * 2 + Z * 2 + N * 2
         row = {"sparsity_level": s_, "nnz": nnz, "TEAL_HIP": ms[0], "TEAL_HIP_min": ms[1], "TEAL_HIP_max": ms[2],
                "Dense": d_ms[0], "Dense_min": d_ms[1], "Dense_max": d_ms[2], "Theoretical Optimal": d_ms[0] * (1 - s_),
-               "TEAL_HIP_GBps": algo / (ms[0] * 1e-3) / 1e9, "speedup_vs_dense": d_ms[0] / ms[0]}
+               "TEAL_HIP_GBps": algo / (ms[0] * 1e-3) / 1e9, "speedup_vs_dense": d_ms[0] / ms[0],
+               "TEAL_HIP_cache_resident": ms_res[0]}  # labelled: NOT an HBM number
         if O is not None and abs(s_ * 20 - round(s_ * 20)) < 1e-9 and s_ in (0.0, 0.25, 0.5, 0.75):
             O.fast_sparse_gemv(xb_host, wb_host, tau, Z, N, 0)
             t0 = time.perf_counter()
@@ -117,7 +123,7 @@ def main():
             row["CPU_threads"] = O.num_threads()
         rows.append(row)
         print(f"s={s_:.2f} nnz={nnz:5d}  hip {ms[0]*1e3:7.2f} us ({row['TEAL_HIP_GBps']:7.1f} GB/s)  dense {d_ms[0]*1e3:7.2f} us  "
-              f"speed-up {row['speedup_vs_dense']:.2f}x" + (f"  cpu {row['CPU_port_ms']:.2f} ms" if "CPU_port_ms" in row else ""))
+              f"speed-up {row['speedup_vs_dense']:.2f}x  [cache-resident {ms_res[0]*1e3:6.2f} us]" + (f"  cpu {row['CPU_port_ms']:.2f} ms" if "CPU_port_ms" in row else ""))
     path = os.path.join(a.out, f"Kernel Plot (MI355X) ({Z}x{N}).csv")
     keys = sorted({k for r in rows for k in r}, key=lambda k: (k != "sparsity_level", k))
     with open(path, "w", newline="") as f:
