@@ -373,25 +373,27 @@ def test_decode_attention_split_long_context(dtype):
         assert torch.equal(bits, got)
 
 
-def test_engine_long_context_uses_split_attention():
+@pytest.mark.parametrize("block,plen,fused", [(4096, 3000, True), (8192, 5000, False)])
+def test_engine_long_context_uses_split_attention(block, plen, fused):
+    """8 split-KV partials merged by the wo launch up to 4096 positions; 16 + the merge launch beyond."""
     from teal_amd.gpt_fast import generate as G
     from teal_amd.gpt_fast.engine import DecodeEngine
     ref = G.build_synthetic_model("tiny-test", DEV, torch.float16, seed=3, std=0.05)
     eng_m = G.build_synthetic_model("tiny-test", DEV, torch.float16, seed=3, std=0.05)
     for m in (ref, eng_m):
-        m.config.block_size = 4096
+        m.config.block_size = block
     ths = G.apply_sparsity(ref, sparsity=0.0, hist_path=None, greedy_lookup=None, synthetic=True)
     G.apply_sparsity(eng_m, sparsity=0.0, hist_path=None, greedy_lookup=None, synthetic=True)
-    prompt = torch.randint(0, 512, (3000,), device=DEV, dtype=torch.int, generator=torch.Generator(device=DEV).manual_seed(4))
+    prompt = torch.randint(0, 512, (plen,), device=DEV, dtype=torch.int, generator=torch.Generator(device=DEV).manual_seed(4))
     with torch.no_grad():
         for m in (ref, eng_m):
             m.max_seq_length = -1
-            m.setup_caches(1, 4096)
-            m(prompt.view(1, -1), torch.arange(3000, device=DEV))
+            m.setup_caches(1, block)
+            m(prompt.view(1, -1), torch.arange(plen, device=DEV))
         eng = DecodeEngine(eng_m, ths)
-        assert eng.att_split >= 2
+        assert eng.att_split >= 2 and eng.att_fused_merge == fused
         tok = torch.tensor([[7]], device=DEV, dtype=torch.int)
-        pos = torch.tensor([3000], device=DEV, dtype=torch.int)
+        pos = torch.tensor([plen], device=DEV, dtype=torch.int)
         a, b = ref(tok, pos).float().view(-1), eng(tok, pos).float().view(-1)
         assert torch.allclose(a, b, atol=8e-3, rtol=8e-3), float((a - b).abs().max())
 
