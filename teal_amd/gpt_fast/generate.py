@@ -247,6 +247,39 @@ class GraphedDecoder:
         return self._step()
 
 
+class GraphedPrefill:
+    """`--compile_prefill` (gpt-fast/generate.py:423-425, 540): the prompt pass captured into a hipGraph per prompt
+    length (the reference compiles `prefill` with Inductor).  Static token / position buffers, kept alive with the
+    graph; the model's KV caches must not be re-allocated between capture and replay (setup_caches keeps them
+    when the sizes are unchanged; a new cache object gets a new graph)."""
+
+    def __init__(self, model: Transformer):
+        self.model = model
+        self.graphs = {}
+
+    def __call__(self, prompt: torch.Tensor) -> torch.Tensor:
+        T = prompt.numel()
+        key = (T, self.model.max_seq_length, id(self.model.layers[0].attention.kv_cache))
+        if key not in self.graphs:
+            dev = prompt.device
+            toks = torch.zeros(1, T, dtype=torch.int, device=dev)
+            pos = torch.arange(0, T, device=dev)
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                toks.copy_(prompt.view(1, -1))
+                self.model(toks, pos)  # warm-up outside capture (allocator pools, GEMM heuristics)
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                logits = self.model(toks, pos)
+            self.graphs[key] = (g, toks, pos, logits)  # every tensor the graph reads or writes stays alive
+        g, toks, _pos, logits = self.graphs[key]
+        toks.copy_(prompt.view(1, -1))
+        g.replay()
+        return logits
+
+
 class EngineDecoder:
     """GraphedDecoder's role for the fused HIP engine: built lazily once the KV caches exist."""
 
@@ -265,7 +298,7 @@ class EngineDecoder:
 
 @torch.no_grad()
 def generate(model: Transformer, prompt: torch.Tensor, max_new_tokens: int, decoder: GraphedDecoder,
-             temperature: float = 0.8, top_k: Optional[int] = 200) -> torch.Tensor:
+             temperature: float = 0.8, top_k: Optional[int] = 200, prefill: Optional[GraphedPrefill] = None) -> torch.Tensor:
     """prefill (seq > 1: ops fall back to dense matmul) then max_new_tokens-1 decode steps."""
     T = prompt.size(0)
     T_new = T + max_new_tokens
@@ -273,7 +306,7 @@ def generate(model: Transformer, prompt: torch.Tensor, max_new_tokens: int, deco
     model.setup_caches(max_batch_size=1, max_seq_length=min(T_new, model.config.block_size))
     seq = torch.empty(T_new, dtype=prompt.dtype, device=dev)
     seq[:T] = prompt
-    logits = model(prompt.view(1, -1), torch.arange(0, T, device=dev))
+    logits = prefill(prompt) if prefill is not None else model(prompt.view(1, -1), torch.arange(0, T, device=dev))
     next_token = sample(logits, temperature=temperature, top_k=top_k)[0].clone()
     seq[T] = next_token
     if hasattr(decoder.model, "decode_n"):  # HIP engine: the whole loop stays on the device
@@ -326,6 +359,7 @@ def main(args) -> Dict:
     if use_engine:
         assert thresholds is not None, "--engine needs thresholds (--hist_path or --synthetic)"
         decoder = EngineDecoder(model, thresholds, args.compile, args.temperature, args.top_k)
+    prefill = GraphedPrefill(model) if getattr(args, "compile_prefill", False) else None
     tps = []
     start = -1 if args.compile else 0
     for i in range(start, args.num_samples):
@@ -335,7 +369,8 @@ def main(args) -> Dict:
             prof = torch.profiler.profile()
         t0 = time.perf_counter()
         with prof:
-            y = generate(model, prompt, args.max_new_tokens, decoder, temperature=args.temperature, top_k=args.top_k)
+            y = generate(model, prompt, args.max_new_tokens, decoder, temperature=args.temperature, top_k=args.top_k,
+                         prefill=prefill)
         torch.cuda.synchronize()
         t = time.perf_counter() - t0
         if i == -1:
@@ -367,6 +402,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--temperature", type=float, default=0.8)
     p.add_argument("--checkpoint_path", type=Path, default=Path("checkpoints/meta-llama/Llama-2-7b-chat-hf/model.pth"))
     p.add_argument("--compile", action="store_true", help="capture the decode step into a hipGraph")
+    p.add_argument("--compile_prefill", action="store_true", help="capture the prompt pass into a hipGraph too "
+                   "(the reference's flag of the same name, generate.py:540)")
     p.add_argument("--profile", type=Path, default=None)
     p.add_argument("--device", type=str, default=default_device)
     # monkeypatch (reference flags)

@@ -142,7 +142,8 @@ def test_sparse_thresholds_reduce_rows_read():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [["--engine"], [], ["--no_engine"], ["--precision", "bf16"], ["--engine", "--sparsity", "0.0"]])
+@pytest.mark.parametrize("extra", [["--engine"], [], ["--no_engine"], ["--precision", "bf16"], ["--engine", "--sparsity", "0.0"],
+                                   ["--compile_prefill"]])
 def test_generate_main_synthetic_cli(extra):
     """the reference-shaped CLI end to end on a tiny synthetic model: load -> monkeypatch -> capture ->
     timed samples, through the fused engine and through the module path."""
@@ -166,3 +167,25 @@ def test_generate_greedy_fixture_table():
     assert len({ths[0]["q"], ths[0]["k"], ths[0]["v"]}) == 3 and ths[0]["gate"] != ths[0]["up"]
     at = m.layers[0].attention
     assert (at.thresh_q, at.thresh_k, at.thresh_v) == (ths[0]["q"], ths[0]["k"], ths[0]["v"])
+
+
+@pytest.mark.gpu
+def test_graphed_prefill_equals_eager_prefill():
+    """--compile_prefill: the captured prompt pass returns the same logits and fills the same KV cache."""
+    m = G.build_synthetic_model("tiny-test", "cuda", torch.float16, seed=3, std=0.05)
+    G.apply_sparsity(m, sparsity=0.5, hist_path=None, greedy_lookup=None, synthetic=True)
+    m.max_seq_length = -1
+    m.setup_caches(1, 64)
+    pre = G.GraphedPrefill(m)
+    for seed, T in ((1, 6), (2, 6), (3, 11)):
+        prompt = torch.randint(0, 512, (T,), device="cuda", dtype=torch.int, generator=torch.Generator(device="cuda").manual_seed(seed))
+        with torch.no_grad():
+            want = m(prompt.view(1, -1), torch.arange(T, device="cuda")).clone()
+            kc = m.layers[0].attention.kv_cache.k_cache.clone()
+            m.layers[0].attention.kv_cache.k_cache.zero_()
+            got = pre(prompt)
+            junk = [torch.randn(4096, device="cuda") for _ in range(8)]  # allocator churn: the graph's inputs must survive it
+            torch.cuda.synchronize()
+        assert torch.equal(got, want) and len(junk) == 8
+        assert torch.equal(m.layers[0].attention.kv_cache.k_cache[:, :, :T], kc[:, :, :T])
+    assert len(pre.graphs) == 2  # one graph per prompt length
