@@ -206,7 +206,26 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
     int total_cols = 0;
     for (int i = 0; i < p.nseg; ++i) total_cols += p.seg[i].ncols;
     Config c = pick_config(p.Z, total_cols, p.nseg);
-    if (few_slabs && c.split > 1 && !g_override.split && !g_override.lpr) {
+    bool wide_sliced = false;
+    if (few_slabs && to_ws && p.Z >= 8192 && !p.w8 && !p.pair && !g_override.split && !g_override.lpr) {
+        // slab output with long vectors (70B-class widths): 128-column tiles (256-byte row segments) with the
+        // kept rows sliced so that tiles x slices ~ the CU count — fewer, longer row requests per CU.  Measured
+        // +2-8 % on the 8192-wide launches; at Z = 4096 the extra slices cost more in the consumers' prologues
+        // than they save (7B: 529 -> 517 tok/s), hence the width gate.
+        const int ncu = g_num_cu > 0 ? g_num_cu : 256;
+        const int tiles = (total_cols + 127) / 128;
+        const int rounds = (((p.Z + 63) >> 6) + 15) / 16;
+        int split = ncu / tiles;
+        if (split > rounds) split = rounds;
+        if (split > 8) split = 8;
+        if (split < 1) split = 1;
+        if (tiles * split * 10 >= ncu * 7 && (size_t)((p.Z + split - 1) / split) * 4 <= 40 * 1024) {
+            c.lpr = 16;
+            c.split = split;
+            wide_sliced = true;
+        }
+    }
+    if (!wide_sliced && few_slabs && c.split > 1 && !g_override.split && !g_override.lpr) {
         // the consumer re-reads every slab in each of its workgroups: prefer narrow tiles and a
         // shallow split (64-column tiles, <= 8 slabs) over 512-byte row segments
         const int ncu = g_num_cu > 0 ? g_num_cu : 256;
