@@ -207,11 +207,12 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
     for (int i = 0; i < p.nseg; ++i) total_cols += p.seg[i].ncols;
     Config c = pick_config(p.Z, total_cols, p.nseg);
     bool wide_sliced = false;
-    if (few_slabs && to_ws && p.Z >= 8192 && !p.w8 && !p.pair && !g_override.split && !g_override.lpr) {
-        // slab output with long vectors (70B-class widths): 128-column tiles (256-byte row segments) with the
-        // kept rows sliced so that tiles x slices ~ the CU count — fewer, longer row requests per CU.  Measured
-        // +2-8 % on the 8192-wide launches; at Z = 4096 the extra slices cost more in the consumers' prologues
-        // than they save (7B: 529 -> 517 tok/s), hence the width gate.
+    if (few_slabs && to_ws && (size_t)p.Z * total_cols >= (size_t)8192 * 8192 && !p.w8 && !p.pair && !g_override.split &&
+        !g_override.lpr) {
+        // slab output of a 70B-class matrix (>= 8192 x 8192): 128-column tiles (256-byte row segments) with the kept
+        // rows sliced so that tiles x slices ~ the CU count — fewer, longer row requests per CU.  Measured +2-8 % on
+        // those launches; on 7B / 8B matrices the extra slices cost more in the consumers' prologues than they save
+        // (7B: 529 -> 518 tok/s), hence the size gate.
         const int ncu = g_num_cu > 0 ? g_num_cu : 256;
         const int tiles = (total_cols + 127) / 128;
         const int rounds = (((p.Z + 63) >> 6) + 15) / 16;
