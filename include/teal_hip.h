@@ -233,6 +233,9 @@ int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll);
  * of a workgroup-wide list; removes every barrier between the activation and the first weight load. */
 int teal_set_wave_local(int on);
 
+/* Lean kernel for qualifying shapes (default on; 0 forces the general kernel everywhere: A/B and parity tests). */
+int teal_set_fast(int on);
+
 /* Column-tile XOR swizzle that spreads every XCD over all DRAM channel residues (default on). */
 int teal_set_swizzle(int on);
 
@@ -241,6 +244,9 @@ int teal_set_swizzle(int on);
  * workgroup stores 100 MHz wall-clock stamps of its phases (0 start, 1 ballots, 2 scatter,
  * 3 list ready, 4 rows streamed, 5 done).  NULL (default) disables.  Process-global. */
 int teal_set_phase_buffer(void* dev_u64);
+/* > 0: consecutive GEMV launches stamp consecutive regions of `u64_per_launch` uint64 of the phase buffer (so that a
+ * chain of launches can be timed against each other); 0 (default): every launch stamps the start of the buffer. */
+int teal_set_phase_stride(size_t u64_per_launch);
 
 /* The geometry a GEMV of this shape would use: out[0..5) = {lanes_per_row, waves, split, unroll,
  * workgroups}. */

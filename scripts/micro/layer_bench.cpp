@@ -1,0 +1,480 @@
+// layer_bench — the fused decode step of teal_amd/gpt_fast/engine.py driven straight through the C ABI (no Python, no
+// torch: starts in a second on a fresh GPU box), for kernel experiments on MI355X.  Benchmark utility, not product code.
+//
+//   hipcc --offload-arch=gfx950 -O2 -std=c++17 -I include scripts/micro/layer_bench.cpp -L teal_amd -lteal_hip \
+//         -Wl,-rpath,'$ORIGIN/../../teal_amd' -o scripts/micro/layer_bench
+//   layer_bench [--layers 32] [--steps 100] [--sparsity 0.5] [--model 7b|8b|70b] [--phase] [--dense] [--pos 64]
+//               [--tune stage:lpr:waves:split:unroll,...]   (stage = qkv|wo|gu|down|head|all)
+//
+// One token = per layer {qkv, attention, wo, gate|up, down} + lm_head + sampler, captured in ONE hipGraph and replayed —
+// exactly the launch sequence of DecodeEngine.__call__ + sample_fused (engine.py:206-252).  Weights are random, the
+// thresholds are calibrated layer by layer on the activations the sparse path itself produces (median of |x|), so every
+// projection keeps ~(1 - sparsity) of its rows like the engine's synthetic calibration does.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "teal_hip.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+#define TK(x) do { int r_ = (x); if (r_ != 0) { fprintf(stderr, "teal error %d (%s) at %s:%d\n", r_, teal_strerror(r_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__device__ __forceinline__ uint32_t mix(uint32_t a) {
+    a ^= a >> 16; a *= 0x7feb352du; a ^= a >> 15; a *= 0x846ca68bu; a ^= a >> 16;
+    return a;
+}
+// uniform(-amp, amp) halves / bf16
+__global__ void fill_uniform(uint16_t* p, size_t n, uint32_t seed, float amp, int bf16) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t h = mix((uint32_t)i * 0x9E3779B9u + seed * 0x85EBCA6Bu + (uint32_t)(i >> 32));
+        const float v = ((float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f) * amp;
+        uint16_t b;
+        if (bf16) { uint32_t u = __float_as_uint(v); u += 0x7FFFu + ((u >> 16) & 1u); b = (uint16_t)(u >> 16); }
+        else { _Float16 hh = (_Float16)v; b = __builtin_bit_cast(uint16_t, hh); }
+        p[i] = b;
+    }
+}
+
+static float h2f(uint16_t b, bool bf) {
+    if (bf) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+    const int s = b >> 15, e = (b >> 10) & 31, m = b & 1023;
+    float v;
+    if (e == 0) v = ldexpf((float)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = ldexpf((float)(m + 1024), e - 25);
+    return s ? -v : v;
+}
+static uint16_t f2h(float f, bool bf) {  // round to nearest even (host side, calibration only)
+    if (bf) { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
+    _Float16 h = (_Float16)f; uint16_t b; memcpy(&b, &h, 2); return b;
+}
+
+struct Shape { int dim, inter, n_head, n_kv, hd, vocab; };
+static Shape shape_of(const std::string& m) {
+    if (m == "8b") return {4096, 14336, 32, 8, 128, 128256};
+    if (m == "70b") return {8192, 28672, 64, 8, 128, 32000};
+    return {4096, 11008, 32, 32, 128, 32000};
+}
+
+struct Tune { int lpr = 0, waves = 0, split = 0, unroll = 0; };
+static std::map<std::string, Tune> g_tune;
+static bool g_trace = false;
+static hipStream_t g_st;
+static void apply_tune(const char* stage) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone; hipStreamIsCapturing(g_st, &cs);
+    if (g_trace && cs == hipStreamCaptureStatusNone) { hipError_t e = hipStreamSynchronize(g_st); fprintf(stderr, "[trace] sync=%s -> %s\n", hipGetErrorName(e), stage); fflush(stderr); }
+    Tune t;
+    if (g_tune.count("all")) t = g_tune["all"];
+    if (g_tune.count(stage)) t = g_tune[stage];
+    TK(teal_set_tuning(t.lpr, t.waves, t.split, t.unroll));
+}
+
+struct Layer {
+    uint16_t *wqkv, *wo, *w1, *w3, *w2, *norm1, *norm2, *kc, *vc;
+    float tq, to, tg, td;
+};
+
+int main(int argc, char** argv) {
+    int n_layer = 32, steps = 100, pos0 = 64, warm = 5, att_split = 0, pair = 1;
+    float sparsity = 0.5f;
+    bool phase = false, dense = false, bf = false;
+    std::string model = "7b";
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto nxt = [&]() { return std::string(argv[++i]); };
+        if (a == "--layers") n_layer = atoi(nxt().c_str());
+        else if (a == "--steps") steps = atoi(nxt().c_str());
+        else if (a == "--pos") pos0 = atoi(nxt().c_str());
+        else if (a == "--sparsity") sparsity = atof(nxt().c_str());
+        else if (a == "--model") model = nxt();
+        else if (a == "--phase") phase = true;
+        else if (a == "--dense") dense = true;
+        else if (a == "--bf16") bf = true;
+        else if (a == "--att_split") att_split = atoi(nxt().c_str());
+        else if (a == "--no_pair") pair = 0;
+        else if (a == "--tune") {
+            std::string s = nxt();
+            size_t p = 0;
+            while (p < s.size()) {
+                size_t q = s.find(',', p); if (q == std::string::npos) q = s.size();
+                std::string it = s.substr(p, q - p); p = q + 1;
+                char st[32]; Tune t;
+                if (sscanf(it.c_str(), "%31[^:]:%d:%d:%d:%d", st, &t.lpr, &t.waves, &t.split, &t.unroll) >= 2) g_tune[st] = t;
+            }
+        } else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
+    }
+    const Shape S = shape_of(model);
+    const int dim = S.dim, inter = S.inter, hd = S.hd, kv = S.n_kv * hd, nqkv = dim + 2 * kv;
+    const int dt = bf ? TEAL_BF16 : TEAL_F16;
+    const int max_seq = std::max(256, pos0 + steps + warm + 64);
+    if (!att_split) att_split = max_seq <= 1024 ? 4 : 8;
+    const int ncu = teal_init();
+    if (ncu <= 0) { fprintf(stderr, "no device\n"); return 1; }
+    hipStream_t st; CK(hipStreamCreate(&st));
+    g_st = st; g_trace = getenv("LB_TRACE") != nullptr;
+    auto alloc16 = [&](size_t n, uint32_t seed, float amp) {
+        uint16_t* p; CK(hipMalloc(&p, n * 2));
+        hipLaunchKernelGGL(fill_uniform, dim3(2048), dim3(256), 0, st, p, n, seed, amp, bf ? 1 : 0);
+        return p;
+    };
+    auto allocz = [&](size_t bytes) { void* p; CK(hipMalloc(&p, bytes)); CK(hipMemsetAsync(p, 0, bytes, st)); return p; };
+    const int ldq = nqkv + 64, ldo = dim + 64, ldi = inter + 64, ldd = dim + 64, ldv = S.vocab + 64;
+    std::vector<Layer> Ls(n_layer);
+    uint32_t seed = 1;
+    for (auto& l : Ls) {
+        const float a_in = sqrtf(3.0f / dim), a_dn = sqrtf(3.0f / inter);
+        l.wqkv = alloc16((size_t)dim * ldq, seed++, a_in * 1.5f);
+        l.wo = alloc16((size_t)dim * ldo, seed++, a_in * 1.5f);
+        l.w1 = alloc16((size_t)dim * ldi, seed++, a_in * 1.5f);
+        l.w3 = alloc16((size_t)dim * ldi, seed++, a_in * 1.5f);
+        l.w2 = alloc16((size_t)inter * ldd, seed++, a_dn * 1.5f);
+        l.norm1 = alloc16(dim, seed++, 0.0f); l.norm2 = alloc16(dim, seed++, 0.0f);
+        l.kc = alloc16((size_t)S.n_kv * max_seq * hd, seed++, 1.0f);
+        l.vc = alloc16((size_t)S.n_kv * max_seq * hd, seed++, 1.0f);
+    }
+    uint16_t* wout = alloc16((size_t)dim * ldv, seed++, sqrtf(3.0f / dim));
+    uint16_t* normf = alloc16(dim, seed++, 0.0f);
+    uint16_t* emb = alloc16((size_t)S.vocab * dim, seed++, 1.7f);
+    // norm weights = 1.0
+    {
+        std::vector<uint16_t> ones(dim, f2h(1.0f, bf));
+        for (auto& l : Ls) { CK(hipMemcpyAsync(l.norm1, ones.data(), dim * 2, hipMemcpyHostToDevice, st)); CK(hipMemcpyAsync(l.norm2, ones.data(), dim * 2, hipMemcpyHostToDevice, st)); }
+        CK(hipMemcpyAsync(normf, ones.data(), dim * 2, hipMemcpyHostToDevice, st));
+        CK(hipStreamSynchronize(st));
+    }
+    // rope table [max_seq][hd/2][2]
+    uint16_t* rope; CK(hipMalloc(&rope, (size_t)max_seq * hd * 2));
+    {
+        std::vector<uint16_t> r((size_t)max_seq * hd);
+        for (int p = 0; p < max_seq; ++p)
+            for (int j = 0; j < hd / 2; ++j) {
+                const float f = p * powf(10000.0f, -2.0f * j / hd);
+                r[((size_t)p * (hd / 2) + j) * 2] = f2h(cosf(f), bf);
+                r[((size_t)p * (hd / 2) + j) * 2 + 1] = f2h(sinf(f), bf);
+            }
+        CK(hipMemcpy(rope, r.data(), r.size() * 2, hipMemcpyHostToDevice));
+    }
+    uint16_t* A = (uint16_t*)allocz(dim * 2); uint16_t* B = (uint16_t*)allocz(dim * 2);
+    uint16_t* y_attn = (uint16_t*)allocz(dim * 2); uint16_t* h_mlp = (uint16_t*)allocz(inter * 2);
+    uint16_t* gu = (uint16_t*)allocz((size_t)2 * inter * 2);
+    unsigned long long* y_mask = (unsigned long long*)allocz(((dim + 63) / 64) * 8);
+    unsigned long long* h_mask = (unsigned long long*)allocz(((inter + 63) / 64) * 8);
+    const size_t slab_floats = (size_t)32 * std::max(dim, nqkv);
+    float* s_wo = (float*)allocz(slab_floats * 4); float* s_down = (float*)allocz(slab_floats * 4);
+    float* s_qkv = (float*)allocz((size_t)8 * nqkv * 4);
+    const size_t att_bytes = (size_t)S.n_head * att_split * (hd + 2) * 4;
+    float* att_ws = (float*)allocz(att_bytes);
+    uint16_t* logits = (uint16_t*)allocz((size_t)S.vocab * 2);
+    const size_t ws_bytes = teal_workspace_bytes(std::max(dim, inter), std::max(std::max(nqkv, inter), S.vocab));
+    void* ws = allocz(ws_bytes);
+    int32_t* tok = (int32_t*)allocz(4); int32_t* pos = (int32_t*)allocz(4); int32_t* hist = (int32_t*)allocz(4 * 65536);
+    unsigned long long* rng = (unsigned long long*)allocz(16);
+    { int32_t p = pos0, t = 3; CK(hipMemcpy(pos, &p, 4, hipMemcpyHostToDevice)); CK(hipMemcpy(tok, &t, 4, hipMemcpyHostToDevice));
+      unsigned long long r[2] = {1234, 0}; CK(hipMemcpy(rng, r, 16, hipMemcpyHostToDevice)); }
+    const bool fused_merge = (att_split == 4 && dim <= 16384) || (att_split == 8 && dim <= 8192);
+    const float NEG = -INFINITY, eps = 1e-5f;
+    int n_qkv = 0, n_wo = 0, n_down = 0;
+
+    auto mk_out = [&](int nseg, const void* const* w, const int* ld, const int* col0, const int* nc, const float* tau, void* const* y, int mode,
+                      float* slabs) {
+        teal_gemv_out_t o; memset(&o, 0, sizeof o);
+        o.nseg = nseg;
+        for (int i = 0; i < nseg; ++i) { o.w[i] = w[i]; o.ld[i] = ld[i]; o.col0[i] = col0[i]; o.ncols[i] = nc[i]; o.tau[i] = tau[i]; o.y[i] = y ? y[i] : nullptr; }
+        o.mode = mode;
+        if (slabs) { o.slabs = slabs; o.slabs_bytes = slab_floats * 4; o.slabs_interleaved = 1; }
+        return o;
+    };
+    // ---- the five launches of layer i (engine.py:_build) --------------------------------------------------
+    auto k_qkv = [&](int i, float tq) {
+        Layer& l = Ls[i];
+        teal_gemv_in_t in; memset(&in, 0, sizeof in);
+        in.mode = TEAL_IN_RESID_NORM; in.resid_in = i == 0 ? (const void*)emb : (const void*)A; in.row_index = i == 0 ? tok : nullptr;
+        in.slabs = i == 0 ? nullptr : s_down; in.nslabs = i == 0 ? 0 : n_down; in.slabs_interleaved = 1;
+        in.norm_weight = l.norm1; in.eps = eps; in.resid_out = B;
+        const void* w[3] = {l.wqkv, l.wqkv, l.wqkv}; const int ld[3] = {ldq, ldq, ldq}; const int c0[3] = {0, dim, dim + kv};
+        const int nc[3] = {dim, kv, kv}; const float tau[3] = {tq, tq, tq};
+        teal_gemv_out_t o = mk_out(3, w, ld, c0, nc, tau, nullptr, TEAL_OUT_SLABS, s_qkv);
+        o.slabs_bytes = (size_t)8 * nqkv * 4;
+        apply_tune("qkv");
+        TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, &n_qkv, st));
+    };
+    auto k_attn = [&](int i, bool to_y, float tau_o) {
+        Layer& l = Ls[i];
+        apply_tune("attn");
+        TK(teal_decode_attention_split_slabs(s_qkv, n_qkv, rope, pos, l.kc, l.vc, to_y ? y_attn : nullptr, y_mask, tau_o, S.n_head, S.n_kv,
+                                             hd, max_seq, att_split, att_ws, att_bytes, dt, st));
+    };
+    auto k_wo = [&](int i, float to) {
+        Layer& l = Ls[i];
+        teal_gemv_in_t in; memset(&in, 0, sizeof in);
+        if (fused_merge) { in.mode = TEAL_IN_ATTN_MERGE; in.x = att_ws; in.att_head_dim = hd; in.att_nsplit = att_split; }
+        else { in.mode = TEAL_IN_MASKED; in.x = y_attn; in.masks = y_mask; }
+        const void* w[1] = {l.wo}; const int ld[1] = {ldo}; const int c0[1] = {0}; const int nc[1] = {dim}; const float tau[1] = {to};
+        teal_gemv_out_t o = mk_out(1, w, ld, c0, nc, tau, nullptr, TEAL_OUT_SLABS, s_wo);
+        apply_tune("wo");
+        TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, &n_wo, st));
+    };
+    auto k_gu = [&](int i, float tg, float td) {
+        Layer& l = Ls[i];
+        teal_gemv_in_t in; memset(&in, 0, sizeof in);
+        in.mode = TEAL_IN_RESID_NORM; in.resid_in = B; in.slabs = s_wo; in.nslabs = n_wo; in.slabs_interleaved = 1;
+        in.norm_weight = l.norm2; in.eps = eps; in.resid_out = A;
+        const void* w[2] = {l.w1, l.w3}; const int ld[2] = {ldi, ldi}; const int c0[2] = {0, 0}; const int nc[2] = {inter, inter};
+        const float tau[2] = {tg, tg};
+        apply_tune("gu");
+        if (pair) {
+            void* y[2] = {h_mlp, nullptr};
+            teal_gemv_out_t o = mk_out(2, w, ld, c0, nc, tau, y, TEAL_OUT_PAIR_SILU, nullptr);
+            o.mask_out = h_mask; o.mask_tau = td;
+            TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, nullptr, st));
+        } else {
+            void* y[2] = {gu, gu + inter};
+            teal_gemv_out_t o = mk_out(2, w, ld, c0, nc, tau, y, TEAL_OUT_ROUNDED, nullptr);
+            TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, nullptr, st));
+        }
+    };
+    auto k_down = [&](int i, float td) {
+        Layer& l = Ls[i];
+        teal_gemv_in_t in; memset(&in, 0, sizeof in);
+        if (pair) { in.mode = TEAL_IN_MASKED; in.x = h_mlp; in.masks = h_mask; }
+        else { in.mode = TEAL_IN_SILU_MUL; in.x = gu; }
+        const void* w[1] = {l.w2}; const int ld[1] = {ldd}; const int c0[1] = {0}; const int nc[1] = {dim}; const float tau[1] = {td};
+        teal_gemv_out_t o = mk_out(1, w, ld, c0, nc, tau, nullptr, TEAL_OUT_SLABS, s_down);
+        apply_tune("down");
+        TK(teal_fused_gemv(&in, &o, inter, dt, ws, ws_bytes, &n_down, st));
+    };
+    auto k_head = [&]() {
+        teal_gemv_in_t in; memset(&in, 0, sizeof in);
+        in.mode = TEAL_IN_RESID_NORM; in.resid_in = A; in.slabs = s_down; in.nslabs = n_down; in.slabs_interleaved = 1;
+        in.norm_weight = normf; in.eps = eps; in.resid_out = nullptr;
+        const void* w[1] = {wout}; const int ld[1] = {ldv}; const int c0[1] = {0}; const int nc[1] = {S.vocab}; const float tau[1] = {NEG};
+        void* y[1] = {logits};
+        teal_gemv_out_t o = mk_out(1, w, ld, c0, nc, tau, y, TEAL_OUT_ROUNDED, nullptr);
+        apply_tune("head");
+        TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, nullptr, st));
+    };
+
+    // ---- calibration: median |x| of every projection input, layer by layer, on the sparse path itself ----
+    auto quantile_abs = [&](std::vector<float>& v, float q) {
+        for (auto& x : v) x = fabsf(x);
+        std::sort(v.begin(), v.end());
+        const size_t k = std::min(v.size() - 1, (size_t)(q * v.size()));
+        return k == 0 ? -INFINITY : 0.5f * (v[k - 1] + v[k]);  // strictly between two samples
+    };
+    auto fetch16 = [&](const uint16_t* d, int n) {
+        std::vector<uint16_t> h(n); CK(hipStreamSynchronize(st)); CK(hipMemcpy(h.data(), d, n * 2, hipMemcpyDeviceToHost));
+        std::vector<float> f(n); for (int i = 0; i < n; ++i) f[i] = h2f(h[i], bf);
+        return f;
+    };
+    auto norm_of = [&](const uint16_t* d) {  // x = round(round(h * rstd) * 1.0)
+        std::vector<float> h = fetch16(d, dim);
+        double ss = 0; for (float v : h) ss += (double)v * v;
+        const float rstd = 1.0f / sqrtf((float)(ss / dim) + eps);
+        for (auto& v : h) v = h2f(f2h(v * rstd, bf), bf);
+        return h;
+    };
+    std::vector<double> kept(4, 0.0);
+    for (int i = 0; i < n_layer; ++i) {
+        Layer& l = Ls[i];
+        if (dense) { l.tq = l.to = l.tg = l.td = NEG; k_qkv(i, NEG); k_attn(i, false, NEG); k_wo(i, NEG); k_gu(i, NEG, NEG); k_down(i, NEG); continue; }
+        k_qkv(i, INFINITY);  // writes the residual stream (B) only
+        { auto x = norm_of(B); l.tq = quantile_abs(x, sparsity); }
+        k_qkv(i, l.tq);
+        k_attn(i, true, 0.0f);
+        { auto y = fetch16(y_attn, dim); l.to = quantile_abs(y, sparsity); }
+        k_attn(i, !fused_merge, l.to);
+        k_wo(i, l.to);
+        k_gu(i, INFINITY, 0.0f);
+        { auto x = norm_of(A); l.tg = quantile_abs(x, sparsity); }
+        k_gu(i, l.tg, 0.0f);
+        if (pair) {
+            auto h = fetch16(h_mlp, inter); l.td = quantile_abs(h, sparsity);
+            k_gu(i, l.tg, l.td);
+            CK(hipStreamSynchronize(st));
+            std::vector<unsigned long long> m((inter + 63) / 64); CK(hipMemcpy(m.data(), h_mask, m.size() * 8, hipMemcpyDeviceToHost));
+            size_t c = 0; for (auto w : m) c += __builtin_popcountll(w);
+            kept[3] += (double)c / inter;
+        } else {
+            auto g = fetch16(gu, 2 * inter);
+            std::vector<float> h(inter);
+            for (int j = 0; j < inter; ++j) { const float s = h2f(f2h(g[j] / (1.0f + expf(-g[j])), bf), bf); h[j] = h2f(f2h(s * g[inter + j], bf), bf); }
+            l.td = quantile_abs(h, sparsity);
+        }
+        k_down(i, l.td);
+    }
+    k_head();
+    CK(hipStreamSynchronize(st));
+    printf("model %s dtype %s layers %d cu %d pos0 %d max_seq %d att_split %d pair %d | slabs qkv %d wo %d down %d", model.c_str(), bf ? "bf16" : "f16",
+           n_layer, ncu, pos0, max_seq, att_split, pair, n_qkv, n_wo, n_down);
+    if (!dense && pair) printf(" | kept(down) %.3f", kept[3] / n_layer);
+    printf("\n  tau layer0: q %.4f o %.5f g %.4f d %.5f\n", Ls[0].tq, Ls[0].to, Ls[0].tg, Ls[0].td);
+
+    if (getenv("LB_VERIFY")) {
+        // lean kernel vs general kernel on the same inputs: bit-identical outputs expected (same arithmetic, same order)
+        auto snap = [&](const void* d, size_t bytes) { std::vector<unsigned char> h(bytes); CK(hipStreamSynchronize(st)); CK(hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost)); return h; };
+        int bad = 0;
+        auto cmp = [&](const char* what, const std::vector<unsigned char>& a, const std::vector<unsigned char>& b) {
+            size_t nd = 0; for (size_t i = 0; i < a.size(); ++i) nd += a[i] != b[i];
+            printf("  verify %-22s %s (%zu of %zu bytes differ)\n", what, nd ? "DIFF" : "same", nd, a.size()); bad += nd != 0;
+        };
+        for (int i : {0, 1, n_layer - 1}) {
+            Layer& l = Ls[i];
+            // chain state: run the layers before i
+            for (int e = 0; e < i; ++e) { Layer& q = Ls[e]; k_qkv(e, q.tq); k_attn(e, !fused_merge, q.to); k_wo(e, q.to); k_gu(e, q.tg, q.td); k_down(e, q.td); }
+            printf(" layer %d\n", i);
+            TK(teal_set_fast(0)); k_qkv(i, l.tq); auto q0 = snap(s_qkv, (size_t)4 * nqkv * 4); auto b0 = snap(B, dim * 2);
+            TK(teal_set_fast(1)); k_qkv(i, l.tq); cmp("qkv slabs", q0, snap(s_qkv, (size_t)4 * nqkv * 4)); cmp("qkv resid_out", b0, snap(B, dim * 2));
+            k_attn(i, !fused_merge, l.to);
+            TK(teal_set_fast(0)); k_wo(i, l.to); auto w0 = snap(s_wo, (size_t)((n_wo + 3) & ~3) * dim * 4);
+            TK(teal_set_fast(1)); k_wo(i, l.to); cmp("wo slabs", w0, snap(s_wo, (size_t)((n_wo + 3) & ~3) * dim * 4));
+            TK(teal_set_fast(0)); k_gu(i, l.tg, l.td); auto h0 = snap(h_mlp, inter * 2); auto m0 = snap(h_mask, ((inter + 63) / 64) * 8); auto a0 = snap(A, dim * 2);
+            TK(teal_set_fast(1)); k_gu(i, l.tg, l.td); cmp("gate|up h", h0, snap(h_mlp, inter * 2)); cmp("gate|up masks", m0, snap(h_mask, ((inter + 63) / 64) * 8)); cmp("gate|up resid_out", a0, snap(A, dim * 2));
+            TK(teal_set_fast(0)); k_down(i, l.td); auto d0 = snap(s_down, (size_t)((n_down + 3) & ~3) * dim * 4);
+            TK(teal_set_fast(1)); k_down(i, l.td); cmp("down slabs", d0, snap(s_down, (size_t)((n_down + 3) & ~3) * dim * 4));
+        }
+        TK(teal_set_fast(0)); k_head(); auto g0 = snap(logits, (size_t)S.vocab * 2);
+        TK(teal_set_fast(1)); k_head(); cmp("lm_head logits", g0, snap(logits, (size_t)S.vocab * 2));
+        printf("verify: %s\n", bad ? "FAILED" : "ok");
+        if (bad) return 3;
+    }
+    auto token_step = [&]() {
+        for (int i = 0; i < n_layer; ++i) {
+            Layer& l = Ls[i];
+            k_qkv(i, l.tq); k_attn(i, !fused_merge, l.to); k_wo(i, l.to); k_gu(i, l.tg, l.td); k_down(i, l.td);
+        }
+        k_head();
+        TK(teal_sample_topk(logits, S.vocab, dt, 200, 0.8f, rng, tok, pos, hist, 65536, st));
+    };
+    auto capture = [&](auto&& fn) {
+        hipGraph_t g; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+        fn();
+        CK(hipStreamEndCapture(st, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        return ge;
+    };
+    auto time_graph = [&](hipGraphExec_t ge, int n, bool reset_pos) {
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        if (reset_pos) { int32_t p = pos0; CK(hipMemcpy(pos, &p, 4, hipMemcpyHostToDevice)); }
+        for (int i = 0; i < warm; ++i) CK(hipGraphLaunch(ge, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < n; ++i) CK(hipGraphLaunch(ge, st));
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        return ms * 1000.0 / n;  // us per replay
+    };
+    auto mark = [&](const char* m) { fprintf(stderr, "[mark] %s\n", m); fflush(stderr); };
+    mark("eager token");
+    token_step();  // warm-up outside capture
+    CK(hipStreamSynchronize(st));
+    mark("capture");
+    hipGraphExec_t gtok = capture(token_step);
+    mark("replay x1");
+    CK(hipGraphLaunch(gtok, st)); CK(hipStreamSynchronize(st));
+    mark("timed replays");
+    const double us_tok = time_graph(gtok, steps, true);
+    mark("stage graphs");
+    // per-stage cost: the same graph without one stage kind (the remaining launches still see correct-shaped inputs)
+    auto stage_graph = [&](int skip) {
+        return capture([&]() {
+            for (int i = 0; i < n_layer; ++i) {
+                Layer& l = Ls[i];
+                if (skip != 0) k_qkv(i, l.tq);
+                if (skip != 1) k_attn(i, !fused_merge, l.to);
+                if (skip != 2) k_wo(i, l.to);
+                if (skip != 3) k_gu(i, l.tg, l.td);
+                if (skip != 4) k_down(i, l.td);
+            }
+        });
+    };
+    double us_layers = time_graph(stage_graph(-1), std::max(10, steps / 4), true);
+    printf("token %.1f us = %.1f tok/s | layers only %.1f us (%.2f us/layer) | head+sampler %.1f us\n", us_tok, 1e6 / us_tok, us_layers,
+           us_layers / n_layer, us_tok - us_layers);
+    const char* nm[5] = {"qkv", "attn", "wo", "gate|up", "down"};
+    printf("  per-layer cost by leave-one-out:");
+    for (int s = 0; s < 5; ++s) {
+        const double u = time_graph(stage_graph(s), std::max(10, steps / 4), true);
+        printf(" %s %.2f", nm[s], (us_layers - u) / n_layer);
+    }
+    printf("\n");
+
+    if (phase) {
+        // phase stamps (teal_set_phase_buffer + teal_set_phase_stride: 32 uint64 per workgroup, one region per launch) of the
+        // GEMV launches of one middle layer, taken in flight: the real chain runs before and after on the same stream
+        const size_t region = (size_t)1024 * 32; const int nreg = 5;
+        unsigned long long* ph; CK(hipMalloc(&ph, region * nreg * 8));
+        std::vector<unsigned long long> hp(region * nreg);
+        const int li = n_layer / 2;
+        const char* sn[5] = {"qkv", "wo", "gate|up", "down", "qkv+1"};
+        std::vector<std::vector<std::vector<double>>> rows(nreg);
+        std::vector<std::vector<double>> wave_end(nreg);
+        std::vector<int> nwgs(nreg, 0), nwaves(nreg, 0);
+        for (int it = 0; it < 9; ++it) {
+            CK(hipMemsetAsync(ph, 0, region * nreg * 8, st));
+            auto full_layer = [&](int e) { Layer& q = Ls[e]; k_qkv(e, q.tq); k_attn(e, !fused_merge, q.to); k_wo(e, q.to); k_gu(e, q.tg, q.td); k_down(e, q.td); };
+            for (int e = 0; e < li; ++e) full_layer(e);
+            TK(teal_set_phase_stride(region)); TK(teal_set_phase_buffer(ph));
+            full_layer(li);
+            k_qkv(li + 1, Ls[li + 1].tq);
+            TK(teal_set_phase_buffer(nullptr)); TK(teal_set_phase_stride(0));
+            { Layer& q = Ls[li + 1]; k_attn(li + 1, !fused_merge, q.to); k_wo(li + 1, q.to); k_gu(li + 1, q.tg, q.td); k_down(li + 1, q.td); }
+            for (int e = li + 2; e < n_layer; ++e) full_layer(e);
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(hp.data(), ph, region * nreg * 8, hipMemcpyDeviceToHost));
+            double prev_end = 0;
+            for (int g = 0; g < nreg; ++g) {
+                const unsigned long long* base = &hp[region * g];
+                const int nwg = (int)(base[13] & 0xFFFFFFFFull), waves = (int)(base[13] >> 32);
+                if (nwg <= 0 || nwg > 1024) { printf("[%s] no stamps\n", sn[g]); continue; }
+                nwgs[g] = nwg; nwaves[g] = waves;
+                double t0 = 1e30, tend = 0;
+                for (int b = 0; b < nwg; ++b) t0 = std::min(t0, (double)base[(size_t)b * 32]);
+                std::vector<double> d(8, 0.0), we(16, 0.0);
+                double skew = 0, first_end = 1e30, tail_a = 0, tail_b = 0, pr_a = 0, pr_b = 0, pr_c = 0;
+                for (int b = 0; b < nwg; ++b) {
+                    const unsigned long long* r = &base[(size_t)b * 32];
+                    skew = std::max(skew, (double)r[0] - t0); tend = std::max(tend, (double)r[7]); first_end = std::min(first_end, (double)r[7] - t0);
+                    for (int k = 0; k < 7; ++k) d[k] += (double)r[k + 1] - (double)r[k];
+                    double wmax = 0;
+                    for (int w = 0; w < waves && w < 16; ++w) { we[w] += (double)r[16 + w] - (double)r[3]; wmax = std::max(wmax, (double)r[16 + w]); }
+                    tail_a += (double)r[6] - wmax; tail_b += (double)r[7] - (double)r[6];
+                    if (r[8]) { pr_a += (double)r[8] - (double)r[1]; pr_b += (double)r[9] - (double)r[8]; pr_c += (double)r[2] - (double)r[9]; }
+                }
+                std::vector<double> row = {(tend - t0) / 100.0, g ? (t0 - prev_end) / 100.0 : 0.0, skew / 100.0};
+                for (int k = 0; k < 7; ++k) row.push_back(d[k] / nwg / 100.0);
+                row.push_back(first_end / 100.0);
+                row.push_back(tail_a / nwg / 100.0); row.push_back(tail_b / nwg / 100.0);
+                row.push_back(pr_a / nwg / 100.0); row.push_back(pr_b / nwg / 100.0); row.push_back(pr_c / nwg / 100.0);
+                rows[g].push_back(row);
+                for (auto& v : we) v = v / nwg / 100.0;
+                wave_end[g] = we;
+                prev_end = tend;
+            }
+        }
+        for (int g = 0; g < nreg; ++g) {
+            if (rows[g].empty()) continue;
+            // median of every column separately
+            const size_t nc = rows[g][0].size();
+            std::vector<double> m(nc);
+            for (size_t c = 0; c < nc; ++c) { std::vector<double> v; for (auto& r : rows[g]) v.push_back(r[c]); std::sort(v.begin(), v.end()); m[c] = v[v.size() / 2]; }
+            printf("[%-7s] wgs %d x %d waves | span %.2f | gap from previous GEMV end %.2f; entry skew %.2f; kernarg %.2f; x ready %.2f; list %.2f; "
+                   "first batch %.2f; stream(w0) %.2f; wait+reduce %.2f; store %.2f; earliest WG end %.2f\n", sn[g], nwgs[g], nwaves[g], m[0], m[1], m[2],
+                   m[3], m[4], m[5], m[6], m[7], m[8], m[9], m[10]);
+            printf("          tail: slowest wave -> past reduce barrier %.2f, -> stores issued %.2f | producer: kernarg -> loads back %.2f, -> past barrier %.2f, -> x %.2f\n",
+                   m[11], m[12], m[13], m[14], m[15]);
+            printf("          per-wave stream end after list-ready (us):");
+            for (int w = 0; w < nwaves[g] && w < 16; ++w) printf(" %.1f", wave_end[g][w]);
+            printf("\n");
+        }
+    }
+    return 0;
+}

@@ -18,7 +18,10 @@ CSRC = os.path.join(_PKG, "csrc")
 # translation units: host logic + GEMV ABI, attention + sampler, and the GEMV kernel instantiations split by
 # (weight width, activation dtype) so that they compile in parallel
 SOURCES = ("teal_kernels.hip", "teal_attention.hip", "teal_gemv_w16_f16.hip", "teal_gemv_w16_bf16.hip",
-           "teal_gemv_w8_f16.hip", "teal_gemv_w8_bf16.hip")
+           "teal_gemv_w8_f16.hip", "teal_gemv_w8_bf16.hip", "teal_gemv_fast_f16.hip", "teal_gemv_fast_bf16.hip")
+# translation units whose kernels take their hot arguments as scalar parameters: the command processor preloads the
+# first 11 dwords into SGPRs at wave launch (no scalar-cache miss before the first activation load)
+PRELOAD = {"teal_gemv_fast_f16.hip": 11, "teal_gemv_fast_bf16.hip": 11}
 INCLUDE = os.path.join(_ROOT, "include")
 OBJ_DIR = os.path.join(CSRC, "_obj")
 LIB_PATH = os.path.join(_PKG, "libteal_hip.so")
@@ -27,7 +30,7 @@ LIB_PATH = os.path.join(_PKG, "libteal_hip.so")
 EXPORTS = (
     "teal_version", "teal_strerror", "teal_init", "teal_workspace_bytes", "teal_compact",
     "teal_sparse_gemv", "teal_sparse_qkv_gemv", "teal_dense_gemv", "teal_sparse_gateup_silu",
-    "teal_set_tuning", "teal_get_config", "teal_set_phase_buffer", "teal_fused_gemv", "teal_decode_attention", "teal_sample_topk", "teal_set_swizzle", "teal_set_wave_local", "teal_sparse_qkv_gemv_ld", "teal_decode_attention_masked", "teal_decode_attention_split", "teal_sparse_qkv_gemv_i8", "teal_decode_attention_split_slabs",
+    "teal_set_tuning", "teal_get_config", "teal_set_phase_buffer", "teal_fused_gemv", "teal_decode_attention", "teal_sample_topk", "teal_set_swizzle", "teal_set_wave_local", "teal_sparse_qkv_gemv_ld", "teal_decode_attention_masked", "teal_decode_attention_split", "teal_sparse_qkv_gemv_i8", "teal_decode_attention_split_slabs", "teal_set_phase_stride", "teal_set_fast",
 )
 
 _lib = None
@@ -56,7 +59,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_header):
             return obj
-        cmd = [hipcc, *flags, "-c", src, "-o", obj]
+        extra = []
+        if os.path.basename(src) in PRELOAD:
+            extra = ["-mllvm", f"-amdgpu-kernarg-preload-count={PRELOAD[os.path.basename(src)]}"]
+        cmd = [hipcc, *flags, *extra, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -103,10 +109,12 @@ def load() -> ctypes.CDLL:
     L.teal_sparse_gateup_silu.argtypes = [vp, vp, vp, vp, cf, cf, ci, ci, ci, vp, sz, vp]
     L.teal_set_tuning.argtypes = [ci, ci, ci, ci]
     L.teal_set_phase_buffer.argtypes = [vp]
+    L.teal_set_phase_stride.argtypes = [sz]
     L.teal_fused_gemv.argtypes = [vp, vp, ci, ci, vp, sz, ctypes.POINTER(ci), vp]
     L.teal_sample_topk.argtypes = [vp, ci, ci, ci, cf, vp, vp, vp, vp, ci, vp]
     L.teal_set_swizzle.argtypes = [ci]
     L.teal_set_wave_local.argtypes = [ci]
+    L.teal_set_fast.argtypes = [ci]
     L.teal_decode_attention_masked.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, ci, vp]
     L.teal_decode_attention_split.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, ci, vp, sz, ci, vp]
     L.teal_decode_attention_split_slabs.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, ci, vp, sz, ci, vp]

@@ -772,7 +772,7 @@ int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_
     auto* vc = reinterpret_cast<uint16_t*>(v_cache);
     auto* yo = reinterpret_cast<uint16_t*>(y);
     auto* mo = reinterpret_cast<unsigned long long*>(mask_out);
-#define TEAL_ATT(BF, NTV, HDV) hipLaunchKernelGGL((decode_attention_kernel<BF, NTV, HDV>), grid, block, lds, st, q, r, pos, kc, vc, yo, mo, mask_tau, n_head, n_kv_head, max_seq, scale, g_phase)
+#define TEAL_ATT(BF, NTV, HDV) hipLaunchKernelGGL((decode_attention_kernel<BF, NTV, HDV>), grid, block, lds, st, q, r, pos, kc, vc, yo, mo, mask_tau, n_head, n_kv_head, max_seq, scale, g_phase_stride ? nullptr : g_phase)
 #define TEAL_ATT_HD(BF, NTV) do { if (head_dim == 128) TEAL_ATT(BF, NTV, 128); else TEAL_ATT(BF, NTV, 64); } while (0)
     if (dtype == TEAL_BF16) TEAL_ATT_HD(true, 1024);
     else TEAL_ATT_HD(false, 1024);
@@ -856,7 +856,7 @@ int teal_sample_topk(const void* logits, int vocab, int dtype, int top_k, float 
     auto* lg = reinterpret_cast<const uint16_t*>(logits);
     auto* rs = reinterpret_cast<unsigned long long*>(rng_state);
 #define TEAL_SAMPLE(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len)
-#define TEAL_SAMPLE_W(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len, g_phase)
+#define TEAL_SAMPLE_W(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len, g_phase_stride ? nullptr : g_phase)
     const bool bf = dtype == TEAL_BF16;
     if ((vocab & 7) == 0 && vocab <= 4 * 8192) {  // register-resident keys, window select: 4 vectors per thread
         if (bf) TEAL_SAMPLE_W((sample_topk_window_kernel<true, 4>)); else TEAL_SAMPLE_W((sample_topk_window_kernel<false, 4>));

@@ -83,6 +83,8 @@ struct Config {
 extern int g_num_cu;
 extern Config g_override;
 extern unsigned long long* g_phase;
+extern size_t g_phase_stride;
+extern int g_phase_seq;
 extern int g_swizzle;
 extern int g_wave_local;
 

@@ -1,0 +1,449 @@
+// teal_gemv_fast.h — the lean sparse GEMV kernel of the fused decode step (16-bit weights, whole 64-element chunks,
+// whole column tiles).  Same algorithm and the same arithmetic, in the same order, as sparse_gemv_kernel
+// (teal_gemv_kernel.h, which stays the general kernel: ragged shapes, int8 weights, planar slabs, long vectors), i.e.
+// it replaces the same reference code:
+//   kernels/sparse_gemv.py:50-83    splitk_sparse_gemv_kernel   (mask + gathered GEMV)
+//   kernels/sparse_gemv.py:152-194  qkv_kernel                  (three thresholds over one fused weight)
+//   gpt-fast/model.py:158-161,258-259,289-291                   (residual adds, RMSNorm, silu(gate) * up: fused producers)
+//
+// Why a second kernel: on MI355X a 7B-class launch streams for 3-14 us, and the phase stamps of the general kernel
+// showed 2.3 us between kernel entry and "row list ready" of which only ~0.8 us is memory latency — the rest is
+// INSTRUCTION ISSUE: 16 waves share 4 SIMDs, so every instruction of the per-wave prologue costs four issue slots, and
+// the general kernel executes ~800 of them (runtime geometry: integer division of the block index, segment lookup,
+// clamps for ragged vectors, 64-bit address arithmetic, five dependent groups of scalar kernel-argument loads that
+// each miss the scalar cache).  Here:
+//   * the arguments the first loads need are separate scalar kernel parameters, preloaded into SGPRs by the command
+//     processor (-mllvm -amdgpu-kernarg-preload-count): the activation loads leave at the first instruction;
+//   * everything else arrives with ONE batch of scalar loads that overlaps the activation loads;
+//   * the grid is (tiles, slices): no division; vectors are whole chunks and tiles whole: no clamps;
+//   * 32-bit element offsets against uniform bases;
+//   * phase stamps are a template flag (compiled out of the production instantiations).
+#pragma once
+#include "teal_gemv_fast_decl.h"
+#include "teal_gemv_kernel.h"
+
+namespace teal {
+
+// ONE batch of scalar loads for every remaining kernel argument, placed right after the activation loads have been
+// issued (an "s" input forces the value into an SGPR at this point of the program)
+#define TEAL_FAST_ARGS_BATCH(a)                                                                                         \
+    asm volatile("" ::"s"((a).w0), "s"((a).w1), "s"((a).y), "s"((a).ws), "s"((a).mask_out), "s"((a).resid_out),          \
+                 "s"((a).phase), "s"((a).ld0), "s"((a).ld1), "s"((a).seg_tile1), "s"((a).seg_tile2), "s"((a).tau0),       \
+                 "s"((a).tau1), "s"((a).tau2), "s"((a).mask_tau), "s"((a).ws_stride), "s"((a).att_hd), "s"((a).att_ns),  \
+                 "s"((a).cap))
+
+
+// LPR lanes x 16 B = BN columns per tile; KR = register-cached 64-element chunks per wave.
+//   MODE 0 plain x; 1 residual + slabs -> RMSNorm (in0 residual, in1 slabs, in2 norm weight); 3 x + producer masks
+//   (in0 x, in1 masks); 4 split-KV attention partials (in0).  Element-wise modes (0, 3, 4) cache the rounds of the
+//   workgroup's own slice only: register k <-> round slice + k * split.
+//   EXACT (MODE 1): Z == 1024 * KR, every cached chunk exists — no clamps, no guards.
+template <bool BF16, int MODE, bool PAIR, int LPR, int KR, bool EXACT, bool PHASE>
+__global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const void* in1, const void* in2,
+                                                         const int* row_index, const int Z, const int nslabs,
+                                                         const float eps, const FastArgs a) {
+    constexpr int WAVES = 16, U = 4;
+    constexpr int RPW = 64 / LPR;
+    constexpr int BN = LPR * 8;
+    unsigned long long t_entry = 0;
+    if constexpr (PHASE) t_entry = wall_clock64();
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x, slice = blockIdx.y, split = gridDim.y;
+    const int nch = Z >> 6;
+    const uint32_t bid = blockIdx.y * gridDim.x + blockIdx.x;
+    auto stamp = [&](const int i) {
+        if constexpr (PHASE) { if (a.phase && tid == 0) a.phase[(size_t)bid * kPhaseRow + i] = wall_clock64(); }
+    };
+
+    // ---- producer: every load is issued before anything waits -----------------------------------------------
+    const uint16_t* __restrict__ x16 = reinterpret_cast<const uint16_t*>(in0);
+    uint32_t xr[KR];
+    bool own[KR];    // chunk exists and its rows belong to this workgroup (wave-uniform)
+    int cidx[KR];
+    float sumsq_part = 0.0f;
+    float rv[MODE == 1 ? KR : 1];
+    uint32_t wb[MODE == 1 ? KR : 1];
+    unsigned long long mk[MODE == 3 ? KR : 1];
+    {
+        int kmod = 0;  // MODE 1 caches every round; round k belongs to slice k mod split
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const int round = MODE == 1 ? k : slice + k * split;
+            const int c = wave + WAVES * round;
+            cidx[k] = c;
+            own[k] = (EXACT || c < nch) && (MODE != 1 || kmod == slice);
+            kmod = (kmod + 1 == split) ? 0 : kmod + 1;
+        }
+    }
+    if constexpr (MODE == 1) {
+        const uint16_t* resid = x16;
+        if (row_index) resid += (size_t)row_index[0] * (size_t)Z;  // embedding row of the current token
+        const uint16_t* nw = reinterpret_cast<const uint16_t*>(in2);
+        const float* slabs = reinterpret_cast<const float*>(in1);
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        uint32_t rb[KR];
+        f32x4 v0[KR], v1[KR];
+        const uint32_t stride = (uint32_t)(nslabs + 3) & ~3u;
+        uint32_t mel[KR];
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            mel[k] = (uint32_t)(EXACT ? cidx[k] : min(cidx[k], nch - 1)) * 64u + lane;
+            rb[k] = resid[mel[k]];
+            wb[k] = nw[mel[k]];
+        }
+        if (nslabs > 0) {
+#pragma unroll
+            for (int k = 0; k < KR; ++k) v0[k] = *reinterpret_cast<const f32x4*>(slabs + mel[k] * stride);
+        }
+        if (nslabs > 4) {
+#pragma unroll
+            for (int k = 0; k < KR; ++k) v1[k] = *reinterpret_cast<const f32x4*>(slabs + mel[k] * stride + 4);
+        }
+        TEAL_FAST_ARGS_BATCH(a);
+        stamp(1);
+        // slab order 0, 1, 2, ... (the order of the ordered reduce launch); adding an absent slab as 0.0f is exact
+        float ysum[KR];
+        if (nslabs == 4) {
+#pragma unroll
+            for (int k = 0; k < KR; ++k) ysum[k] = (((0.0f + v0[k][0]) + v0[k][1]) + v0[k][2]) + v0[k][3];
+        } else if (nslabs > 0) {
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                float sacc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sacc += (j < nslabs) ? v0[k][j] : 0.0f;
+                if (nslabs > 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sacc += (4 + j < nslabs) ? v1[k][j] : 0.0f;
+                }
+                ysum[k] = sacc;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            float r = bits_to_float(rb[k], BF16);
+            if (nslabs > 0) {
+                const float yv = bits_to_float(float_to_bits<BF16>(ysum[k]), BF16);
+                r = bits_to_float(float_to_bits<BF16>(r + yv), BF16);
+            }
+            if (!EXACT) r = (cidx[k] < nch) ? r : 0.0f;
+            rv[k] = r;
+            sumsq_part += r * r;
+        }
+        stamp(8);
+        float* sumsq = reinterpret_cast<float*>(smem);
+        const float ssw = wave_sum_f(sumsq_part);
+        if (lane == 0) sumsq[wave] = ssw;
+        __syncthreads();
+        stamp(9);
+        float tot = (lane < WAVES) ? sumsq[lane] : 0.0f;
+        tot = wave_sum_f(tot);
+        const float rstd = rsqrtf(tot / (float)Z + eps);
+        uint16_t* rout = reinterpret_cast<uint16_t*>(a.resid_out);
+        const bool writer = rout && bid == 0;
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const float xn = bits_to_float(float_to_bits<BF16>(rv[k] * rstd), BF16);
+            xr[k] = float_to_bits<BF16>(xn * bits_to_float(wb[k], BF16));
+            if (writer && (EXACT || cidx[k] < nch)) rout[(uint32_t)cidx[k] * 64u + lane] = float_to_bits<BF16>(rv[k]);
+        }
+    } else if constexpr (MODE == 4) {
+        // attention output merged from the split-KV partials {max, sum, o[hd]} per (head, split): see the merge
+        // producer of sparse_gemv_kernel; one lane per (cached chunk, split) fetches {max, sum}
+        const float* att = reinterpret_cast<const float*>(in0);
+        const int hd = a.att_hd, hs = hd + 2;
+        auto merge = [&](auto ns_tag) {
+            constexpr int NS = decltype(ns_tag)::value;
+            static_assert(KR * NS <= 64, "one lane per (chunk, split)");
+            const int kk = min(lane / NS, KR - 1), qq = lane % NS;
+            const int ck = min(wave + WAVES * (slice + kk * split), nch - 1);
+            const float2 st = *reinterpret_cast<const float2*>(att + ((size_t)((ck << 6) / hd) * NS + qq) * hs);
+            float ov[KR][NS];
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                const int m = (min(cidx[k], nch - 1) << 6) + lane;
+                const int h = m / hd, d = m - h * hd;
+                const float* b = att + (size_t)h * NS * hs + 2 + d;
+#pragma unroll
+                for (int q = 0; q < NS; ++q) ov[k][q] = b[q * hs];
+            }
+            TEAL_FAST_ARGS_BATCH(a);
+            stamp(1);
+#define TEAL_DPPF(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
+            float M = fmaxf(st.x, TEAL_DPPF(st.x, 0xB1));
+            M = fmaxf(M, TEAL_DPPF(M, 0x4E));
+            if constexpr (NS == 8) M = fmaxf(M, TEAL_DPPF(M, 0x141));
+            const float f = st.y > 0.0f ? expf(st.x - M) : 0.0f;
+            float Ls = st.y * f;
+            Ls += TEAL_DPPF(Ls, 0xB1);
+            Ls += TEAL_DPPF(Ls, 0x4E);
+            if constexpr (NS == 8) Ls += TEAL_DPPF(Ls, 0x141);
+#undef TEAL_DPPF
+            const int cw = __float_as_int(f / Ls);
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                float Os = 0.0f;
+#pragma unroll
+                for (int q = 0; q < NS; ++q) Os += ov[k][q] * __int_as_float(__builtin_amdgcn_readlane(cw, NS * k + q));
+                xr[k] = float_to_bits<BF16>(Os);
+            }
+        };
+        if constexpr (KR * 8 <= 64) {
+            if (a.att_ns == 8) merge(std::integral_constant<int, 8>{});
+            else merge(std::integral_constant<int, 4>{});
+        } else {
+            merge(std::integral_constant<int, 4>{});
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const int c = min(cidx[k], nch - 1);
+            xr[k] = x16[(uint32_t)c * 64u + lane];
+            if constexpr (MODE == 3) mk[k] = reinterpret_cast<const unsigned long long*>(in1)[c];
+        }
+        TEAL_FAST_ARGS_BATCH(a);
+        stamp(1);
+    }
+    stamp(2);
+
+    // ---- mask + wave-local compaction: (row:16 | x:16) pairs of the wave's own chunks, ascending ---------------
+    int s = 0;
+    if (tile >= a.seg_tile1) s = 1;
+    if (tile >= a.seg_tile2) s = 2;
+    const float tau_s = s == 0 ? a.tau0 : (s == 1 ? a.tau1 : a.tau2);
+    const float tau = PAIR ? fminf(a.tau0, a.tau1) : tau_s;  // PAIR: union of the two keep sets
+    uint32_t* list = reinterpret_cast<uint32_t*>(smem + 64) + (size_t)wave * a.cap;
+    float* red = reinterpret_cast<float*>(smem + 64 + (size_t)WAVES * a.cap * 4);
+    int nloc = 0;
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        if (own[k]) {
+            unsigned long long mask;
+            if constexpr (MODE == 3) {
+                mask = mk[k];
+            } else {
+                const float v = bits_to_float(xr[k], BF16);
+                mask = __ballot(keep_rule(v, tau) || (v != v));  // NaN propagates like the reference's 0 * NaN
+            }
+            if ((mask >> lane) & 1ull) list[nloc + lane_rank(mask)] = (((uint32_t)cidx[k] * 64u + lane) << 16) | xr[k];
+            nloc += __popcll(mask);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    stamp(3);
+
+    // ---- stream the kept rows: U independent non-temporal 16-byte loads per lane, two batches in flight -------
+    const int g = lane / LPR, cl = lane % LPR;
+    const uint32_t col = (uint32_t)tile * BN + cl * 8;
+    const char* wp = reinterpret_cast<const char*>(a.w0) + (size_t)col * 2;
+    const uint32_t ldb = (uint32_t)a.ld0 * 2u;
+    const char* wp2 = PAIR ? reinterpret_cast<const char*>(a.w1) + (size_t)col * 2 : nullptr;
+    const uint32_t ldb2 = PAIR ? (uint32_t)a.ld1 * 2u : 0u;
+    const float tau_g = a.tau0, tau_u = a.tau1;
+    const bool two_tau = PAIR && (tau_g != tau_u);
+    float acc[8], acc2[PAIR ? 8 : 1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < (PAIR ? 8 : 1); ++j) acc2[j] = 0.0f;
+    {
+        constexpr int STEP = U * RPW;
+        auto full = [&](const int e) { return e + STEP <= nloc; };
+        auto issue = [&](u32x4 (&w)[U], u32x4 (&w2)[PAIR ? U : 1], float (&xv)[U], const int e0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t ent = list[e0 + u * RPW + g];
+                xv[u] = bits_to_float(ent & 0xFFFFu, BF16);
+                w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)(ent >> 16) * ldb));
+                if constexpr (PAIR)
+                    w2[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp2 + (size_t)(ent >> 16) * ldb2));
+            }
+        };
+        auto consume = [&](u32x4 (&w)[U], u32x4 (&w2)[PAIR ? U : 1], float (&xv)[U]) {
+            if (two_tau) {  // a row outside one of the two keep sets: zero weights, exactly a masked load
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float ax = fabsf(xv[u]);
+                    const bool nanx = xv[u] != xv[u];
+                    if (!(ax > tau_g || nanx)) w[u] = u32x4(0u);
+                    if constexpr (PAIR) if (!(ax > tau_u || nanx)) w2[u] = u32x4(0u);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                fma8<BF16>(acc, w[u], xv[u]);
+                if constexpr (PAIR) fma8<BF16>(acc2, w2[u], xv[u]);
+            }
+        };
+        u32x4 wa[U], wbb[U], w2a[PAIR ? U : 1], w2b[PAIR ? U : 1];
+        float xa[U], xb[U];
+        int eb = 0;
+        bool fa = full(eb);
+        bool first_done = false;
+        if (fa) issue(wa, w2a, xa, eb);
+        while (fa) {
+            int ebn = eb + STEP;
+            const bool fb = full(ebn);
+            if (fb) issue(wbb, w2b, xb, ebn);
+            consume(wa, w2a, xa);
+            if constexpr (PHASE) { if (!first_done) { first_done = true; stamp(4); } }
+            eb = ebn;
+            if (!fb) break;
+            ebn = eb + STEP;
+            fa = full(ebn);
+            if (fa) issue(wa, w2a, xa, ebn);
+            consume(wbb, w2b, xb);
+            eb = ebn;
+        }
+        if (eb < nloc) {  // tail: clamp the entry index, zero the weights of clamped lanes
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = eb + u * RPW + g;
+                const bool ok = e < nloc;
+                const uint32_t ent = list[ok ? e : nloc - 1];
+                xa[u] = ok ? bits_to_float(ent & 0xFFFFu, BF16) : 0.0f;
+                u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)(ent >> 16) * ldb));
+                if (!ok) t = u32x4(0u);
+                wa[u] = t;
+                if constexpr (PAIR) {
+                    u32x4 t2 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp2 + (size_t)(ent >> 16) * ldb2));
+                    if (!ok) t2 = u32x4(0u);
+                    w2a[u] = t2;
+                }
+            }
+            consume(wa, w2a, xa);
+        }
+    }
+    stamp(5);
+    if constexpr (PHASE) { if (a.phase && lane == 0) a.phase[(size_t)bid * kPhaseRow + 16 + wave] = wall_clock64(); }
+
+    // ---- reduce: row groups of the wave (shuffles), then waves in fixed order through LDS -------------------
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], off);
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc2[j] += __shfl_xor(acc2[j], off);
+        }
+    }
+    if (lane < LPR) {
+        float* r = red + wave * BN + lane * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = acc[j];
+        if constexpr (PAIR) {
+            float* r2 = red + (WAVES + wave) * BN + lane * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r2[j] = acc2[j];
+        }
+    }
+    __syncthreads();
+    stamp(6);
+    if (tid < BN) {  // whole waves: BN is a multiple of 64
+        const uint32_t c = (uint32_t)tile * BN + tid;
+        float gs = 0.0f, us = 0.0f;
+#pragma unroll
+        for (int wv = 0; wv < WAVES; ++wv) {
+            gs += red[wv * BN + tid];
+            if constexpr (PAIR) us += red[(WAVES + wv) * BN + tid];
+        }
+        if constexpr (PAIR) {
+            // h = silu(gate) * up with the roundings of the unfused sequence (gpt-fast/model.py:258-259), and the keep
+            // masks of h against the down projection's threshold for a MODE 3 consumer
+            const float g16 = bits_to_float(float_to_bits<BF16>(gs), BF16);
+            const float u16 = bits_to_float(float_to_bits<BF16>(us), BF16);
+            const float sl = bits_to_float(float_to_bits<BF16>(g16 / (1.0f + expf(-g16))), BF16);
+            const uint32_t hb = float_to_bits<BF16>(sl * u16);
+            reinterpret_cast<uint16_t*>(a.y)[c] = (uint16_t)hb;
+            const float hv = bits_to_float(hb, BF16);
+            const unsigned long long mko = __ballot(keep_rule(hv, a.mask_tau) || (hv != hv));
+            if (a.mask_out && lane == 0) a.mask_out[c >> 6] = mko;
+        } else if (a.ws_stride == 0) {
+            reinterpret_cast<uint16_t*>(a.y)[c] = float_to_bits<BF16>(gs);
+        } else {
+            a.ws[c * (uint32_t)a.ws_stride + slice] = gs;
+        }
+    }
+    stamp(7);
+    if constexpr (PHASE) {
+        if (a.phase && tid == 0) {
+            unsigned xcc = 0, hwid = 0;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            a.phase[(size_t)bid * kPhaseRow] = t_entry;
+            a.phase[(size_t)bid * kPhaseRow + 12] = ((unsigned long long)hwid << 32) | xcc;
+            a.phase[(size_t)bid * kPhaseRow + 13] = ((unsigned long long)WAVES << 32) | (gridDim.x * gridDim.y);
+        }
+    }
+}
+
+
+template <bool BF16, int MODE, bool PAIR, int LPR, int KR, bool EXACT>
+hipError_t launch_fast_e(const FastLaunch& f, hipStream_t st) {
+    const dim3 grid(f.ntiles, f.split), block(1024);
+    if (f.a.phase) {
+        if constexpr (!BF16) {  // stamped instantiations exist for fp16 only (diagnostics)
+            hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, true>), grid, block, f.lds, st, f.in0, f.in1,
+                               f.in2, f.row_index, f.Z, f.nslabs, f.eps, f.a);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, false>), grid, block, f.lds, st, f.in0, f.in1, f.in2,
+                       f.row_index, f.Z, f.nslabs, f.eps, f.a);
+    return hipGetLastError();
+}
+
+template <bool BF16, int MODE, bool PAIR, int LPR, int KR>
+hipError_t launch_fast_k(const FastLaunch& f, hipStream_t st) {
+    if constexpr (MODE == 1) {
+        if (f.Z == 1024 * KR) return launch_fast_e<BF16, MODE, PAIR, LPR, KR, true>(f, st);
+    }
+    return launch_fast_e<BF16, MODE, PAIR, LPR, KR, false>(f, st);
+}
+
+template <bool BF16, int MODE, bool PAIR, int LPR>
+hipError_t launch_fast_r(const FastLaunch& f, hipStream_t st) {
+    if constexpr (MODE == 1) {
+        switch (f.kr) {
+            case 4: return launch_fast_k<BF16, MODE, PAIR, LPR, 4>(f, st);
+            case 8: return launch_fast_k<BF16, MODE, PAIR, LPR, 8>(f, st);
+            case 16: return launch_fast_k<BF16, MODE, PAIR, LPR, 16>(f, st);
+            default: return hipErrorInvalidValue;
+        }
+    } else {
+        switch (f.kr) {
+            case 1: return launch_fast_k<BF16, MODE, PAIR, LPR, 1>(f, st);
+            case 4: return launch_fast_k<BF16, MODE, PAIR, LPR, 4>(f, st);
+            case 8: return launch_fast_k<BF16, MODE, PAIR, LPR, 8>(f, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
+}
+
+template <bool BF16, int LPR>
+hipError_t launch_fast_m(const FastLaunch& f, hipStream_t st) {
+    if (f.pair) return f.mode == 1 ? launch_fast_r<BF16, 1, true, LPR>(f, st) : hipErrorInvalidValue;
+    switch (f.mode) {
+        case 0: return launch_fast_r<BF16, 0, false, LPR>(f, st);
+        case 1: return launch_fast_r<BF16, 1, false, LPR>(f, st);
+        case 3: return launch_fast_r<BF16, 3, false, LPR>(f, st);
+        case 4: return launch_fast_r<BF16, 4, false, LPR>(f, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <bool BF16>
+hipError_t launch_fast_q(const FastLaunch& f, hipStream_t st) {
+    switch (f.lpr) {
+        case 8: return launch_fast_m<BF16, 8>(f, st);
+        case 16: return launch_fast_m<BF16, 16>(f, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace teal

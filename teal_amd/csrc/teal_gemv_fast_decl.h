@@ -1,0 +1,36 @@
+// teal_gemv_fast_decl.h — argument blocks of the lean sparse GEMV kernel (teal_gemv_fast.h) shared with the host side.
+#pragma once
+#include "teal_common.h"
+
+namespace teal {
+
+struct FastArgs {
+    const void* w0;                 // weight image [Z][ld0]
+    const void* w1;                 // PAIR: the up projection's image [Z][ld1]
+    void* y;                        // rounded output [ncols] (PAIR: h = silu(gate) * up)
+    float* ws;                      // slab output, interleaved [ncols][ws_stride]
+    unsigned long long* mask_out;   // PAIR: keep masks of h vs mask_tau (or null)
+    void* resid_out;                // MODE 1: updated residual stream, written by workgroup (0, 0) (or null)
+    unsigned long long* phase;      // PHASE instantiations: stamp buffer
+    int ld0, ld1;                   // row strides in elements
+    int seg_tile1, seg_tile2;       // first tile of threshold segments 1 and 2 (INT_MAX when absent)
+    float tau0, tau1, tau2;         // thresholds (PAIR: tau0 = gate, tau1 = up)
+    float mask_tau;
+    int ws_stride;                  // (split + 3) & ~3, or 0: round and store y (split == 1)
+    int att_hd, att_ns;             // MODE 4
+    int cap;                        // list entries one wave can own
+};
+
+// Launch description filled by run_gemv when the shape qualifies (teal_kernels.hip: fast_eligible)
+struct FastLaunch {
+    const void* in0; const void* in1; const void* in2; const int* row_index;
+    int Z, nslabs; float eps;
+    FastArgs a;
+    int mode, pair, lpr, kr, ntiles, split;
+    size_t lds;
+};
+
+hipError_t launch_fast_f16(const FastLaunch& f, hipStream_t st);   // teal_gemv_fast_f16.hip
+hipError_t launch_fast_bf16(const FastLaunch& f, hipStream_t st);  // teal_gemv_fast_bf16.hip
+
+}  // namespace teal

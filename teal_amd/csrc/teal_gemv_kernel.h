@@ -66,9 +66,13 @@ __device__ __forceinline__ void fma8(float (&acc)[8], const u32x2 w, const float
 }
 
 
-// optional per-workgroup phase timestamps (constant 100 MHz clock, comparable across CUs)
+// optional per-workgroup phase timestamps (constant 100 MHz clock, comparable across CUs).  Layout: 32 uint64 per
+// workgroup: [0] kernel entry (taken before any kernel argument is used), [1] kernel arguments in registers,
+// [2] activation ready, [3] list ready, [4] first weight batch consumed (wave 0), [5] wave 0 done streaming,
+// [6] after the reduce barrier, [7] done, [12] hw id | xcc, [13] grid | waves << 32, [16 + w] end of stream of wave w
+constexpr int kPhaseRow = 32;
 __device__ __forceinline__ void stamp(const Params& p, int phase) {
-    if (p.phase && threadIdx.x == 0) p.phase[(size_t)blockIdx.x * 8 + phase] = wall_clock64();
+    if (p.phase && threadIdx.x == 0) p.phase[(size_t)blockIdx.x * kPhaseRow + phase] = wall_clock64();
 }
 
 
@@ -84,6 +88,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
     constexpr int T = WAVES * 64;
     constexpr int STRIDE = WAVES * RPW;  // list entries consumed per workgroup step
 
+    const unsigned long long t_entry = wall_clock64();  // before the first use of a kernel argument
     extern __shared__ __align__(16) unsigned char smem[];
     const int Z = p.Z;
     const int nch = (Z + 63) >> 6;
@@ -113,7 +118,8 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
     const int tcol0 = (tile - sg.tile0) * BN;  // first column of the tile inside the segment
 
     const uint16_t* __restrict__ x = reinterpret_cast<const uint16_t*>(p.x);
-    stamp(p, 0);
+    if (p.phase && threadIdx.x == 0) p.phase[(size_t)blockIdx.x * kPhaseRow] = t_entry;
+    stamp(p, 1);
     // int8: the per-column scales are needed only in the epilogue, where a dependent global load would add a full
     // (cold) memory round trip to every launch: thread t fetches the scale of tile column t right now
     uint32_t scb = 0u, scb2 = 0u;
@@ -224,9 +230,11 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
             rv[k] = r;
             ss += r * r;
         }
+        stamp(p, 8);   // loads back, row sums formed
         ss = wave_sum_f(ss);
         if (lane == 0) sumsq[wave] = ss;
         __syncthreads();
+        stamp(p, 9);   // past the producer barrier
         float tot = (lane < WAVES) ? sumsq[lane] : 0.0f;
         tot = wave_sum_f(tot);
         const float rstd = rsqrtf(tot / (float)Z + p.in.eps);
@@ -306,6 +314,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
 #pragma unroll
         for (int k = 0; k < KR; ++k) xr[k] = x[mcl[k]];
     }
+    stamp(p, 2);
     const unsigned long long* gmask = MODE == 3 ? p.in.masks : masks;  // where chunk masks live
     int nloc = 0;                      // entries this wave/workgroup will stream
     const uint32_t* lp = list;         // where they are
@@ -350,12 +359,12 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         lp = mylist;
         estride = RPW;
         eb = 0;
-        stamp(p, 1); stamp(p, 6); stamp(p, 2); stamp(p, 3);
+        stamp(p, 3);
     } else {
             if constexpr (MODE != 3) {
             int mycnt = 0;
         #pragma unroll
-            for (int k = 0; k < KR; ++k) {
+            for (int k = 0; k < GREG * PER; ++k) {  // whole groups of 64 chunks only (the reload loop takes the rest)
                 const int c = (k / PER) * 64 + wave + (k % PER) * WAVES;
                 if (c < nch) {
                     const float v = bits_to_float(xr[k], BF16);
@@ -378,9 +387,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
                 mycnt += __popcll(mask);
             }
             if (lane == 0) wavecnt[wave] = mycnt;
-            stamp(p, 1);
             __syncthreads();
-            stamp(p, 6);
         }
 
         // ---- phase B: every wave scans the chunk popcounts itself (DPP, no second barrier, no serial
@@ -403,7 +410,6 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         const int lo = (int)(((long long)total * slice) / p.split);
         const int hi = (int)(((long long)total * (slice + 1)) / p.split);
         nloc = hi - lo;
-        stamp(p, 7);
         {
             int base = 0;
             auto scatter_group = [&](const int g0, const uint32_t* xg) {
@@ -434,7 +440,6 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
                 if (g * 64 < nch && base < hi) scatter_group(g * 64, &xr[g * PER]);
             for (int g0 = GREG * 64; g0 < nch && base < hi; g0 += 64) scatter_group(g0, nullptr);
         }
-        stamp(p, 2);
         __syncthreads();
         stamp(p, 3);
     }
@@ -521,12 +526,14 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         wvec wa[U], wb[U], w2a[PAIR ? U : 1], w2b[PAIR ? U : 1];
         float xa[U], xb[U];
         bool fa = full(eb);
+        bool first_done = false;
         if (fa) issue(wa, w2a, xa, eb);
         while (fa) {
             int ebn = eb + STEP;
             const bool fb = full(ebn);
             if (fb) issue(wb, w2b, xb, ebn);
             consume(wa, w2a, xa);
+            if (p.phase && !first_done) { first_done = true; stamp(p, 4); }
             eb = ebn;
             if (!fb) break;
             ebn = eb + STEP;
@@ -559,8 +566,8 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         }
     }
 
-    stamp(p, 4);
-    if (p.phase && lane == 0) p.phase[(size_t)gridDim.x * 8 + (size_t)blockIdx.x * 16 + wave] = wall_clock64();  // per-wave end of stream
+    stamp(p, 5);
+    if (p.phase && lane == 0) p.phase[(size_t)blockIdx.x * kPhaseRow + 16 + (wave & 15)] = wall_clock64();  // per-wave end of stream
     // ---- reduce: row groups of the wave, then waves (fixed order) --------------------------------
 #pragma unroll
     for (int off = LPR; off < 64; off <<= 1) {
@@ -594,6 +601,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         }
     }
     __syncthreads();
+    stamp(p, 6);
     // W8: sum q*x = sum (q + 1152)*x - 1152 * sum x (see fma8), then the per-column scale (quantize.py:354: the product is
     // scaled AFTER the reduction; here in fp32 before the single rounding)
     float bias = 0.0f, bias2 = 0.0f;
@@ -655,25 +663,34 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
             }
         }
     }
-    stamp(p, 5);
+    stamp(p, 7);
     if (p.phase && threadIdx.x == 0) {
         unsigned xcc = 0, hwid = 0;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        p.phase[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)hwid << 32) | xcc;
+        p.phase[(size_t)blockIdx.x * kPhaseRow + 12] = ((unsigned long long)hwid << 32) | xcc;
+        p.phase[(size_t)blockIdx.x * kPhaseRow + 13] = ((unsigned long long)WAVES << 32) | gridDim.x;
     }
 }
 
 
 // ---- launch dispatch: runtime (lanes per row, waves, unroll, producer mode, register-cache depth) -> template
 //      instantiation, for one (activation dtype, weight width) quadrant -------------------------------------
+
+// which instantiations exist.  Production geometry: 16-wave workgroups, unroll 4, every tile width / producer / cache
+// depth.  8-wave workgroups and unroll 8 exist for the plain GEMV only (geometry sweeps: measured no better, with 4-wave
+// workgroups worse — the launch is bound by HBM and by instruction issue in the prologue, not by dispatch).
+template <bool W8, int LPR, int WAVES, int U, int MODE, int KRT, bool PAIR>
+constexpr bool variant_built() {
+    if (W8) return WAVES == 16 && U == 4 && LPR <= 32;
+    if (WAVES == 16) return U == 4 || (MODE == 0 && !PAIR);
+    return MODE == 0 && !PAIR && KRT == 16;
+}
+
 template <bool BF16, bool W8, int LPR, int WAVES, int U, int MODE, int KRT, bool PAIR>
 hipError_t launch_gemv_k(const Params& p, size_t lds, hipStream_t st) {
     const dim3 grid(p.ntiles * p.split), block(WAVES * 64);
-    // int8 weights: production geometry only (16 waves, unroll 4, tiles up to 256 columns);
-    // 16-bit weights: the fused variants are built for unroll 4 only
-    constexpr bool built = W8 ? (WAVES == 16 && U == 4 && LPR <= 32) : (U == 4 || (MODE == 0 && !PAIR));
-    if constexpr (built) {
+    if constexpr (variant_built<W8, LPR, WAVES, U, MODE, KRT, PAIR>()) {
         hipLaunchKernelGGL((sparse_gemv_kernel<LPR, WAVES, U, BF16, MODE, KRT, PAIR, W8>), grid, block, lds, st, p);
         return hipGetLastError();
     } else {
@@ -681,30 +698,26 @@ hipError_t launch_gemv_k(const Params& p, size_t lds, hipStream_t st) {
     }
 }
 
-// register-cache depth: smallest KRT with KRT * WAVES * 64 >= Z (16-wave production geometry), or what the
-// wave-local slice needs (p.krt); longer vectors use KRT = 16 plus the reload path
+// register-cache depth: smallest KRT with KRT * WAVES * 64 >= Z, or what the wave-local slice needs (p.krt);
+// longer vectors use KRT = 16 plus the reload path
 template <bool BF16, bool W8, int LPR, int WAVES, int U, int MODE, bool PAIR>
 hipError_t launch_gemv_m(const Params& p, size_t lds, hipStream_t st) {
     if constexpr (WAVES == 16) {
         const int owned = p.krt ? p.krt : (((p.Z + 63) >> 6) + WAVES - 1) / WAVES;
         if (owned <= 4) return launch_gemv_k<BF16, W8, LPR, WAVES, U, MODE, 4, PAIR>(p, lds, st);
         if (owned <= 8) return launch_gemv_k<BF16, W8, LPR, WAVES, U, MODE, 8, PAIR>(p, lds, st);
-        return launch_gemv_k<BF16, W8, LPR, WAVES, U, MODE, 16, PAIR>(p, lds, st);
-    } else {
-        return launch_gemv_k<BF16, W8, LPR, WAVES, U, MODE, 16, PAIR>(p, lds, st);
     }
+    return launch_gemv_k<BF16, W8, LPR, WAVES, U, MODE, 16, PAIR>(p, lds, st);
 }
 
 template <bool BF16, bool W8, int LPR, int WAVES, int U>
 hipError_t launch_gemv_t(const Params& p, size_t lds, hipStream_t st) {
     if (p.in.mode == 0 && !p.pair) return launch_gemv_m<BF16, W8, LPR, WAVES, U, 0, false>(p, lds, st);
-    if constexpr (WAVES == 16 && U == 4) {  // fused variants are built for the production geometry only
-        if (p.pair) return p.in.mode == 1 ? launch_gemv_m<BF16, W8, LPR, WAVES, U, 1, true>(p, lds, st) : hipErrorInvalidValue;
-        if (p.in.mode == 1) return launch_gemv_m<BF16, W8, LPR, WAVES, U, 1, false>(p, lds, st);
-        if (p.in.mode == 2) return launch_gemv_m<BF16, W8, LPR, WAVES, U, 2, false>(p, lds, st);
-        if (p.in.mode == 3) return launch_gemv_m<BF16, W8, LPR, WAVES, U, 3, false>(p, lds, st);
-        if (p.in.mode == 4) return launch_gemv_m<BF16, W8, LPR, WAVES, U, 4, false>(p, lds, st);
-    }
+    if (p.pair) return p.in.mode == 1 ? launch_gemv_m<BF16, W8, LPR, WAVES, U, 1, true>(p, lds, st) : hipErrorInvalidValue;
+    if (p.in.mode == 1) return launch_gemv_m<BF16, W8, LPR, WAVES, U, 1, false>(p, lds, st);
+    if (p.in.mode == 2) return launch_gemv_m<BF16, W8, LPR, WAVES, U, 2, false>(p, lds, st);
+    if (p.in.mode == 3) return launch_gemv_m<BF16, W8, LPR, WAVES, U, 3, false>(p, lds, st);
+    if (p.in.mode == 4) return launch_gemv_m<BF16, W8, LPR, WAVES, U, 4, false>(p, lds, st);
     return hipErrorInvalidValue;
 }
 

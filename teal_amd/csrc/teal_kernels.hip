@@ -11,6 +11,9 @@
 //   kernels/sparse_gemv.py:196-237  qkv_gemv                                           -> teal_sparse_qkv_gemv*
 //   kernels/sparse_gemv.py:8-12     init_to_zero("Y") pre-hook memset                  -> gone
 #include "teal_common.h"
+#include "teal_gemv_fast_decl.h"
+
+#include <limits.h>
 
 namespace teal {
 
@@ -120,8 +123,11 @@ __global__ __launch_bounds__(1024) void compact_kernel(const uint16_t* __restric
 int g_num_cu = 0;
 Config g_override = {0, 0, 0, 0};
 unsigned long long* g_phase = nullptr;
+size_t g_phase_stride = 0;  // > 0: consecutive GEMV launches stamp consecutive regions of this many uint64
+int g_phase_seq = 0;
 int g_swizzle = 0;
 int g_wave_local = 1;
+int g_fast = 1;  // lean kernel (teal_gemv_fast.h) where the shape qualifies
 
 
 size_t lds_bytes(int Z, int cap, int waves, int lpr, bool pair = false) {
@@ -143,7 +149,7 @@ Config pick_config(int Z, int ncols_total, int nseg_tiles_hint) {
     (void)nseg_tiles_hint;
     const int ncu = g_num_cu > 0 ? g_num_cu : 256;
     Config c;
-    c.waves = 16;
+    c.waves = g_override.waves ? g_override.waves : 16;
     c.unroll = 4;
     c.lpr = 0;
     c.split = 1;
@@ -162,7 +168,7 @@ Config pick_config(int Z, int ncols_total, int nseg_tiles_hint) {
                   // wave-local compaction a slice is a set of 16-chunk rounds, so split <= rounds (and <= 8
                   // keeps the slab count small for consumers that re-read them); without it, 512-byte row
                   // segments and a deeper split measured best.
-            const int rounds = (((Z + 63) >> 6) + 15) / 16;
+            const int rounds = (((Z + 63) >> 6) + c.waves - 1) / c.waves;
             if (g_wave_local && rounds >= 2) {
                 c.lpr = 8;
                 const int tiles = (ncols_total + 63) / 64;
@@ -193,6 +199,70 @@ Config pick_config(int Z, int ncols_total, int nseg_tiles_hint) {
 }
 
 
+// Does this launch qualify for the lean kernel (teal_gemv_fast.h)?  16-bit weights, whole chunks and tiles, one weight
+// image (or the gate|up pair), interleaved slabs or a single rounded output, wave-local lists that fit.
+bool fast_eligible(const Params& p, const Config& c, bool to_ws, FastLaunch& f) {
+    if (!g_fast || p.w8 || c.waves != 16 || c.unroll != 4 || (c.lpr != 8 && c.lpr != 16) || p.swizzle) return false;
+    if ((p.Z & 63) || p.Z > 65536 || !p.wl) return false;
+    const int mode = p.in.mode;
+    if (mode != 0 && mode != 1 && mode != 3 && mode != 4) return false;
+    const int bn = c.lpr * 8, nch = p.Z >> 6, owned_all = (nch + 15) / 16;
+    if (to_ws ? (!p.ws_il || c.split > 8) : (c.split != 1)) return false;
+    const int nseg = p.pair ? 2 : p.nseg;
+    int off = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const Seg& sg = p.seg[i];
+        if (sg.ncols % bn) return false;
+        if (p.pair) continue;
+        if (sg.w != p.seg[0].w || sg.ld != p.seg[0].ld || sg.col0 != p.seg[0].col0 + off) return false;
+        if (!to_ws && reinterpret_cast<const uint16_t*>(sg.y) != reinterpret_cast<const uint16_t*>(p.seg[0].y) + off) return false;
+        off += sg.ncols;
+    }
+    if (p.pair && (mode != 1 || p.seg[0].ncols != p.seg[1].ncols)) return false;
+    int kr, rounds_owned;
+    if (mode == 1) {
+        if (owned_all > 16 || c.split > owned_all) return false;
+        kr = owned_all <= 4 ? 4 : (owned_all <= 8 ? 8 : 16);
+        rounds_owned = (kr + c.split - 1) / c.split;
+    } else {
+        const int need = (owned_all + c.split - 1) / c.split;
+        if (need > 8 || c.split > owned_all) return false;
+        kr = need <= 1 ? 1 : (need <= 4 ? 4 : 8);
+        rounds_owned = need;
+        if (mode == 4 && kr * p.in.att_ns > 64) return false;
+    }
+    f = FastLaunch{};
+    f.a.cap = rounds_owned * 64;
+    f.lds = 64 + (size_t)16 * f.a.cap * 4 + (size_t)16 * bn * 4 * (p.pair ? 2 : 1);
+    if (f.lds > 64 * 1024) return false;
+    f.mode = mode; f.pair = p.pair; f.lpr = c.lpr; f.kr = kr; f.ntiles = p.ntiles; f.split = c.split;
+    f.Z = p.Z; f.nslabs = p.in.nslabs; f.eps = p.in.eps;
+    switch (mode) {
+        case 1: f.in0 = p.in.resid_in; f.in1 = p.in.slabs; f.in2 = p.in.norm_w; f.row_index = p.in.row_index;
+                if (p.in.nslabs > 0 && !p.in.slabs_il) return false;
+                if (p.in.nslabs > 8) return false;
+                break;
+        case 3: f.in0 = p.x; f.in1 = p.in.masks; break;
+        case 4: f.in0 = p.in.att; f.a.att_hd = p.in.att_hd; f.a.att_ns = p.in.att_ns; break;
+        default: f.in0 = p.x; break;
+    }
+    f.a.w0 = reinterpret_cast<const uint16_t*>(p.seg[0].w) + p.seg[0].col0;
+    f.a.ld0 = p.seg[0].ld;
+    f.a.w1 = p.pair ? reinterpret_cast<const uint16_t*>(p.seg[1].w) + p.seg[1].col0 : nullptr;
+    f.a.ld1 = p.pair ? p.seg[1].ld : 0;
+    f.a.y = p.seg[0].y;
+    f.a.ws = p.ws;
+    f.a.mask_out = p.mask_out;
+    f.a.mask_tau = p.mask_tau;
+    f.a.resid_out = p.in.resid_out;
+    f.a.phase = p.phase;
+    f.a.tau0 = p.seg[0].tau; f.a.tau1 = p.seg[1].tau; f.a.tau2 = p.seg[2].tau;
+    f.a.seg_tile1 = (!p.pair && p.nseg > 1) ? p.seg[1].tile0 : INT_MAX;
+    f.a.seg_tile2 = (!p.pair && p.nseg > 2) ? p.seg[2].tile0 : INT_MAX;
+    f.a.ws_stride = to_ws ? ((c.split + 3) & ~3) : 0;
+    return true;
+}
+
 // one translation unit per (weight width, dtype): see teal_common.h
 inline hipError_t launch_gemv(const Params& p, int dtype, size_t lds, const Config& c, hipStream_t st) {
     if (p.w8) return dtype == TEAL_BF16 ? launch_gemv_w8_bf16(p, lds, c, st) : launch_gemv_w8_f16(p, lds, c, st);
@@ -215,7 +285,7 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
         // (7B: 529 -> 518 tok/s), hence the size gate.
         const int ncu = g_num_cu > 0 ? g_num_cu : 256;
         const int tiles = (total_cols + 127) / 128;
-        const int rounds = (((p.Z + 63) >> 6) + 15) / 16;
+        const int rounds = (((p.Z + 63) >> 6) + c.waves - 1) / c.waves;
         int split = ncu / tiles;
         if (split > rounds) split = rounds;
         if (split > 8) split = 8;
@@ -265,11 +335,11 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
         for (int i = 0; i < (p.pair ? 2 : p.nseg); ++i)
             if (!p.seg[i].scale || (p.seg[i].ld & 7) || (p.seg[i].col0 & 7)) return TEAL_ERR_ARG;
     }
-    if (p.in.mode != 0 || p.pair || p.w8) {  // fused / int8 variants exist for 16-wave workgroups
+    if (p.w8 || p.in.mode != 0 || p.pair) {  // fused / int8 variants exist for 16-wave workgroups
         c.waves = 16;
         c.unroll = 4;
-        if ((p.in.mode == 1 || p.in.mode == 4) && p.Z > 16 * 64 * 16) return TEAL_ERR_SHAPE;  // register-resident producer
     }
+    if ((p.in.mode == 1 || p.in.mode == 4) && p.Z > c.waves * 64 * 16) return TEAL_ERR_SHAPE;  // register-resident producer
     if (p.pair) {  // both matrices in one workgroup; the activation needs complete sums: no split-K
         c.split = 1;
         if ((size_t)(p.Z + 1) * 4 > 44 * 1024) return TEAL_ERR_SHAPE;
@@ -299,23 +369,30 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
     p.krt = 0;
     if (g_wave_local && c.waves == 16) {
         const int nch = (p.Z + 63) >> 6;
-        const int owned = (nch + 15) / 16;  // rounds of 16 chunks
+        const int owned = (nch + c.waves - 1) / c.waves;  // rounds of `waves` chunks
         // element-wise producers (everything but the RMSNorm, which needs the whole vector in every workgroup)
         // cache only the rounds of the workgroup's slice
         const bool slice_local = p.in.mode != 1 && c.split > 1;
         const int need = slice_local ? (owned + c.split - 1) / c.split : owned;
         const int krt = need <= 4 ? 4 : (need <= 8 ? 8 : 16);
         const int capw = (slice_local ? need : (krt + c.split - 1) / c.split) * 64;  // entries one wave can own
-        if (need <= krt && c.split <= owned && (size_t)16 * capw * 4 <= 40 * 1024) {
+        const bool merge_ok = p.in.mode != 4 || krt * p.in.att_ns <= 64;  // one lane per (chunk, split) in the merge
+        if (need <= krt && c.split <= owned && (size_t)c.waves * capw * 4 <= 40 * 1024 && merge_ok) {
             p.wl = 1;
             p.sl = slice_local ? 1 : 0;
             p.krt = krt;
             p.cap = capw;
         }
     }
+    if (p.in.mode == 4) {  // the merge producer holds one lane per (cached chunk, split): cache depth x splits <= 64
+        const int owned_all = (((p.Z + 63) >> 6) + c.waves - 1) / c.waves;
+        const int kr = p.krt ? p.krt : (owned_all <= 4 ? 4 : (owned_all <= 8 ? 8 : 16));
+        if (kr * p.in.att_ns > 64 || (!p.wl && owned_all > kr)) return TEAL_ERR_SHAPE;
+    }
     p.to_ws = to_ws ? 1 : 0;
     p.ws = reinterpret_cast<float*>(ws);
-    p.phase = g_phase;
+    p.phase = g_phase ? g_phase + (size_t)g_phase_seq * g_phase_stride : nullptr;
+    if (g_phase && g_phase_stride) ++g_phase_seq;
     p.swizzle = g_swizzle;
     const size_t lds = lds_bytes(p.Z, p.wl ? p.cap * c.waves : p.cap, c.waves, c.lpr, p.pair != 0);
     if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
@@ -326,6 +403,13 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
         if (!aligned16(ws)) return TEAL_ERR_ALIGN;
     }
     if (used) *used = c;
+    {
+        FastLaunch f;
+        if (fast_eligible(p, c, to_ws, f)) {
+            const hipError_t e = dtype == TEAL_BF16 ? launch_fast_bf16(f, st) : launch_fast_f16(f, st);
+            return e == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
+        }
+    }
     if (launch_gemv(p, dtype, lds, c, st) != hipSuccess) return TEAL_ERR_LAUNCH;
     if (c.split > 1 && !to_ws) {
         const dim3 grid((off + 255) / 256), block(256);
@@ -403,6 +487,11 @@ int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll) {
     return TEAL_OK;
 }
 
+int teal_set_fast(int on) {
+    g_fast = on ? 1 : 0;
+    return TEAL_OK;
+}
+
 int teal_set_wave_local(int on) {
     g_wave_local = on ? 1 : 0;
     return TEAL_OK;
@@ -415,6 +504,13 @@ int teal_set_swizzle(int on) {
 
 int teal_set_phase_buffer(void* dev_u64) {
     g_phase = reinterpret_cast<unsigned long long*>(dev_u64);
+    g_phase_seq = 0;
+    return TEAL_OK;
+}
+
+int teal_set_phase_stride(size_t u64_per_launch) {
+    g_phase_stride = u64_per_launch;
+    g_phase_seq = 0;
     return TEAL_OK;
 }
 
