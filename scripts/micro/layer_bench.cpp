@@ -410,11 +410,11 @@ int main(int argc, char** argv) {
     if (phase) {
         // phase stamps (teal_set_phase_buffer + teal_set_phase_stride: 32 uint64 per workgroup, one region per launch) of the
         // GEMV launches of one middle layer, taken in flight: the real chain runs before and after on the same stream
-        const size_t region = (size_t)1024 * 32; const int nreg = 5;
+        const size_t region = (size_t)1024 * 32; const int nreg = 6;
         unsigned long long* ph; CK(hipMalloc(&ph, region * nreg * 8));
         std::vector<unsigned long long> hp(region * nreg);
         const int li = n_layer / 2;
-        const char* sn[5] = {"qkv", "wo", "gate|up", "down", "qkv+1"};
+        const char* sn[6] = {"qkv", "attn", "wo", "gate|up", "down", "qkv+1"};
         std::vector<std::vector<std::vector<double>>> rows(nreg);
         std::vector<std::vector<double>> wave_end(nreg);
         std::vector<int> nwgs(nreg, 0), nwaves(nreg, 0);

@@ -6,6 +6,8 @@
 
 namespace teal {
 
+constexpr int kPhaseRowA = 32;  // phase-stamp row of the split attention kernel (same layout as the GEMV's)
+
 // ------------------------------------------------------------------------------------------------
 // Single-token attention over a static KV cache (the step between gemv1 and gemv2 of
 // gpt-fast/model.py:163-190): RoPE on q and the new k, KV-cache append, softmax(q K^T / sqrt(d)) V.
@@ -196,76 +198,102 @@ __global__ __launch_bounds__(NT) void decode_attention_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// Long contexts: split the cached positions of a head over `nsplit` workgroups (flash-decoding).
-// Each workgroup produces an un-normalised partial {running max m, sum l, o[hd]} over its range; the
-// merge kernel rescales and sums them, rounds once and emits the keep masks for the wo projection.
-// With one workgroup per head a 4k context would leave 224 CUs idle while 32 stream 2 MB each.
+// Split-KV decode attention (flash-decoding): the cached positions of a head are dealt to `nsplit` workgroups in
+// groups of STEP = (waves x rows per wave) rows, round-robin (group g belongs to workgroup g mod nsplit), so that
+//   * the work is balanced at every position without knowing it, and
+//   * the K/V rows a workgroup will read do NOT depend on *pos: the first PF row groups of K and V, the q/k/v
+//     projection (rounded, or the fp32 split-K slabs of the projection launch) and *pos itself are all requested at
+//     the first instruction — one memory round trip before RoPE instead of three dependent ones (pos -> addresses ->
+//     rows).  The pointer arguments are scalar kernel parameters preloaded into SGPRs (teal_amd/_lib.py: PRELOAD).
+// Each workgroup writes an un-normalised partial {running max m, sum l, o[hd]}; the wo projection's merge producer
+// (or the merge kernel) rescales and sums them and rounds once.
 // ------------------------------------------------------------------------------------------------
 template <bool BF16, int HD, int NT>
 __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
-    const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ rope, const int* __restrict__ pos_ptr,
-    uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache, float* __restrict__ partials,
-    const int n_head, const int n_kv, const int max_seq, const int nsplit, const int chunk_max, const float scale,
-    const float* __restrict__ qkv_slabs, const int qkv_nslabs) {
+    const int* __restrict__ pos_ptr, const float* __restrict__ qkv_slabs, uint16_t* __restrict__ k_cache,
+    uint16_t* __restrict__ v_cache, const uint16_t* __restrict__ qkv, float* __restrict__ partials,
+    const uint16_t* __restrict__ rope, const int n_head, const int n_kv, const int max_seq, const int nsplit,
+    const float scale, const int qkv_nslabs, unsigned long long* __restrict__ phase) {
     constexpr int NW = NT / 64, hd = HD, SL = HD / 8, RW = 64 / SL;
+    constexpr int PF = 4, STEP = NW * RW;
+    const unsigned long long t_entry = wall_clock64();
+    auto stamp_p = [&](const int i) { if (phase && threadIdx.x == 0) phase[(size_t)blockIdx.x * kPhaseRowA + i] = wall_clock64(); };
     extern __shared__ __align__(16) unsigned char smem[];
     float* qs = reinterpret_cast<float*>(smem);
     float* kn = qs + hd;
     float* vn = kn + hd;
     float* red = vn + hd;            // [2 * NW]
     float* part = red + 2 * NW;      // [NW][hd]
-    float* sc = part + NW * hd;      // [chunk_max]
+    float* sc = part + NW * hd;      // [local steps][STEP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
     const int rep = n_head / n_kv, kvh = h / rep;
+    const int dim = n_head * hd, kvs = n_kv * hd;
+    uint16_t* kc = k_cache + (size_t)kvh * max_seq * hd;
+    uint16_t* vc = v_cache + (size_t)kvh * max_seq * hd;
+    // lanes = (row rw, 16-byte slice ds): a wave load covers RW whole cache rows (coalesced)
+    const int ds = lane % SL, rw = lane / SL;
+    const int rbase = wave * RW + rw;                  // row inside a step
+    auto row_of = [&](const int i) { return (sp + i * nsplit) * STEP + rbase; };  // local step i -> cache row
+    u32x4 kreg[PF], vreg[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+        const size_t off = (size_t)min(row_of(i), max_seq - 1) * hd + ds * 8;
+        kreg[i] = *reinterpret_cast<const u32x4*>(kc + off);
+        vreg[i] = *reinterpret_cast<const u32x4*>(vc + off);
+    }
+    // q, k, v of this head: the rounded projection, or its fp32 split-K slabs, interleaved [col][(nslabs + 3) & ~3],
+    // summed in slice order and rounded once here (what the ordered reduce launch would have written)
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int sstride = (qkv_nslabs + 3) & ~3;
+    auto raw_at = [&](const int col, f32x4& a, f32x4& b, uint16_t& r) {
+        if (qkv_slabs) {
+            const float* p = qkv_slabs + (size_t)col * sstride;
+            a = *reinterpret_cast<const f32x4*>(p);
+            b = qkv_nslabs > 4 ? *reinterpret_cast<const f32x4*>(p + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        } else {
+            r = qkv[col];
+        }
+    };
+    auto fin_at = [&](const f32x4& a, const f32x4& b, const uint16_t r) -> float {
+        if (!qkv_slabs) return bits_to_float(r, BF16);
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += (j < qkv_nslabs) ? a[j] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += (4 + j < qkv_nslabs) ? b[j] : 0.0f;
+        return bits_to_float(float_to_bits<BF16>(s), BF16);
+    };
+    f32x4 la[4], lb[4];
+    uint16_t lr[4] = {0, 0, 0, 0};
+    const bool rot = tid < hd / 2, vld = tid >= 128 && tid < 128 + hd;
+    if (rot) {
+        raw_at(h * hd + 2 * tid, la[0], lb[0], lr[0]);
+        raw_at(h * hd + 2 * tid + 1, la[1], lb[1], lr[1]);
+        raw_at(dim + kvh * hd + 2 * tid, la[2], lb[2], lr[2]);
+        raw_at(dim + kvh * hd + 2 * tid + 1, la[3], lb[3], lr[3]);
+    } else if (vld) {
+        raw_at(dim + kvs + kvh * hd + (tid - 128), la[0], lb[0], lr[0]);
+    }
     const int pos = min(max(pos_ptr[0], 0), max_seq - 1), n = pos + 1;  // clamped: never writes past the cache
-    const int chunk = (n + nsplit - 1) / nsplit;
-    const int t0 = sp * chunk, t1 = min(n, t0 + chunk);
     float* out = partials + (size_t)blockIdx.x * (hd + 2);
-    if (t0 >= t1) {  // empty range (short sequence, many splits)
+    if (phase && threadIdx.x == 0) { phase[(size_t)blockIdx.x * kPhaseRowA] = t_entry; phase[(size_t)blockIdx.x * kPhaseRowA + 13] = ((unsigned long long)NW << 32) | gridDim.x; }
+    stamp_p(1);
+    if (sp * STEP >= n) {  // no row group of this workgroup is in range yet (short sequence, many splits)
         if (tid < hd) out[2 + tid] = 0.0f;
         if (tid == 0) { out[0] = -INFINITY; out[1] = 0.0f; }
         return;
     }
-    const bool has_new = (t1 == n);  // this workgroup's range ends with the token being decoded
-    const int dim = n_head * hd, kvs = n_kv * hd;
-    const uint16_t* qh = qkv + (size_t)h * hd;
-    const uint16_t* kh = qkv + dim + (size_t)kvh * hd;
-    const uint16_t* vh = qkv + dim + kvs + (size_t)kvh * hd;
-    uint16_t* kc = k_cache + (size_t)kvh * max_seq * hd;
-    uint16_t* vc = v_cache + (size_t)kvh * max_seq * hd;
-    // lanes = (row rw, 16-byte slice ds): a wave load covers RW whole cache rows (coalesced).  The cached
-    // rows depend only on pos, not on this step's q: the first PF row groups of K AND V are requested
-    // before anything else, so their latency hides behind the q/rope loads, the rope and both barriers.
-    const int ds = lane % SL, rw = lane / SL;
-    constexpr int PF = 4, STEP = NW * RW;
-    const int trow = t0 + wave * RW + rw;
-    u32x4 kreg[PF], vreg[PF];
-#pragma unroll
-    for (int i = 0; i < PF; ++i) {
-        const int t = trow + i * STEP;
-        const size_t off = (size_t)((t < t1 && t != pos) ? t : t0) * hd + ds * 8;
-        kreg[i] = *reinterpret_cast<const u32x4*>(kc + off);
-        vreg[i] = *reinterpret_cast<const u32x4*>(vc + off);
-    }
-    // element `col` of the qkv projection: the rounded vector, or (qkv_slabs) the fp32 split-K slabs of the
-    // projection launch, interleaved [col][(nslabs + 3) & ~3], summed in slice order and rounded once here —
-    // a narrow (GQA) wqkv can then be row-sliced over all CUs without a reduce launch in between
-    auto qkv_at = [&](const uint16_t* base, const int i) -> uint16_t {
-        if (!qkv_slabs) return base[i];
-        const float* sp = qkv_slabs + (size_t)((base - qkv) + i) * ((qkv_nslabs + 3) & ~3);
-        float a = 0.0f;
-        for (int q = 0; q < qkv_nslabs; ++q) a += sp[q];
-        return float_to_bits<BF16>(a);
-    };
-    if (tid < hd / 2) {
+    const int nsteps = ((n + STEP - 1) / STEP - sp + nsplit - 1) / nsplit;  // local steps with a row in range
+    const bool has_new = ((pos / STEP) % nsplit) == sp;  // this workgroup's rows include the token being decoded
+    if (rot) {
         const float c = bits_to_float(rope[((size_t)pos * (hd / 2) + tid) * 2], BF16);
         const float sn = bits_to_float(rope[((size_t)pos * (hd / 2) + tid) * 2 + 1], BF16);
-        const float q0 = bits_to_float(qkv_at(qh, 2 * tid), BF16), q1 = bits_to_float(qkv_at(qh, 2 * tid + 1), BF16);
+        const float q0 = fin_at(la[0], lb[0], lr[0]), q1 = fin_at(la[1], lb[1], lr[1]);
         qs[2 * tid] = bits_to_float(float_to_bits<BF16>(q0 * c - q1 * sn), BF16);
         qs[2 * tid + 1] = bits_to_float(float_to_bits<BF16>(q1 * c + q0 * sn), BF16);
         if (has_new) {
-            const float k0 = bits_to_float(qkv_at(kh, 2 * tid), BF16), k1 = bits_to_float(qkv_at(kh, 2 * tid + 1), BF16);
+            const float k0 = fin_at(la[2], lb[2], lr[2]), k1 = fin_at(la[3], lb[3], lr[3]);
             const uint16_t ka = float_to_bits<BF16>(k0 * c - k1 * sn), kb = float_to_bits<BF16>(k1 * c + k0 * sn);
             kn[2 * tid] = bits_to_float(ka, BF16);
             kn[2 * tid + 1] = bits_to_float(kb, BF16);
@@ -274,18 +302,20 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
                 kc[(size_t)pos * hd + 2 * tid + 1] = kb;
             }
         }
-    } else if (has_new && tid >= 128 && tid < 128 + hd) {
+    } else if (has_new && vld) {
         const int d = tid - 128;
-        const uint16_t vb = qkv_at(vh, d);
-        vn[d] = bits_to_float(vb, BF16);
-        if (h % rep == 0) vc[(size_t)pos * hd + d] = vb;
+        const float vf = fin_at(la[0], lb[0], lr[0]);
+        vn[d] = vf;
+        if (h % rep == 0) vc[(size_t)pos * hd + d] = float_to_bits<BF16>(vf);
     }
     __syncthreads();
+    stamp_p(2);
     float qv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) qv[j] = qs[ds * 8 + j];
     float lmax = -INFINITY;
-    auto score_row = [&](const int t, const u32x4 w) {
+    auto score_row = [&](const int i, const u32x4 w) {
+        const int t = row_of(i);
         float a = 0.0f;
         if (t == pos) {
 #pragma unroll
@@ -299,43 +329,48 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
         }
         a = row_slices_sum<SL>(a);
         const float sv = bits_to_float(float_to_bits<BF16>(a * scale), BF16);
-        if (t < t1) {
-            if (ds == 0) sc[t - t0] = sv;
+        if (t < n) {
+            if (ds == 0) sc[i * STEP + rbase] = sv;
             lmax = fmaxf(lmax, sv);
         }
     };
 #pragma unroll
     for (int i = 0; i < PF; ++i)
-        if (t0 + i * STEP < t1) score_row(trow + i * STEP, kreg[i]);  // workgroup-uniform guard
+        if (i < nsteps) score_row(i, kreg[i]);  // workgroup-uniform guard
 #pragma unroll 4
-    for (int tb = t0 + PF * STEP; tb < t1; tb += STEP) {
-        const int t = tb + wave * RW + rw;
-        score_row(t, *reinterpret_cast<const u32x4*>(kc + (size_t)((t < t1 && t != pos) ? t : t0) * hd + ds * 8));
-    }
+    for (int i = PF; i < nsteps; ++i)
+        score_row(i, *reinterpret_cast<const u32x4*>(kc + (size_t)min(row_of(i), max_seq - 1) * hd + ds * 8));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, d));
     if (lane == 0) red[wave] = lmax;
     __syncthreads();
+    stamp_p(3);
     float mx = red[0];
 #pragma unroll
     for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w]);
     float lsum = 0.0f;
-    for (int t = t0 + tid; t < t1; t += NT) {
-        const float e = expf(sc[t - t0] - mx);
-        sc[t - t0] = e;
-        lsum += e;
+    for (int e = tid; e < nsteps * STEP; e += NT) {
+        const int t = (sp + (e / STEP) * nsplit) * STEP + (e % STEP);
+        if (t < n) {
+            const float ex = expf(sc[e] - mx);
+            sc[e] = ex;
+            lsum += ex;
+        }
     }
     lsum = wave_sum_f(lsum);
     if (lane == 0) red[NW + wave] = lsum;
     __syncthreads();
+    stamp_p(4);
     float tot = 0.0f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) tot += red[NW + w];
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = 0.0f;
-    auto pv_row = [&](const int t, const u32x4 w) {
-        const float pr = sc[t - t0];
+    auto pv_row = [&](const int i, const u32x4 w) {
+        const int t = row_of(i);
+        if (t >= n) return;
+        const float pr = sc[i * STEP + rbase];
         if (t == pos) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += pr * vn[ds * 8 + j];
@@ -349,9 +384,10 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
     };
 #pragma unroll
     for (int i = 0; i < PF; ++i)
-        if (trow + i * STEP < t1) pv_row(trow + i * STEP, vreg[i]);
+        if (i < nsteps) pv_row(i, vreg[i]);
 #pragma unroll 4
-    for (int t = trow + PF * STEP; t < t1; t += STEP) pv_row(t, *reinterpret_cast<const u32x4*>(vc + (size_t)t * hd + ds * 8));
+    for (int i = PF; i < nsteps; ++i)
+        pv_row(i, *reinterpret_cast<const u32x4*>(vc + (size_t)min(row_of(i), max_seq - 1) * hd + ds * 8));
     for (int off = SL; off < 64; off <<= 1) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] += __shfl_xor(o[j], off);
@@ -361,6 +397,7 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
         for (int j = 0; j < 8; ++j) part[wave * hd + lane * 8 + j] = o[j];
     }
     __syncthreads();
+    stamp_p(5);
     if (tid < hd) {
         float acc = 0.0f;
 #pragma unroll
@@ -368,6 +405,7 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
         out[2 + tid] = acc;
     }
     if (tid == 0) { out[0] = mx; out[1] = tot; }
+    stamp_p(7);
 }
 
 template <bool BF16>
@@ -793,10 +831,13 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
         return TEAL_ERR_SHAPE;
     if (partials_bytes < (size_t)n_head * nsplit * (head_dim + 2) * sizeof(float)) return TEAL_ERR_WORKSPACE;
     const int chunk_max = (max_seq + nsplit - 1) / nsplit;
-    // bandwidth of one workgroup = bytes in flight / latency: long shares get 16 waves (the whole K and V
-    // share of up to 256 rows is requested up front), short ones 4 waves (cheaper barriers)
+    // bandwidth of one workgroup = bytes in flight / latency: long shares get 16 waves, short ones 4 waves (cheaper
+    // barriers).  Rows are dealt to the workgroups of a head in groups of STEP = waves x rows-per-wave, round-robin.
     const int nt = chunk_max > 128 ? 1024 : 256;
-    const size_t lds = (size_t)(3 * head_dim + 2 * (nt / 64) + (nt / 64) * head_dim + chunk_max) * sizeof(float);
+    const int step = (nt / 64) * (64 / (head_dim / 8));
+    const int steps_total = (max_seq + step - 1) / step;
+    const int local_steps = (steps_total + nsplit - 1) / nsplit;
+    const size_t lds = (size_t)(3 * head_dim + 2 * (nt / 64) + (nt / 64) * head_dim + local_steps * step) * sizeof(float);
     if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const float scale = 1.0f / sqrtf((float)head_dim);
@@ -806,7 +847,9 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
     auto* vc = reinterpret_cast<uint16_t*>(v_cache);
     auto* pw = reinterpret_cast<float*>(partials);
     const dim3 grid(n_head * nsplit), block(nt);
-#define TEAL_ATTS(BF, HDV, NTV) hipLaunchKernelGGL((decode_attention_split_kernel<BF, HDV, NTV>), grid, block, lds, st, q, r, pos, kc, vc, pw, n_head, n_kv_head, max_seq, nsplit, chunk_max, scale, qkv_slabs, qkv_nslabs)
+    // stride mode (teal_set_phase_stride): the attention launch takes the next region like a GEMV launch does
+    unsigned long long* ph = (g_phase && g_phase_stride) ? g_phase + (size_t)g_phase_seq++ * g_phase_stride : nullptr;
+#define TEAL_ATTS(BF, HDV, NTV) hipLaunchKernelGGL((decode_attention_split_kernel<BF, HDV, NTV>), grid, block, lds, st, pos, qkv_slabs, kc, vc, q, pw, r, n_head, n_kv_head, max_seq, nsplit, scale, qkv_nslabs, ph)
 #define TEAL_ATTS_NT(BF, HDV) do { if (nt == 1024) TEAL_ATTS(BF, HDV, 1024); else TEAL_ATTS(BF, HDV, 256); } while (0)
     if (dtype == TEAL_BF16) { if (head_dim == 128) TEAL_ATTS_NT(true, 128); else TEAL_ATTS_NT(true, 64); }
     else { if (head_dim == 128) TEAL_ATTS_NT(false, 128); else TEAL_ATTS_NT(false, 64); }
