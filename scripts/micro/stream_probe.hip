@@ -1,0 +1,104 @@
+// stream_probe — what HBM rate does the kept-row gather pattern of the sparse GEMV reach on MI355X, by weight layout?
+//   A  row-major  W^T [Z][ld]          : workgroup t reads 128 B of every kept row (stride ld*2 bytes between rows)
+//   B  tile-major [tile][Z][64]        : workgroup t reads 128 B pieces of ITS OWN contiguous 512 KB region
+//   C  contiguous                      : every workgroup streams a contiguous share (the chip's read ceiling)
+// hipcc --offload-arch=gfx950 -O3 scripts/micro/stream_probe.hip -o scripts/micro/stream_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP %s @%d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// lists: [16 waves][cap] row ids per wave (same for every workgroup, like one activation mask)
+template <int MODE, int NMAT, bool NT>
+__global__ __launch_bounds__(1024) void probe(const char* __restrict__ w0, const char* __restrict__ w1, const int* __restrict__ lists,
+                                              const int* __restrict__ counts, int cap, size_t ldb, size_t tile_bytes, unsigned* sink) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, cl = lane & 7;
+    const int tile = blockIdx.x;
+    const int n = counts[wave];
+    const int* lp = lists + wave * cap;
+    u32x4 acc = {0, 0, 0, 0};
+    auto ld = [&](const char* base, int row) {
+        const char* p;
+        if (MODE == 0) p = base + (size_t)row * ldb + (size_t)tile * 128 + cl * 16;
+        else p = base + (size_t)tile * tile_bytes + (size_t)row * 128 + cl * 16;
+        return NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)) : *reinterpret_cast<const u32x4*>(p);
+    };
+    int e = 0;
+    for (; e + 32 <= n; e += 32) {
+        u32x4 v[4 * NMAT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = lp[e + u * 8 + g];
+            v[u] = ld(w0, row);
+            if (NMAT == 2) v[4 + u] = ld(w1, row);
+        }
+#pragma unroll
+        for (int u = 0; u < 4 * NMAT; ++u) acc ^= v[u];
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
+}
+
+__global__ __launch_bounds__(1024) void contig(const char* __restrict__ w, size_t bytes_per_wg, unsigned* sink) {
+    const char* p = w + (size_t)blockIdx.x * bytes_per_wg + threadIdx.x * 16;
+    u32x4 acc = {0, 0, 0, 0};
+    for (size_t o = 0; o + 4 * 16384 <= bytes_per_wg; o += 4 * 16384) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + o + u * 16384));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc ^= v[u];
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
+}
+
+int main() {
+    const int Z = 4096, N = 11008, tiles = N / 64, ld = N + 64, NBUF = 6;
+    const size_t mat = (size_t)Z * 128 * 272;  // >= row-major image and 256 tile-major regions
+    std::vector<char*> bufs(2 * NBUF);
+    for (auto& b : bufs) { CK(hipMalloc(&b, mat)); CK(hipMemset(b, 1, mat)); }
+    // one mask: wave w owns chunks w, w+16, w+32, w+48; keep ~50 %
+    std::vector<int> lists(16 * 256), counts(16, 0);
+    unsigned s = 12345;
+    for (int w = 0; w < 16; ++w)
+        for (int k = 0; k < 4; ++k)
+            for (int i = 0; i < 64; ++i) { s = s * 1664525u + 1013904223u; if ((s >> 16) & 1) lists[w * 256 + counts[w]++] = (w + 16 * k) * 64 + i; }
+    int total = 0; for (int c : counts) total += c / 32 * 32;
+    int *dl, *dc; unsigned* sink;
+    CK(hipMalloc(&dl, lists.size() * 4)); CK(hipMalloc(&dc, 64)); CK(hipMalloc(&sink, 4));
+    CK(hipMemcpy(dl, lists.data(), lists.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dc, counts.data(), 64, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto timeit = [&](const char* name, auto&& launch, double bytes) {
+        for (int i = 0; i < NBUF; ++i) launch(i);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        const int reps = 10 * NBUF;
+        for (int i = 0; i < reps; ++i) launch(i % NBUF);
+        CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1000.0 / reps;
+        printf("%-44s %7.2f us/launch  %6.2f TB/s (incl. launch boundary)\n", name, us, bytes / us / 1e6);
+    };
+    const double b1 = (double)total * 128 * tiles, b2 = 2 * b1;
+    printf("kept rows %d of %d; %d tiles; bytes per launch: single %.1f MB, pair %.1f MB\n", total, Z, tiles, b1 / 1e6, b2 / 1e6);
+    for (int grid : {172, 256}) {
+        const int t = grid;  // 256: pretend N = 16384 columns (buffers are large enough only for tile-major if t <= tiles): clamp
+        if (t > tiles) continue;
+        (void)t;
+    }
+    timeit("A row-major   pair  nt", [&](int i) { hipLaunchKernelGGL((probe<0, 2, true>), dim3(tiles), dim3(1024), 0, 0, bufs[2 * i], bufs[2 * i + 1], dl, dc, 256, (size_t)ld * 2, 0, sink); }, b2);
+    timeit("B tile-major  pair  nt", [&](int i) { hipLaunchKernelGGL((probe<1, 2, true>), dim3(tiles), dim3(1024), 0, 0, bufs[2 * i], bufs[2 * i + 1], dl, dc, 256, 0, (size_t)Z * 128, sink); }, b2);
+    timeit("A row-major   pair  default policy", [&](int i) { hipLaunchKernelGGL((probe<0, 2, false>), dim3(tiles), dim3(1024), 0, 0, bufs[2 * i], bufs[2 * i + 1], dl, dc, 256, (size_t)ld * 2, 0, sink); }, b2);
+    timeit("A row-major   single nt (172 wgs)", [&](int i) { hipLaunchKernelGGL((probe<0, 1, true>), dim3(tiles), dim3(1024), 0, 0, bufs[2 * i], bufs[2 * i + 1], dl, dc, 256, (size_t)ld * 2, 0, sink); }, b1);
+    timeit("B tile-major  single nt (172 wgs)", [&](int i) { hipLaunchKernelGGL((probe<1, 1, true>), dim3(tiles), dim3(1024), 0, 0, bufs[2 * i], bufs[2 * i + 1], dl, dc, 256, 0, (size_t)Z * 128, sink); }, b1);
+    // 256 workgroups on a matrix region of 256 tiles x 64 columns: treat each buffer as [Z][256 * 64 + pad]? not enough
+    // columns in N = 11008; use the tile-major form, where a "tile" is just a 512 KB region: 256 regions fit a buffer
+    timeit("B tile-major  single nt (256 wgs)", [&](int i) { hipLaunchKernelGGL((probe<1, 1, true>), dim3(256), dim3(1024), 0, 0, bufs[2 * i], bufs[2 * i + 1], dl, dc, 256, 0, (size_t)Z * 128, sink); }, b1 * 256 / tiles);
+    timeit("B tile-major  pair   nt (256 wgs)", [&](int i) { hipLaunchKernelGGL((probe<1, 2, true>), dim3(256), dim3(1024), 0, 0, bufs[2 * i], bufs[2 * i + 1], dl, dc, 256, 0, (size_t)Z * 128, sink); }, b2 * 256 / tiles);
+    // row-major with a short row stride (the down projection's shape: ld = 4160): 172 / 256 workgroups... needs 256 * 128 B
+    // = 32 KB of columns per row; use ld = 16448 elements (256 tiles + pad) within the same buffers (Z * 16448 * 2 = 134 MB > mat?)
+    timeit("C contiguous 90 MB, 256 wgs", [&](int i) { hipLaunchKernelGGL(contig, dim3(256), dim3(1024), 0, 0, bufs[2 * i], (size_t)(90u << 20) / 256 / 65536 * 65536, sink); }, (double)((size_t)(90u << 20) / 256 / 65536 * 65536) * 256);
+    timeit("C contiguous 90 MB, 172 wgs", [&](int i) { hipLaunchKernelGGL(contig, dim3(172), dim3(1024), 0, 0, bufs[2 * i], (size_t)(90u << 20) / 172 / 65536 * 65536, sink); }, (double)((size_t)(90u << 20) / 172 / 65536 * 65536) * 172);
+    return 0;
+}

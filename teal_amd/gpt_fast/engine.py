@@ -203,39 +203,62 @@ class DecodeEngine:
         if rc != 0:
             _lib.check(rc, "teal_fused_gemv")
 
-    def __call__(self, idx: torch.Tensor, input_pos: torch.Tensor) -> torch.Tensor:
-        """idx: int32 [1, 1] token id, input_pos: int32 [1] position -> logits [1, 1, vocab]."""
+    def __call__(self, idx: torch.Tensor, input_pos: torch.Tensor, hook=None) -> torch.Tensor:
+        """idx: int32 [1, 1] token id, input_pos: int32 [1] position -> logits [1, 1, vocab].
+
+        `hook(when, stage, layer)` (tests / measurements only; never under graph capture) is called around every launch:
+        when in {"before", "after"}, stage in {"qkv", "attn", "wo", "gate_up", "down", "head"}."""
         assert idx.dtype == torch.int32 and input_pos.dtype == torch.int32 and idx.numel() == 1
-        cfg = self.cfg
         self._stream = runtime.stream_ptr()
         tok_ptr, pos_ptr = idx.data_ptr(), input_pos.data_ptr()
-        for i, (k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out, tau_o) in enumerate(self.stages):
-            if i == 0:
-                k1_in.row_index = tok_ptr
-            else:
-                k1_in.nslabs = self.n_down.value
-            self._gemv(k1_in, k1_out, self.dim, self.n_qkv if self.att_split else None)
-            ymask = self.y_mask.data_ptr() if self.pair else None
-            if self.att_split:
-                rc = self.L.teal_decode_attention_split_slabs(self.s_qkv.data_ptr(), self.n_qkv.value, self.rope.data_ptr(), pos_ptr,
-                                                              kc.data_ptr(), vc.data_ptr(),
-                                                              None if self.att_fused_merge else self.y_attn.data_ptr(), ymask, tau_o,
-                                                              cfg.n_head, cfg.n_local_heads, cfg.head_dim, self.max_seq,
-                                                              self.att_split, self.att_ws.data_ptr(), self.att_ws.numel() * 4,
-                                                              self.code, self._stream)
-            else:
-                rc = self.L.teal_decode_attention_masked(self.qkv.data_ptr(), self.rope.data_ptr(), pos_ptr, kc.data_ptr(), vc.data_ptr(),
-                                                         self.y_attn.data_ptr(), ymask, tau_o, cfg.n_head, cfg.n_local_heads,
-                                                         cfg.head_dim, self.max_seq, self.code, self._stream)
-            if rc != 0:
-                _lib.check(rc, "teal_decode_attention")
-            self._gemv(k3_in, k3_out, self.dim, self.n_wo)
-            k4_in.nslabs = self.n_wo.value
-            self._gemv(k4_in, k4_out, self.dim)
-            self._gemv(k5_in, k5_out, self.inter, self.n_down)
+        for i in range(len(self.stages)):
+            self._layer(i, tok_ptr, pos_ptr, hook)
         self.head_in.nslabs = self.n_down.value
+        if hook:
+            hook("before", "head", -1)
         self._gemv(self.head_in, self.head_out, self.dim)
+        if hook:
+            hook("after", "head", -1)
         return self.logits
+
+    def _layer(self, i: int, tok_ptr: int, pos_ptr: int, hook=None):
+        """The five launches of layer i (module docstring)."""
+        cfg = self.cfg
+        k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out, tau_o = self.stages[i]
+        cb = hook if hook else (lambda *a: None)
+        if i == 0:
+            k1_in.row_index = tok_ptr
+        else:
+            k1_in.nslabs = self.n_down.value
+        cb("before", "qkv", i)
+        self._gemv(k1_in, k1_out, self.dim, self.n_qkv if self.att_split else None)
+        cb("after", "qkv", i)
+        ymask = self.y_mask.data_ptr() if self.pair else None
+        cb("before", "attn", i)
+        if self.att_split:
+            rc = self.L.teal_decode_attention_split_slabs(self.s_qkv.data_ptr(), self.n_qkv.value, self.rope.data_ptr(), pos_ptr,
+                                                          kc.data_ptr(), vc.data_ptr(),
+                                                          None if self.att_fused_merge else self.y_attn.data_ptr(), ymask, tau_o,
+                                                          cfg.n_head, cfg.n_local_heads, cfg.head_dim, self.max_seq,
+                                                          self.att_split, self.att_ws.data_ptr(), self.att_ws.numel() * 4,
+                                                          self.code, self._stream)
+        else:
+            rc = self.L.teal_decode_attention_masked(self.qkv.data_ptr(), self.rope.data_ptr(), pos_ptr, kc.data_ptr(), vc.data_ptr(),
+                                                     self.y_attn.data_ptr(), ymask, tau_o, cfg.n_head, cfg.n_local_heads,
+                                                     cfg.head_dim, self.max_seq, self.code, self._stream)
+        if rc != 0:
+            _lib.check(rc, "teal_decode_attention")
+        cb("after", "attn", i)
+        cb("before", "wo", i)
+        self._gemv(k3_in, k3_out, self.dim, self.n_wo)
+        cb("after", "wo", i)
+        k4_in.nslabs = self.n_wo.value
+        cb("before", "gate_up", i)
+        self._gemv(k4_in, k4_out, self.dim)
+        cb("after", "gate_up", i)
+        cb("before", "down", i)
+        self._gemv(k5_in, k5_out, self.inter, self.n_down)
+        cb("after", "down", i)
 
     def sample_fused(self, logits: torch.Tensor, temperature: float = 1.0, top_k: Optional[int] = None,
                      feed: bool = False) -> torch.Tensor:

@@ -1,0 +1,217 @@
+"""GPU: every launch of the fused decode engine against the oracle, at REAL layer widths and UNDER SPARSITY.
+
+One decode step of a 2-layer model (Llama-2-7B fp16 @ 50 %, Llama-3-8B bf16 @ 40 %, Llama-2-70B widths fp16 @ 50 %) is run launch
+by launch; for layer 1 the test restates, on the host, the activation each launch consumes (residual + split-K slabs ->
+RMSNorm; the split-KV attention merge; the engine's own h = silu(gate) * up bits), picks thresholds at the target kept
+fraction that no activation sits next to, and checks what the launch produced:
+
+  * residual stream written by the RMSNorm producers: bit-exact;
+  * q|k|v, wo, down: the fp32 split-K slabs, summed in slice order and rounded once, against oracle.truth64 of the
+    3-threshold / 1-threshold sparse GEMV on that activation, SURVEY 8(c) tolerance;
+  * gate|up (PAIR launch, tau_gate != tau_up): h against silu(truth64 gate) * truth64 up with the propagated tolerance;
+  * keep masks emitted for the down projection: bit-exact against oracle.compact on the engine's own h bits.
+
+Reference semantics: kernels/sparse_gemv.py:75-83,167-181 (keep rule, masked GEMV), gpt-fast/model.py:158-161,258-259,
+289-291 (residual adds, silu * up, RMSNorm).  Covers the lean kernel (teal_gemv_fast.h) and, with it switched off, the
+general kernel — including the 128-column sliced geometry 70B-class slab launches use."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import bits_from_torch, tolerance
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _wT_bits(lin):
+    """W^T image [Z][N] (contiguous bits) of a linear, taken BEFORE the engine re-lays it out."""
+    return bits_from_torch(lin.weight.detach().T.contiguous())
+
+
+def _round(O, a, dtype):
+    return O.from_bits(O.to_bits(np.asarray(a, dtype=np.float32), dtype), dtype).astype(np.float32)
+
+
+def _rmsnorm_variants(O, h, w, eps, dtype):
+    """x = round(round(h * rstd) * w) for rstd and its fp32 neighbours (the GPU sums h^2 in another order and uses the
+    hardware rsqrt): elements whose bits differ between the variants are 'fragile'."""
+    ss = np.float32(np.sum(h.astype(np.float64) ** 2) / h.size)
+    rstd = np.float32(1.0) / np.sqrt(np.float32(ss + np.float32(eps)), dtype=np.float32)
+    out = []
+    for k in (0, -4, 4):
+        r = rstd
+        for _ in range(abs(k)):
+            r = np.nextafter(r, np.float32(0 if k < 0 else 10), dtype=np.float32)
+        xn = _round(O, h * r, dtype)
+        out.append(O.to_bits((xn * w).astype(np.float32), dtype))
+    return out
+
+
+def _safe_tau(O, variants, sparsity, dtype):
+    """A threshold near the `sparsity` quantile of |x| that lies strictly between two adjacent distinct values of |x| and
+    on which every fragile element (bits differ between the variants) falls on the same side in all variants."""
+    a = [np.abs(O.from_bits(v, dtype).astype(np.float32)) for v in variants]
+    frag = np.zeros(a[0].size, dtype=bool)
+    for v in variants[1:]:
+        frag |= v != variants[0]
+    fa = np.stack([x[frag] for x in a]) if frag.any() else np.zeros((len(a), 0), np.float32)
+    u = np.unique(a[0])
+    k0 = int(np.searchsorted(u, np.quantile(a[0], sparsity)))
+    for d in range(0, u.size):
+        for k in (k0 + d, k0 - d):
+            if 0 <= k < u.size - 1:
+                tau = np.float32((np.float64(u[k]) + np.float64(u[k + 1])) / 2)
+                if not (u[k] < tau < u[k + 1]):
+                    continue
+                side = fa > tau
+                if side.size == 0 or (side == side[0]).all():
+                    return float(tau)
+    raise AssertionError("no safe threshold found")
+
+
+def _slab_sum(O, slabs, n, ncols, dtype):
+    """interleaved fp32 slabs [col][(n + 3) & ~3] -> slice-order fp32 sum -> one rounding (bits)"""
+    st = (n + 3) & ~3
+    s = slabs[: ncols * st].reshape(ncols, st)
+    acc = np.zeros(ncols, np.float32)
+    for j in range(n):
+        acc = (acc + s[:, j]).astype(np.float32)
+    return acc, O.to_bits(acc, dtype)
+
+
+def _mask_words(O, bits, tau, dtype):
+    idx = O.compact(bits, tau, dtype)
+    v = O.from_bits(bits, dtype)
+    keep = np.zeros(bits.size, dtype=bool)
+    keep[idx] = True
+    keep |= np.isnan(v)  # GEMV mode: NaN rows are kept (none here)
+    pad = (-bits.size) % 64
+    kb = np.concatenate([keep, np.zeros(pad, bool)]).reshape(-1, 64)
+    return (kb.astype(np.uint64) << np.arange(64, dtype=np.uint64)).sum(axis=1, dtype=np.uint64)
+
+
+CASES = [("7B", torch.float16, 0.5), ("llama-3-8b", torch.bfloat16, 0.4), ("70B", torch.float16, 0.5)]
+
+
+@pytest.mark.parametrize("fast", [1, 0])
+@pytest.mark.parametrize("name,tdt,sparsity", CASES)
+def test_engine_launches_vs_oracle_under_sparsity(oracle, name, tdt, sparsity, fast):
+    from teal_amd import _lib
+    from teal_amd.gpt_fast import generate as G
+    from teal_amd.gpt_fast.engine import DecodeEngine
+    O = oracle
+    dtype = 0 if tdt == torch.float16 else 1
+    L = _lib.load()
+    model = G.build_synthetic_model(name, DEV, tdt, seed=11, n_layer=2)
+    cfg = model.config
+    dim, inter, hd = cfg.dim, cfg.intermediate_size, cfg.head_dim
+    kv = cfg.n_local_heads * hd
+    nqkv = dim + 2 * kv
+    lay = model.layers[1]
+    W = {"qkv": _wT_bits(lay.attention.wqkv), "o": _wT_bits(lay.attention.wo), "gate": _wT_bits(lay.feed_forward.w1),
+         "up": _wT_bits(lay.feed_forward.w3), "down": _wT_bits(lay.feed_forward.w2)}
+    nw1 = O.from_bits(bits_from_torch(lay.attention_norm.weight), dtype).astype(np.float32)
+    nw2 = O.from_bits(bits_from_torch(lay.ffn_norm.weight), dtype).astype(np.float32)
+    ths = G.apply_sparsity(model, sparsity=sparsity, hist_path=None, greedy_lookup=None, synthetic=True)
+    V = cfg.vocab_size
+    prompt = torch.randint(0, V, (6,), device=DEV, dtype=torch.int, generator=torch.Generator(device=DEV).manual_seed(2))
+    try:
+        L.teal_set_fast(fast)
+        with torch.no_grad():
+            model.max_seq_length = -1
+            model.setup_caches(1, 32)
+            model(prompt.view(1, -1), torch.arange(6, device=DEV))
+            eng = DecodeEngine(model, ths)
+        assert eng.pair and eng.att_fused_merge
+        k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out, _ = eng.stages[1]
+        A, B = eng.resid
+        seen = {}
+
+        def np32(t):
+            torch.cuda.synchronize()
+            return t.detach().float().cpu().numpy().astype(np.float32)
+
+        def hook(when, stage, i):
+            if i != 1:
+                return
+            torch.cuda.synchronize()
+            if when == "before" and stage == "qkv":
+                n = eng.n_down.value
+                _, y16 = _slab_sum(O, np32(eng.s_down.view(-1)), n, dim, dtype)
+                h = _round(O, np32(A) + O.from_bits(y16, dtype).astype(np.float32), dtype)
+                seen["h1"] = O.to_bits(h, dtype)
+                xv = _rmsnorm_variants(O, h, nw1, eng.eps, dtype)
+                seen["x1"] = xv[0]
+                seen["tq"], seen["tk"], seen["tv"] = (_safe_tau(O, xv, s, dtype) for s in (sparsity, sparsity + 0.05, sparsity - 0.05))
+                k1_out.tau[0], k1_out.tau[1], k1_out.tau[2] = seen["tq"], seen["tk"], seen["tv"]
+            elif when == "after" and stage == "qkv":
+                assert np.array_equal(bits_from_torch(B), seen["h1"]), "residual written by the qkv launch"
+                acc, _ = _slab_sum(O, np32(eng.s_qkv.view(-1)), eng.n_qkv.value, nqkv, dtype)
+                truth = O.truth64(seen["x1"], W["qkv"], dim, nqkv, seen["tq"], seen["tk"], seen["tv"], dim, kv, dtype)
+                got = O.from_bits(O.to_bits(acc, dtype), dtype)
+                err = np.abs(got - truth)
+                assert (err <= tolerance(O, truth, dtype)).all(), ("qkv", float(err.max()))
+                seen["qkv_kept"] = float((np.abs(O.from_bits(seen["x1"], dtype)) > seen["tq"]).mean())
+            elif when == "before" and stage == "wo":
+                ns = eng.att_split
+                p = np32(eng.att_ws.view(-1))[: cfg.n_head * ns * (hd + 2)].reshape(cfg.n_head, ns, hd + 2).astype(np.float64)
+                M = p[:, :, 0].max(axis=1, keepdims=True)
+                f = np.where(p[:, :, 1] > 0, np.exp(p[:, :, 0] - M), 0.0)
+                Lsum = (p[:, :, 1] * f).sum(axis=1)
+                Osum = (p[:, :, 2:] * f[:, :, None]).sum(axis=1)
+                y = (Osum / Lsum[:, None]).reshape(-1)
+                yv = [O.to_bits((y * s).astype(np.float32), dtype) for s in (1.0, 1.0 - 3e-6, 1.0 + 3e-6)]
+                seen["xo"] = yv[0]
+                seen["to"] = _safe_tau(O, yv, sparsity, dtype)
+                k3_out.tau[0] = seen["to"]
+            elif when == "after" and stage == "wo":
+                acc, _ = _slab_sum(O, np32(eng.s_wo.view(-1)), eng.n_wo.value, dim, dtype)
+                truth = O.truth64(seen["xo"], W["o"], dim, dim, seen["to"], dtype=dtype)
+                err = np.abs(O.from_bits(O.to_bits(acc, dtype), dtype) - truth)
+                assert (err <= tolerance(O, truth, dtype)).all(), ("wo", float(err.max()))
+            elif when == "before" and stage == "gate_up":
+                _, y16 = _slab_sum(O, np32(eng.s_wo.view(-1)), eng.n_wo.value, dim, dtype)
+                h = _round(O, np32(B) + O.from_bits(y16, dtype).astype(np.float32), dtype)
+                seen["h2"] = O.to_bits(h, dtype)
+                xv = _rmsnorm_variants(O, h, nw2, eng.eps, dtype)
+                seen["x2"] = xv[0]
+                seen["tg"], seen["tu"] = _safe_tau(O, xv, sparsity, dtype), _safe_tau(O, xv, sparsity + 0.07, dtype)
+                assert seen["tg"] != seen["tu"]
+                k4_out.tau[0], k4_out.tau[1] = seen["tg"], seen["tu"]
+                seen["td"] = float(k4_out.mask_tau)
+            elif when == "after" and stage == "gate_up":
+                assert np.array_equal(bits_from_torch(A), seen["h2"]), "residual written by the gate|up launch"
+                hb = bits_from_torch(eng.h_mlp)
+                g = O.truth64(seen["x2"], W["gate"], dim, inter, seen["tg"], dtype=dtype)
+                u = O.truth64(seen["x2"], W["up"], dim, inter, seen["tu"], dtype=dtype)
+                sg = g / (1.0 + np.exp(-g))
+                ht = sg * u
+                dsil = 1.1  # |d silu / d g| <= 1.0998
+                tol = dsil * np.abs(u) * tolerance(O, g, dtype) + np.abs(sg) * tolerance(O, u, dtype) + 3 * O.ulp16(ht, dtype) + 1e-7
+                err = np.abs(O.from_bits(hb, dtype) - ht)
+                assert (err <= tol).all(), ("gate|up", float(err.max()), float((err / tol).max()))
+                got_mask = eng.h_mask.detach().cpu().numpy().view(np.uint64)
+                assert np.array_equal(got_mask, _mask_words(O, hb, seen["td"], dtype)), "keep masks of h"
+                seen["hb"] = hb
+                seen["down_kept"] = float(np.unpackbits(got_mask.view(np.uint8)).sum()) / inter
+            elif when == "after" and stage == "down":
+                acc, _ = _slab_sum(O, np32(eng.s_down.view(-1)), eng.n_down.value, dim, dtype)
+                truth = O.truth64(seen["hb"], W["down"], inter, dim, seen["td"], dtype=dtype)
+                err = np.abs(O.from_bits(O.to_bits(acc, dtype), dtype) - truth)
+                assert (err <= tolerance(O, truth, dtype)).all(), ("down", float(err.max()))
+                seen["done"] = True
+
+        tok = torch.tensor([[17]], device=DEV, dtype=torch.int)
+        pos = torch.tensor([6], device=DEV, dtype=torch.int)
+        with torch.no_grad():
+            eng(tok, pos, hook=hook)
+        torch.cuda.synchronize()
+        assert seen.get("done"), "the hook never reached layer 1's down projection"
+        assert abs(seen["qkv_kept"] - (1 - sparsity)) < 0.03 and 0.2 < seen["down_kept"] < 0.8
+    finally:
+        L.teal_set_fast(1)
+        del model
+        torch.cuda.empty_cache()
