@@ -141,12 +141,6 @@ def make_stepper(model, a, dense=False):
     return step, info
 
 
-def kept_fractions(model, info):
-    """achieved kept fraction per projection on one decode step's activations is logged by the
-    calibration; here: re-measure on layer 0..L-1 mlp input with the installed thresholds."""
-    return None
-
-
 def roofline_dominant_kernel(model, a):
     """MLP gate-projection sparse GEMV (the instantiation that also serves up and qkv): algorithmic
     bytes / average launch duration, HIP events around a hipGraph of one launch per layer (each layer's
@@ -260,36 +254,31 @@ def roofline_engine_gateup(eng, a):
         ts.append(e0.elapsed_time(e1) * 1e-3)
     t = float(np.median(ts))
     n = len(launches)
-    cfgv = (ctypes.c_int * 5)()
-    eng.L.teal_get_config(Z, 2 * N, 2, cfgv)
-    if eng.pair:  # PAIR geometry (run_gemv): widest tile that still gives >= 2/3 of the CUs a tile, else 64 columns
-        ncu = runtime.init()
-        cfgv[0] = next((l for l in (64, 32, 16) if ((N + l * 8 - 1) // (l * 8)) * 3 >= ncu * 2), 8)
-        cfgv[3] = 4
-    owned = ((Z + 63) // 64 + 15) // 16
-    krt = 4 if owned <= 4 else (8 if owned <= 8 else 16)
-    kname = f"sparse_gemv_kernel<{cfgv[0]},16,{cfgv[3]},{'true' if eng.code else 'false'},1,{krt},{'true' if eng.pair else 'false'},{'true' if eng.int8 else 'false'}>"
+    kname = eng.L.teal_last_launch_desc().decode()  # the instantiation run_gemv actually launched
     traffic, tsrc = pmc_traffic(kname)
     return {"bound": "hbm", "achieved": total_bytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": total_bytes / t / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+            "traffic_measured_in_this_run": False,
             "kernel": kname + f" (fused RMSNorm -> mask -> gate|up GEMV{' -> silu*mul' if eng.pair else ''}, Z={Z}, N=2x{N})",
             "algorithmic_bytes": total_bytes / n, "us_per_launch": t / n * 1e6, "launches_timed": n,
             "timing": "HIP events (launch stream) around a hipGraph of one launch per layer with that layer's weights; "
                       "per-launch time includes the same-stream launch boundary, like rocprofv3's per-dispatch duration"}
 
 
-def pmc_traffic(kernel_short_name):
-    """HBM read bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc FETCH_SIZE
-    pass of this same command (profiles/*pmc_fetch_by_kernel.csv; counters cannot be sampled from
-    inside the process).  FETCH_SIZE is reported in KiB and, on gfx950, counts 128-byte requests as 64
+def pmc_traffic(kernel_desc):
+    """HBM read bytes per launch of the dominant kernel.  PMC counters cannot be sampled from inside the process: the
+    value comes from the COMMITTED rocprofv3 --pmc FETCH_SIZE pass of this same command (newest
+    profiles/*pmc_fetch_by_kernel.csv) and is reported only if that profile names the kernel this run launched — it is
+    flagged `traffic_measured_in_this_run: false`.  FETCH_SIZE is in KiB and, on gfx950, counts 128-byte requests as 64
     bytes for wide coalesced reads: doubled as MI355X_MICROARCH.md (HBM section) prescribes."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_fetch_by_kernel.csv")))
     if not files:
         return None, None
+    short = kernel_desc.split(" grid")[0].replace(" ", "")
     for r in csv.DictReader(open(files[-1])):
-        if r["kernel"].replace(" ", "") == kernel_short_name.replace(" ", "") and r["counter"] == "FETCH_SIZE":
+        if short and short in r["kernel"].replace(" ", "") and r["counter"] == "FETCH_SIZE":
             return float(r["avg_value"]) * 1024 * 2, os.path.relpath(files[-1], ROOT) + " (FETCH_SIZE KiB x 2, per dispatch)"
     return None, None
 
@@ -342,7 +331,23 @@ def cpu_baseline(model, a, budget_s=12.0):
             break
     t_lm = (time.perf_counter() - t1) / r2
     t_token = cfg.n_layer * t_layer + t_lm
+    # dense leg (kernels/sparse_gemv.py:301-307 DenseGEMV semantics: every row kept) on the same layer
+    def one_layer_dense():
+        for k, (wb, Z, N) in host.items():
+            O.fast_dense_gemv(xs[k], wb, Z, N, code)
+
+    one_layer_dense()
+    t2 = time.perf_counter()
+    r3 = 0
+    while True:
+        one_layer_dense()
+        r3 += 1
+        if time.perf_counter() - t2 > budget_s * 0.5 or r3 >= 20:
+            break
+    t_layer_dense = (time.perf_counter() - t2) / r3
+    t_token_dense = cfg.n_layer * t_layer_dense + t_lm
     return {"value": 1.0 / t_token, "unit": "tokens/s", "cores": used_threads, "kind": "port",
+            "dense_value": 1.0 / t_token_dense, "ms_per_layer_dense": t_layer_dense * 1e3,
             "sample": f"oracle/teal_oracle.c fast path: 1 of {cfg.n_layer} layers (qkv, o, gate, up, down sparse GEMVs at kept "
                       f"fraction {1 - a.sparsity:.2f}) x {reps} reps + dense lm_head x {r2} reps, scaled to one token "
                       f"({cfg.n_layer} layers + lm_head); GEMVs only (no attention/norms), so it flatters the CPU",
@@ -393,13 +398,25 @@ def main():
            "data": "synthetic (random-init weights at exact shapes, random token ids, thresholds calibrated to the kept fraction)",
            "config": {"workload": f"Llama-2-{a.model} bs=1 decode, uniform {a.sparsity:.0%} sparsity, hipGraph-captured step"
                       if a.model == "7B" else f"{a.model} bs=1 decode, uniform {a.sparsity:.0%} sparsity",
-                      "n_layer": cfg.n_layer, "dim": cfg.dim, "mode": mode, "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
-                      "prompt_tokens": a.prompt_tokens}}
+                      "mode": mode, "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
+                      "prompt_tokens": a.prompt_tokens, "context_positions": f"{a.prompt_tokens}..{a.prompt_tokens + a.warmup + a.steps}"}}
     if a.weights == "int8":
         out["metric"] = out["metric"].replace("fp16", "int8-weight/fp16-activation")
         out["dtype"] = out["dtype"] + " activations, int8 weights (per-channel scales)"
         out["config"]["workload"] += ", int8 weight-only"
     out.update(info.get("report", {}))
+    if rank == 0 and mode == "engine":
+        eng = info["engine"]
+        # achieved kept fraction of all seven projections on the DECODE activations of one more step
+        out["kept_fraction"] = {k: round(v, 4) for k, v in
+                                eng.mean_kept_fractions(info["first_token"], info["pos0"], info["span"], 3).items()}
+        out["kept_fraction_note"] = "mean over layers and over 3 decode positions (first, middle, last) of the timed range"
+        # the reference's tokens/sec definition (gpt-fast/generate.py:487-497): generated tokens / (prefill + decode) for
+        # one sample of max_new_tokens = 200 after a prompt of `prompt_tokens`
+        t_pf = info.get("prefill_s")
+        if t_pf:
+            out["tokens_per_sec_reference_definition"] = 200.0 / (t_pf + 200.0 * t / a.steps)
+            out["prefill_ms"] = t_pf * 1e3
     if rank == 0 and world == 1:
         out["roofline"] = roofline_engine_gateup(info["engine"], a) if mode == "engine" else roofline_dominant_kernel(model, a)
         if not a.no_dense:
@@ -416,6 +433,19 @@ def main():
             dense_tps = max(20, a.steps // 2) / td
             out["dense_tokens_per_sec"] = dense_tps
             out["speedup_vs_dense"] = tps / dense_tps
+            out["dense_comparator"] = ("the same fused engine with every row kept (thresholds < 0: same kernels, same launches) — "
+                                       "the strongest dense fp16 path on this box; the reference's own dense path follows")
+            if mode == "engine" and a.weights != "int8":
+                # the reference's dense path as it exists here: the un-patched gpt-fast model (torch.matmul / hipBLASLt,
+                # eager glue; no Inductor on this image) under the same hipGraph capture
+                rmodel = G.build_synthetic_model(a.model, "cuda", dt, n_layer=a.n_layer)
+                rstep, _ = make_stepper(rmodel, a_d, dense=True)
+                nref = max(10, a.steps // 8)
+                tr = timed_decode(rstep, nref, 3, 1)
+                out["reference_dense_path_tokens_per_sec"] = nref / tr
+                out["speedup_vs_reference_dense_path"] = tps / (nref / tr)
+                del rmodel, rstep
+                torch.cuda.empty_cache()
         if not a.no_cpu_baseline and a.weights != "int8":
             out["cpu_baseline"] = cpu_baseline(model, a)
     elif rank == 0:

@@ -233,6 +233,10 @@ int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll);
  * of a workgroup-wide list; removes every barrier between the activation and the first weight load. */
 int teal_set_wave_local(int on);
 
+/* Diagnostics: kernel template instantiation and grid of the most recent GEMV launch of this process (host-side
+ * string; e.g. for naming the kernel in a benchmark record). */
+const char* teal_last_launch_desc(void);
+
 /* Lean kernel for qualifying shapes (default on; 0 forces the general kernel everywhere: A/B and parity tests). */
 int teal_set_fast(int on);
 

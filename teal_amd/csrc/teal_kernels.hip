@@ -14,6 +14,7 @@
 #include "teal_gemv_fast_decl.h"
 
 #include <limits.h>
+#include <stdio.h>
 
 namespace teal {
 
@@ -128,6 +129,7 @@ int g_phase_seq = 0;
 int g_swizzle = 0;
 int g_wave_local = 1;
 int g_fast = 1;  // lean kernel (teal_gemv_fast.h) where the shape qualifies
+char g_last_desc[160] = "";  // template instantiation + grid of the most recent GEMV launch (teal_last_launch_desc)
 
 
 size_t lds_bytes(int Z, int cap, int waves, int lpr, bool pair = false) {
@@ -406,9 +408,19 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
     {
         FastLaunch f;
         if (fast_eligible(p, c, to_ws, f)) {
+            snprintf(g_last_desc, sizeof g_last_desc, "gemv_fast_kernel<%s,%d,%s,%d,%d,%s,false> grid (%d,%d) x 1024",
+                     dtype == TEAL_BF16 ? "true" : "false", f.mode, f.pair ? "true" : "false", f.lpr, f.kr,
+                     (f.mode == 1 && f.Z == 1024 * f.kr) ? "true" : "false", f.ntiles, f.split);
             const hipError_t e = dtype == TEAL_BF16 ? launch_fast_bf16(f, st) : launch_fast_f16(f, st);
             return e == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
         }
+    }
+    {
+        const int owned = p.krt ? p.krt : (((p.Z + 63) >> 6) + c.waves - 1) / c.waves;
+        const int krt = c.waves == 16 ? (owned <= 4 ? 4 : (owned <= 8 ? 8 : 16)) : 16;
+        snprintf(g_last_desc, sizeof g_last_desc, "sparse_gemv_kernel<%d,%d,%d,%s,%d,%d,%s,%s> grid %d x %d", c.lpr, c.waves, c.unroll,
+                 dtype == TEAL_BF16 ? "true" : "false", p.in.mode, krt, p.pair ? "true" : "false", p.w8 ? "true" : "false",
+                 p.ntiles * p.split, c.waves * 64);
     }
     if (launch_gemv(p, dtype, lds, c, st) != hipSuccess) return TEAL_ERR_LAUNCH;
     if (c.split > 1 && !to_ws) {
@@ -486,6 +498,8 @@ int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll) {
     g_override = {lanes_per_row, waves, split, unroll};
     return TEAL_OK;
 }
+
+const char* teal_last_launch_desc(void) { return g_last_desc; }
 
 int teal_set_fast(int on) {
     g_fast = on ? 1 : 0;

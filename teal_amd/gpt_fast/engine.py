@@ -260,6 +260,130 @@ class DecodeEngine:
         self._gemv(k5_in, k5_out, self.inter, self.n_down)
         cb("after", "down", i)
 
+    @torch.no_grad()
+    def site_activations(self, idx: torch.Tensor, input_pos: torch.Tensor) -> List[Dict[str, torch.Tensor]]:
+        """|activation| every projection of every layer consumes in ONE decode step, restated with torch ops from the
+        engine's own buffers while the step runs (sites as in the reference: q/k/v <- attention input, o <- attention
+        output, gate/up <- MLP input, down <- silu(gate) * up).  Measurement / calibration only."""
+        dt, dim, inter = self.dtype, self.dim, self.inter
+        out: List[Dict[str, torch.Tensor]] = [dict() for _ in self.stages]
+        A, B = self.resid
+
+        def slab_sum(slabs, n, ncols):
+            st = (n + 3) & ~3
+            v = slabs.view(-1)[: ncols * st].view(ncols, st)
+            t = torch.zeros(ncols, device=v.device, dtype=torch.float32)
+            for j in range(n):
+                t = t + v[:, j]
+            return t.to(dt)
+
+        def normed(resid, y, w):
+            h = (resid + y).to(dt) if y is not None else resid
+            hf = h.float()
+            return ((hf * torch.rsqrt(hf.pow(2).mean() + self.eps)).to(dt) * w).float().abs()
+
+        def hook(when, stage, i):
+            if i < 0 or when != "before":
+                return
+            layer = self.model.layers[i]
+            if stage == "qkv":
+                if i == 0:
+                    resid, y = self.model.tok_embeddings.weight[int(idx.view(-1)[0])], None
+                else:
+                    resid, y = A, slab_sum(self.s_down, self.n_down.value, dim)
+                out[i]["attn_in"] = normed(resid, y, layer.attention_norm.weight)
+            elif stage == "wo":
+                if self.att_fused_merge:
+                    ns, hd = self.att_split, self.cfg.head_dim
+                    p = self.att_ws[: self.cfg.n_head * ns * (hd + 2)].view(self.cfg.n_head, ns, hd + 2)
+                    m, l, o = p[:, :, 0], p[:, :, 1], p[:, :, 2:]
+                    f = torch.where(l > 0, torch.exp(m - m.max(dim=1, keepdim=True).values), torch.zeros_like(m))
+                    out[i]["attn_out"] = ((o * f[:, :, None]).sum(1) / (l * f).sum(1, keepdim=True)).reshape(-1).to(dt).float().abs()
+                else:
+                    out[i]["attn_out"] = self.y_attn.float().abs().clone()
+            elif stage == "gate_up":
+                out[i]["mlp_in"] = normed(B, slab_sum(self.s_wo, self.n_wo.value, dim), layer.ffn_norm.weight)
+            elif stage == "down":
+                if self.pair:
+                    out[i]["mlp_mid"] = self.h_mlp.float().abs().clone()
+                else:
+                    g, u = self.gu[:inter].float(), self.gu[inter:]
+                    out[i]["mlp_mid"] = (torch.nn.functional.silu(g).to(dt) * u).float().abs()
+
+        self(idx, input_pos, hook=hook)
+        return out
+
+    SITE = {"q": "attn_in", "k": "attn_in", "v": "attn_in", "o": "attn_out", "gate": "mlp_in", "up": "mlp_in", "down": "mlp_mid"}
+
+    def thresholds(self) -> List[Dict[str, float]]:
+        """the thresholds the launch descriptors currently carry"""
+        out = []
+        for (_, k1_out, _, _, _, k3_out, _, k4_out, _, k5_out, _) in self.stages:
+            out.append({"q": k1_out.tau[0], "k": k1_out.tau[1], "v": k1_out.tau[2], "o": k3_out.tau[0], "gate": k4_out.tau[0],
+                        "up": k4_out.tau[1], "down": k5_out.tau[0]})
+        return out
+
+    @torch.no_grad()
+    def kept_fractions(self, idx: torch.Tensor, input_pos: torch.Tensor) -> Dict[str, float]:
+        """Achieved kept fraction of every projection's input on the decode activations of one step (mean over layers)."""
+        acts, ths = self.site_activations(idx, input_pos), self.thresholds()
+        return {p: sum(float((a[self.SITE[p]] > th[p]).float().mean()) for a, th in zip(acts, ths)) / len(acts) for p in self.SITE}
+
+    @torch.no_grad()
+    def _walk(self, first_token: torch.Tensor, pos0: int, n_steps: int, n_samples: int, visit):
+        """n_steps eager decode steps from (first_token, pos0); at n_samples evenly spaced steps (first and last
+        included) the step runs through site_activations and visit(acts) is called."""
+        self.tok_buf.copy_(first_token.view(1, 1))
+        self.pos_buf.fill_(pos0)
+        n_samples = max(1, min(n_samples, n_steps))
+        marks = {round(k * (n_steps - 1) / max(1, n_samples - 1)) for k in range(n_samples)}
+        for t in range(n_steps):
+            if t in marks:
+                visit(self.site_activations(self.tok_buf, self.pos_buf))
+                self.sample_fused(self.logits, 0.8, 200, feed=True)
+            else:
+                self._self_step(0.8, 200)
+
+    @torch.no_grad()
+    def calibrate_on_decode(self, sparsities: Dict[str, List[float]], first_token: torch.Tensor, pos0: int, n_steps: int,
+                            n_samples: int = 5, rounds: int = 2) -> List[Dict[str, float]]:
+        """Synthetic calibration on the DECODE path: thresholds = the target quantile of |activation| pooled over
+        n_samples decode positions in [pos0, pos0 + n_steps), measured on the sparse path itself (`rounds` passes, since
+        a projection's threshold shifts the activations downstream of it).  With random weights the attention output
+        shrinks with the context length, so thresholds taken from a short prefill (generate.calibrate_thresholds) keep far
+        fewer than the target of the o-projection's rows during a long decode; real checkpoints use the histograms."""
+        assert pos0 + n_steps <= self.max_seq
+        ths = self.thresholds()
+        for _ in range(rounds):
+            pool: List[Dict[str, List[torch.Tensor]]] = [dict(attn_in=[], attn_out=[], mlp_in=[], mlp_mid=[]) for _ in self.stages]
+
+            def visit(acts):
+                for i, a in enumerate(acts):
+                    for k, v in a.items():
+                        pool[i][k].append(v)
+
+            self._walk(first_token, pos0, n_steps, n_samples, visit)
+            for i in range(len(self.stages)):
+                for p, site in self.SITE.items():
+                    s = float(sparsities[p][i])
+                    ths[i][p] = -1.0 if s <= 0 else float(torch.quantile(torch.cat(pool[i][site]), s))
+            self._build(ths)
+            self._graph = None
+        return ths
+
+    @torch.no_grad()
+    def mean_kept_fractions(self, first_token: torch.Tensor, pos0: int, n_steps: int, n_samples: int = 3) -> Dict[str, float]:
+        """kept fraction per projection, mean over layers and over n_samples decode positions of [pos0, pos0 + n_steps)"""
+        acc = {p: [] for p in self.SITE}
+        ths = self.thresholds()
+
+        def visit(acts):
+            for p in self.SITE:
+                acc[p].append(sum(float((a[self.SITE[p]] > th[p]).float().mean()) for a, th in zip(acts, ths)) / len(acts))
+
+        self._walk(first_token, pos0, n_steps, n_samples, visit)
+        return {p: sum(v) / len(v) for p, v in acc.items()}
+
     def sample_fused(self, logits: torch.Tensor, temperature: float = 1.0, top_k: Optional[int] = None,
                      feed: bool = False) -> torch.Tensor:
         """One launch: top-k filter + softmax + exponential-race multinomial (generate.py:49-66).
@@ -341,9 +465,20 @@ def make_engine_stepper(model: Transformer, a):
     model.max_seq_length = -1
     model.setup_caches(max_batch_size=1, max_seq_length=min(total, model.config.block_size))
     with torch.no_grad():
+        import time
         logits = model(prompt.view(1, -1), torch.arange(0, npr, device=dev))  # prefill fills the shared KV caches
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()  # timed once more, warm (the reference's tok/s definition includes the prefill)
+        logits = model(prompt.view(1, -1), torch.arange(0, npr, device=dev))
+        torch.cuda.synchronize()
+        prefill_s = time.perf_counter() - t0
         tok = G.sample(logits, temperature=0.8, top_k=200)[0]
         eng = DecodeEngine(model, ths, att_split=int(getattr(a, "att_split", 0)), pair=getattr(a, "pair", None))
+        span = min(a.warmup + a.steps + 4, eng.max_seq - npr)
+        if a.sparsity > 0 and getattr(a, "decode_calibration", True):
+            # thresholds for the kept fraction ON THE MEASURED DECODE POSITIONS (see calibrate_on_decode)
+            sp = {p: [a.sparsity] * len(model.layers) for p in eng.SITE}
+            ths = eng.calibrate_on_decode(sp, tok, npr, span)
         eng.tok_buf.copy_(tok.view(1, 1))
         eng.pos_buf.fill_(npr)
         graph = eng.capture_loop(0.8, 200)
@@ -360,4 +495,4 @@ def make_engine_stepper(model: Transformer, a):
         graph.replay()
         state["pos"] += 1
 
-    return step, {"thresholds": ths, "engine": eng}
+    return step, {"thresholds": ths, "engine": eng, "prefill_s": prefill_s, "first_token": tok, "pos0": npr, "span": span}

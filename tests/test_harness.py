@@ -131,14 +131,27 @@ def test_sparse_decode_graph_replay_equals_eager():
 
 @pytest.mark.gpu
 def test_sparse_thresholds_reduce_rows_read():
-    """kept fraction on the decode activations is near the calibrated target."""
-    import teal_amd.kernels as K
+    """the achieved kept fraction of ALL SEVEN projections, measured on the DECODE activations of the fused engine, is
+    near the calibrated target (and 1.0 with sparsity 0)."""
+    from teal_amd.gpt_fast.engine import DecodeEngine
     dev = "cuda"
-    m = tiny(dev, torch.float16)
-    ths = G.apply_sparsity(m, sparsity=0.5, hist_path=None, greedy_lookup=None, synthetic=True)
-    x = torch.randn(1, 1, 256, device=dev, dtype=torch.float16) * 0.05
-    _, n = K.compact(x, ths[0]["q"])
-    assert 0 <= n <= 256
+    for sparsity in (0.5, 0.0):
+        m = tiny(dev, torch.float16)
+        ths = G.apply_sparsity(m, sparsity=sparsity, hist_path=None, greedy_lookup=None, synthetic=True)
+        m.max_seq_length = -1
+        m.setup_caches(1, 32)
+        prompt = torch.randint(0, m.config.vocab_size, (6,), device=dev, dtype=torch.int)
+        with torch.no_grad():
+            m(prompt.view(1, -1), torch.arange(6, device=dev))
+            eng = DecodeEngine(m, ths)
+            kf = eng.kept_fractions(torch.tensor([[5]], device=dev, dtype=torch.int), torch.tensor([6], device=dev, dtype=torch.int))
+        assert set(kf) == {"q", "k", "v", "o", "gate", "up", "down"}
+        if sparsity == 0.0:
+            assert all(v == 1.0 for v in kf.values()), kf
+        else:
+            # dim-256 toy model, thresholds calibrated on 24 other tokens: per-projection within 0.2, mean within 0.1
+            assert all(abs(v - 0.5) < 0.2 for v in kf.values()), kf
+            assert abs(sum(kf.values()) / 7 - 0.5) < 0.1, kf
 
 
 @pytest.mark.gpu
