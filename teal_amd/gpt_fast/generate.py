@@ -90,10 +90,19 @@ def build_synthetic_model(name: str, device: str, dtype: torch.dtype, seed: int 
 def load_checkpoint_model(checkpoint_path: Path, device: str, dtype: torch.dtype) -> Transformer:
     with torch.device("meta"):
         model = Transformer.from_name(checkpoint_path.parent.name)
+    if "int8" in str(checkpoint_path):  # gpt-fast/generate.py:239-243: an int8 weight-only checkpoint (quantize.py --mode int8)
+        from teal_amd.quantize import convert_for_runtime_int8
+        print("Using int8 weight-only quantization!")
+        convert_for_runtime_int8(model, dtype)
     ckpt = torch.load(str(checkpoint_path), mmap=True, weights_only=True)
     if "model" in ckpt and "stories" in str(checkpoint_path):
         ckpt = ckpt["model"]
     model.load_state_dict(ckpt, assign=True)
+    if "int8" in str(checkpoint_path):  # keep the int8 buffers int8: only floating tensors take the activation dtype
+        model = model.to(device=device)
+        for prm in list(model.parameters()) + [b for b in model.buffers() if b.is_floating_point()]:
+            prm.data = prm.data.to(dtype)
+        return model.eval()
     return model.to(device=device, dtype=dtype).eval()
 
 
@@ -225,9 +234,16 @@ class GraphedDecoder:
             return self.model.sample_fused(logits, **self.kw)
         return sample(logits, **self.kw)[0]
 
-    def capture(self):
+    def capture(self, cur_token: Optional[torch.Tensor] = None, input_pos: Optional[torch.Tensor] = None):
+        """cur_token / input_pos: where decoding stands.  The two eager warm-up steps and the capture run write the KV
+        row of `input_pos` (rewritten with the same values by the first replay) — without them they would run at the
+        stale buffers' position (0 after construction) and overwrite the first prompt token's K/V."""
         if not self.use_graph or self.graph is not None:
             return
+        if cur_token is not None:
+            self.tok.copy_(cur_token.view(1, 1))
+        if input_pos is not None:
+            self.pos.copy_(input_pos)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):  # warm-up outside capture: workspace + allocator pools
@@ -259,7 +275,13 @@ class GraphedPrefill:
 
     def __call__(self, prompt: torch.Tensor) -> torch.Tensor:
         T = prompt.numel()
-        key = (T, self.model.max_seq_length, id(self.model.layers[0].attention.kv_cache))
+        # everything the captured launches hold raw pointers to: a re-laid-out weight (DecodeEngine / monkeypatch
+        # to_column_major replace the storage) or a re-allocated KV cache forces a new capture
+        key = (T, self.model.max_seq_length, self.model.output.weight.data_ptr(), self.model.tok_embeddings.weight.data_ptr()) + tuple(
+            p for layer in self.model.layers for p in (layer.attention.kv_cache.k_cache.data_ptr(), layer.attention.kv_cache.v_cache.data_ptr(),
+                                                       layer.attention.wqkv.weight.data_ptr(), layer.attention.wo.weight.data_ptr(),
+                                                       layer.feed_forward.w1.weight.data_ptr(), layer.feed_forward.w2.weight.data_ptr(),
+                                                       layer.feed_forward.w3.weight.data_ptr()))
         if key not in self.graphs:
             dev = prompt.device
             toks = torch.zeros(1, T, dtype=torch.int, device=dev)
@@ -283,17 +305,35 @@ class GraphedPrefill:
 class EngineDecoder:
     """GraphedDecoder's role for the fused HIP engine: built lazily once the KV caches exist."""
 
-    def __init__(self, torch_model: Transformer, thresholds, use_graph: bool, temperature: float, top_k: Optional[int]):
+    def __init__(self, torch_model: Transformer, thresholds, use_graph: bool, temperature: float, top_k: Optional[int],
+                 decode_calibration: Optional[Dict[str, List[float]]] = None):
         self.torch_model, self.thresholds, self.use_graph = torch_model, thresholds, use_graph
         self.kw = dict(temperature=temperature, top_k=top_k)
-        self._engine = None
+        self._engine, self._key = None, None
+        self.decode_calibration = decode_calibration  # synthetic mode: per-projection target sparsities
+
+    def _cache_key(self):
+        m = self.torch_model
+        return (m.max_seq_length,) + tuple(p for layer in m.layers for p in (layer.attention.kv_cache.k_cache.data_ptr(),
+                                                                              layer.attention.kv_cache.v_cache.data_ptr()))
 
     @property
     def model(self):
-        if self._engine is None or self._engine.max_seq != self.torch_model.max_seq_length:
+        # the engine's launch descriptors hold the KV caches' raw pointers: rebuild when setup_caches re-allocated them
+        # (same size or not), not only when the context length changed
+        key = self._cache_key()
+        if self._engine is None or self._key != key:
             from teal_amd.gpt_fast.engine import DecodeEngine
-            self._engine = DecodeEngine(self.torch_model, self.thresholds)
+            self._engine, self._key = DecodeEngine(self.torch_model, self.thresholds), key
+            self._calibrated = False
         return self._engine
+
+    def maybe_calibrate(self, first_token: torch.Tensor, pos0: int, n_steps: int):
+        """synthetic thresholds re-taken on the decode path once the engine exists (engine.calibrate_on_decode)"""
+        eng = self.model
+        if self.decode_calibration and not self._calibrated and n_steps >= 2:
+            self.thresholds = eng.calibrate_on_decode(self.decode_calibration, first_token, pos0, n_steps)
+            self._calibrated = True
 
 
 @torch.no_grad()
@@ -310,13 +350,15 @@ def generate(model: Transformer, prompt: torch.Tensor, max_new_tokens: int, deco
     next_token = sample(logits, temperature=temperature, top_k=top_k)[0].clone()
     seq[T] = next_token
     if hasattr(decoder.model, "decode_n"):  # HIP engine: the whole loop stays on the device
+        if hasattr(decoder, "maybe_calibrate"):
+            decoder.maybe_calibrate(next_token, T, max_new_tokens - 1)
         toks = decoder.model.decode_n(next_token, T, max_new_tokens - 1, temperature=decoder.kw["temperature"],
                                       top_k=decoder.kw["top_k"], use_graph=decoder.use_graph)
         seq[T + 1:] = toks.to(seq.dtype)
         return seq
-    decoder.capture()
     input_pos = torch.tensor([T], device=dev, dtype=torch.int)
     cur = next_token.view(1, -1)
+    decoder.capture(cur, input_pos)
     for i in range(max_new_tokens - 1):
         nxt = decoder(cur, input_pos)
         input_pos += 1
@@ -358,9 +400,19 @@ def main(args) -> Dict:
     use_engine = args.engine or (args.compile and thresholds is not None and not getattr(args, "no_engine", False))
     if use_engine:
         assert thresholds is not None, "--engine needs thresholds (--hist_path or --synthetic)"
-        decoder = EngineDecoder(model, thresholds, args.compile, args.temperature, args.top_k)
+        cal = None
+        if args.synthetic and args.sparsity > 0 and not args.greedy_lookup:
+            cal = {p: [args.sparsity] * len(model.layers) for p in PROJS}
+        decoder = EngineDecoder(model, thresholds, args.compile, args.temperature, args.top_k, decode_calibration=cal)
+        # the engine re-lays every projection (and lm_head) out column-major when it is built, lazily, after the first
+        # prefill: do it NOW so that a --compile_prefill graph never captures pointers to storage that is freed later
+        from teal_amd.monkeypatch import to_column_major
+        for layer in model.layers:
+            for lin in (layer.attention.wqkv, layer.attention.wo, layer.feed_forward.w1, layer.feed_forward.w3, layer.feed_forward.w2):
+                to_column_major(lin)
+        to_column_major(model.output)
     prefill = GraphedPrefill(model) if getattr(args, "compile_prefill", False) else None
-    tps = []
+    tps, seqs = [], []
     start = -1 if args.compile else 0
     for i in range(start, args.num_samples):
         torch.cuda.synchronize()
@@ -380,6 +432,7 @@ def main(args) -> Dict:
             prof.export_chrome_trace(f"{args.profile}.json")
         n_gen = y.size(0) - prompt.size(0)
         tps.append(n_gen / t)
+        seqs.append(y.tolist())
         if tokenizer is not None:
             print(tokenizer.decode(y.tolist()))
         print(f"Time for inference {i + 1}: {t:.02f} sec total, {tps[-1]:.02f} tokens/sec")
@@ -390,7 +443,8 @@ def main(args) -> Dict:
     mean = sum(tps) / max(1, len(tps))
     print(f"Average tokens/sec: {mean:.2f}")
     print(f"Memory used: {torch.cuda.max_memory_reserved() / 1e9:.02f} GB")
-    return {"tokens_per_sec": tps, "mean_tokens_per_sec": mean, "thresholds": thresholds, "decoder": type(decoder).__name__}
+    return {"tokens_per_sec": tps, "mean_tokens_per_sec": mean, "thresholds": thresholds, "decoder": type(decoder).__name__,
+            "sequences": seqs}
 
 
 def build_parser() -> argparse.ArgumentParser:

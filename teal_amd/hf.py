@@ -39,7 +39,6 @@ class SparsifiedLinear(nn.Module):
     def __init__(self, linear: nn.Linear, sparse_fn: SparsifyFn, use_kernel: bool = True):
         super().__init__()
         self.linear, self.sparse_fn, self.use_kernel = linear, sparse_fn, use_kernel
-        self._wcm: Optional[torch.Tensor] = None  # column-major (padded) copy for the kernel, built lazily
 
     @property
     def weight(self):
@@ -50,14 +49,13 @@ class SparsifiedLinear(nn.Module):
         return self.linear.bias
 
     def _kernel_weight(self) -> torch.Tensor:
-        w = self.linear.weight
-        if self._wcm is None or self._wcm.device != w.device or self._wcm.dtype != w.dtype:
-            from .monkeypatch import ROW_PAD
-            N, Z = w.shape
-            buf = torch.zeros(Z, N + ROW_PAD, dtype=w.dtype, device=w.device)
-            buf[:, :N] = w.detach().T
-            self._wcm = buf[:, :N].T
-        return self._wcm
+        """the linear's OWN weight, re-laid out in place as W^T [Z][N + pad] behind the same [N, Z] view
+        (monkeypatch.to_column_major: F.linear accepts the strided view, so prefill and decode read one copy and a
+        load_state_dict / in-place update can never leave a stale duplicate).  A weight tensor replaced wholesale
+        (load_state_dict(assign=True)) is row-major again and is simply re-laid out at the next single-token call."""
+        from .monkeypatch import to_column_major
+        to_column_major(self.linear)
+        return self.linear.weight
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         w = self.linear.weight

@@ -64,5 +64,18 @@ def quantize_model_int8(model: nn.Module) -> nn.Module:
     return model
 
 
+def convert_for_runtime_int8(model: nn.Module, dtype=torch.bfloat16) -> nn.Module:
+    """Replace every nn.Linear by an EMPTY WeightOnlyInt8Linear (WeightOnlyInt8QuantHandler.convert_for_runtime,
+    quantize.py:332-337 / replace_linear_weight_only_int8_per_channel): the shape an int8 checkpoint's state dict
+    (`weight` int8, `scales`) loads into."""
+    for name, child in list(model.named_children()):
+        if isinstance(child, nn.Linear):
+            dev = child.weight.device
+            setattr(model, name, WeightOnlyInt8Linear(child.in_features, child.out_features, device=dev, dtype=dtype))
+        else:
+            convert_for_runtime_int8(child, dtype)
+    return model
+
+
 def is_int8(lin: nn.Module) -> bool:
     return isinstance(lin, WeightOnlyInt8Linear)

@@ -169,6 +169,19 @@ def test_generate_main_synthetic_cli(extra):
 
 
 @pytest.mark.gpu
+def test_compile_prefill_generates_the_same_tokens():
+    """--compile --compile_prefill on the default (engine) path: the prefill graph is captured before the engine exists;
+    the engine then re-lays the weights out (freeing the storage a stale graph would still point at).  Every timed sample
+    must produce the tokens of the run without a prefill graph, across several samples (allocator reuse in between)."""
+    base = ["--synthetic", "tiny-test", "--sparsity", "0.5", "--compile", "--num_samples", "3", "--max_new_tokens", "24", "--top_k", "1"]
+    a = G.main(G.build_parser().parse_args(base))
+    junk = [torch.randn(1 << 16, device="cuda") for _ in range(16)]  # churn the caching allocator between the two runs
+    b = G.main(G.build_parser().parse_args(base + ["--compile_prefill"]))
+    del junk
+    assert len(a["sequences"]) == 3 and a["sequences"] == b["sequences"]
+
+
+@pytest.mark.gpu
 def test_generate_greedy_fixture_table():
     """block-wise greedy sparsities from the reference-derived table (tests/golden/greedy_llama2_7b.json):
     three distinct q/k/v thresholds and gate != up reach the kernels."""

@@ -83,7 +83,14 @@ def test_sparsified_linear_decode_uses_hip_kernel(tmp_path):
     with torch.no_grad():
         y = sl(x)                                   # HIP sparse GEMV
         ref = torch.nn.functional.linear(fn(x), lin.weight)  # masked dense, reference semantics
-        assert sl._wcm is not None and y.shape == ref.shape
+        # the kernel path re-laid the linear's own weight out column-major in place (no second copy to go stale)
+        assert lin.weight.stride(0) == 1 and lin.weight.shape == (768, 512) and y.shape == ref.shape
         assert torch.allclose(y.float(), ref.float(), atol=3e-3, rtol=3e-3)
         xb = torch.randn(1, 6, 512, device="cuda", dtype=torch.float16)
         assert torch.allclose(sl(xb), torch.nn.functional.linear(fn(xb), lin.weight))  # prefill: eager path
+        # an in-place weight update and a wholesale replacement (load_state_dict(assign=True)) both reach the kernel path
+        lin.weight.data.mul_(2.0)
+        assert torch.allclose(sl(x).float(), 2 * y.float(), atol=6e-3, rtol=3e-3)
+        lin.load_state_dict({"weight": torch.randn(768, 512, device="cuda", dtype=torch.float16) * 0.05}, assign=True)
+        y3 = sl(x)
+        assert torch.allclose(y3.float(), torch.nn.functional.linear(fn(x), lin.weight).float(), atol=3e-3, rtol=3e-3)
