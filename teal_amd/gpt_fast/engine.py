@@ -476,7 +476,8 @@ def make_engine_stepper(model: Transformer, a):
         eng = DecodeEngine(model, ths, att_split=int(getattr(a, "att_split", 0)), pair=getattr(a, "pair", None))
         span = min(a.warmup + a.steps + 4, eng.max_seq - npr)
         if a.sparsity > 0 and getattr(a, "decode_calibration", True):
-            # thresholds for the kept fraction ON THE MEASURED DECODE POSITIONS (see calibrate_on_decode)
+            # thresholds for the kept fraction ON THE MEASURED DECODE POSITIONS (apply_sparsity's synthetic mode already
+            # refined them on a generic 200-token decode; this takes them on exactly the timed range)
             sp = {p: [a.sparsity] * len(model.layers) for p in eng.SITE}
             ths = eng.calibrate_on_decode(sp, tok, npr, span)
         eng.tok_buf.copy_(tok.view(1, 1))

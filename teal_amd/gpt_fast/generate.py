@@ -147,8 +147,36 @@ def calibrate_thresholds(model: Transformer, sparsities: Dict[str, List[float]],
     return out
 
 
+@torch.no_grad()
+def refine_thresholds_on_decode(model: Transformer, sparsities: Dict[str, List[float]], ths: List[Dict[str, float]],
+                                n_prompt: int = 24, n_decode: int = 200) -> List[Dict[str, float]]:
+    """Synthetic mode, GPU: re-take the thresholds on the DECODE path (engine.calibrate_on_decode) so that every
+    projection keeps its target fraction on decode activations — with random weights the attention output shrinks with
+    the context length, and thresholds from a short prefill keep ~10 % of the o-projection's rows after 100 positions.
+    The refined values are written back into the blocks' thresh_* attributes; the caches are released again."""
+    from teal_amd.gpt_fast.engine import DecodeEngine
+    dev = model.output.weight.device
+    span = min(n_decode, model.config.block_size - n_prompt - 8)
+    if span < 8:
+        return ths
+    model.max_seq_length, model.max_batch_size = -1, -1
+    model.setup_caches(max_batch_size=1, max_seq_length=n_prompt + span + 8)
+    toks = torch.randint(0, model.config.vocab_size, (n_prompt,), device=dev, dtype=torch.int,
+                         generator=torch.Generator(device=dev).manual_seed(97))
+    model(toks.view(1, -1), torch.arange(n_prompt, device=dev))
+    eng = DecodeEngine(model, ths)
+    ths = eng.calibrate_on_decode(sparsities, toks[-1:].clone(), n_prompt, span)
+    for layer, th in zip(model.layers, ths):
+        at, ff = layer.attention, layer.feed_forward
+        at.thresh_q, at.thresh_k, at.thresh_v, at.thresh_o = th["q"], th["k"], th["v"], th["o"]
+        ff.thresh_gate, ff.thresh_up, ff.thresh_down = th["gate"], th["up"], th["down"]
+    del eng
+    model.max_seq_length, model.max_batch_size = -1, -1  # let generate() size the caches again
+    return ths
+
+
 def apply_sparsity(model: Transformer, *, sparsity: float, hist_path: Optional[str], greedy_lookup: Optional[str],
-                   synthetic: bool) -> List[Dict[str, float]]:
+                   synthetic: bool, decode_calibration: bool = True) -> List[Dict[str, float]]:
     """monkeypatch every layer (gpt-fast/generate.py:328-331); returns the thresholds used."""
     L = len(model.layers)
     if greedy_lookup and greedy_lookup.endswith(".json"):
@@ -167,6 +195,8 @@ def apply_sparsity(model: Transformer, *, sparsity: float, hist_path: Optional[s
         ths = calibrate_thresholds(model, sparsities)
         for i, layer in enumerate(model.layers):
             monkeypatch_layer(i, layer, sparsity, None, device, thresholds=ths[i])
+        if decode_calibration and device == "cuda" and any(float(v) > 0 for vals in sparsities.values() for v in vals):
+            ths = refine_thresholds_on_decode(model, sparsities, ths)
     else:
         ths = [monkeypatch_layer(i, layer, sparsity, hist_path, device, sparsities=sparsities)
                for i, layer in enumerate(model.layers)]
@@ -305,12 +335,10 @@ class GraphedPrefill:
 class EngineDecoder:
     """GraphedDecoder's role for the fused HIP engine: built lazily once the KV caches exist."""
 
-    def __init__(self, torch_model: Transformer, thresholds, use_graph: bool, temperature: float, top_k: Optional[int],
-                 decode_calibration: Optional[Dict[str, List[float]]] = None):
+    def __init__(self, torch_model: Transformer, thresholds, use_graph: bool, temperature: float, top_k: Optional[int]):
         self.torch_model, self.thresholds, self.use_graph = torch_model, thresholds, use_graph
         self.kw = dict(temperature=temperature, top_k=top_k)
         self._engine, self._key = None, None
-        self.decode_calibration = decode_calibration  # synthetic mode: per-projection target sparsities
 
     def _cache_key(self):
         m = self.torch_model
@@ -325,15 +353,7 @@ class EngineDecoder:
         if self._engine is None or self._key != key:
             from teal_amd.gpt_fast.engine import DecodeEngine
             self._engine, self._key = DecodeEngine(self.torch_model, self.thresholds), key
-            self._calibrated = False
         return self._engine
-
-    def maybe_calibrate(self, first_token: torch.Tensor, pos0: int, n_steps: int):
-        """synthetic thresholds re-taken on the decode path once the engine exists (engine.calibrate_on_decode)"""
-        eng = self.model
-        if self.decode_calibration and not self._calibrated and n_steps >= 2:
-            self.thresholds = eng.calibrate_on_decode(self.decode_calibration, first_token, pos0, n_steps)
-            self._calibrated = True
 
 
 @torch.no_grad()
@@ -350,8 +370,6 @@ def generate(model: Transformer, prompt: torch.Tensor, max_new_tokens: int, deco
     next_token = sample(logits, temperature=temperature, top_k=top_k)[0].clone()
     seq[T] = next_token
     if hasattr(decoder.model, "decode_n"):  # HIP engine: the whole loop stays on the device
-        if hasattr(decoder, "maybe_calibrate"):
-            decoder.maybe_calibrate(next_token, T, max_new_tokens - 1)
         toks = decoder.model.decode_n(next_token, T, max_new_tokens - 1, temperature=decoder.kw["temperature"],
                                       top_k=decoder.kw["top_k"], use_graph=decoder.use_graph)
         seq[T + 1:] = toks.to(seq.dtype)
@@ -392,6 +410,8 @@ def main(args) -> Dict:
         print("Monkeypatching with activation sparsity...")
         thresholds = apply_sparsity(model, sparsity=args.sparsity, hist_path=args.hist_path,
                                     greedy_lookup=args.greedy_lookup, synthetic=bool(args.synthetic))
+    if getattr(args, "no_fused_decode", False):
+        model.fused_decode = False
     torch.cuda.synchronize()
     print(f"Time to load model: {time.time() - t0:.02f} seconds")
     torch.manual_seed(1234)
@@ -400,10 +420,7 @@ def main(args) -> Dict:
     use_engine = args.engine or (args.compile and thresholds is not None and not getattr(args, "no_engine", False))
     if use_engine:
         assert thresholds is not None, "--engine needs thresholds (--hist_path or --synthetic)"
-        cal = None
-        if args.synthetic and args.sparsity > 0 and not args.greedy_lookup:
-            cal = {p: [args.sparsity] * len(model.layers) for p in PROJS}
-        decoder = EngineDecoder(model, thresholds, args.compile, args.temperature, args.top_k, decode_calibration=cal)
+        decoder = EngineDecoder(model, thresholds, args.compile, args.temperature, args.top_k)
         # the engine re-lays every projection (and lm_head) out column-major when it is built, lazily, after the first
         # prefill: do it NOW so that a --compile_prefill graph never captures pointers to storage that is freed later
         from teal_amd.monkeypatch import to_column_major
@@ -440,6 +457,10 @@ def main(args) -> Dict:
     print("==========")
     if thresholds is not None and args.report_kept:
         report_kept_fractions(model, thresholds, prompt)
+        if use_engine and args.max_new_tokens > 4:
+            eng = decoder.model  # all seven projections, on the DECODE activations of the generated range
+            kf = eng.mean_kept_fractions(prompt[-1:].clone(), prompt.numel(), min(args.max_new_tokens - 1, eng.max_seq - prompt.numel()), 3)
+            print("achieved kept fraction (decode activations):", {k: round(v, 3) for k, v in kf.items()})
     mean = sum(tps) / max(1, len(tps))
     print(f"Average tokens/sec: {mean:.2f}")
     print(f"Memory used: {torch.cuda.max_memory_reserved() / 1e9:.02f} GB")
@@ -472,8 +493,11 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--report_kept", action="store_true", help="print the achieved kept fraction per projection")
     p.add_argument("--engine", action="store_true", help="fused HIP decode step (teal_amd/gpt_fast/engine.py); implied by --compile "
                    "when thresholds are installed")
-    p.add_argument("--no_engine", action="store_true", help="with --compile: capture the reference-shaped module path "
-                   "(torch.ops.teal.* + eager glue) instead of the fused engine")
+    p.add_argument("--no_engine", action="store_true", help="with --compile: drive the patched model exactly as the reference "
+                   "harness does (model(token, pos) -> torch sampler, captured in a hipGraph) instead of the device-resident "
+                   "engine loop; single-token calls still run the fused HIP decode step (Transformer.fused_decode)")
+    p.add_argument("--no_fused_decode", action="store_true", help="op-by-op module path (torch.ops.teal.* + eager glue) for "
+                   "single-token calls: A/B against the fused decode step")
     return p
 
 

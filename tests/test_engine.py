@@ -13,6 +13,7 @@ DEV = "cuda"
 def _models(dtype, sparsity, seed=3):
     from teal_amd.gpt_fast import generate as G
     ref = G.build_synthetic_model("tiny-test", DEV, dtype, seed=seed, std=0.05)
+    ref.fused_decode = False  # the reference side of every comparison is the op-by-op module path
     eng_m = G.build_synthetic_model("tiny-test", DEV, dtype, seed=seed, std=0.05)
     ths = G.apply_sparsity(ref, sparsity=sparsity, hist_path=None, greedy_lookup=None, synthetic=True)
     G.apply_sparsity(eng_m, sparsity=sparsity, hist_path=None, greedy_lookup=None, synthetic=True)
@@ -304,6 +305,7 @@ def test_engine_matches_module_path_full_width(name, dtype, n_layer, int8):
     from teal_amd.gpt_fast.engine import DecodeEngine
     from teal_amd.quantize import quantize_model_int8
     ref = G.build_synthetic_model(name, DEV, dtype, seed=5, n_layer=n_layer)
+    ref.fused_decode = False
     eng_m = G.build_synthetic_model(name, DEV, dtype, seed=5, n_layer=n_layer)
     if int8:
         quantize_model_int8(ref)
@@ -379,6 +381,7 @@ def test_engine_long_context_uses_split_attention(block, plen, fused):
     from teal_amd.gpt_fast import generate as G
     from teal_amd.gpt_fast.engine import DecodeEngine
     ref = G.build_synthetic_model("tiny-test", DEV, torch.float16, seed=3, std=0.05)
+    ref.fused_decode = False
     eng_m = G.build_synthetic_model("tiny-test", DEV, torch.float16, seed=3, std=0.05)
     for m in (ref, eng_m):
         m.config.block_size = block

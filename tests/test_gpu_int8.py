@@ -135,6 +135,7 @@ def test_int8_engine_matches_int8_module_path(dtype, sparsity):
     from teal_amd.gpt_fast.engine import DecodeEngine
     from teal_amd.quantize import quantize_model_int8
     ref = quantize_model_int8(G.build_synthetic_model("tiny-test", DEV, dtype, seed=3, std=0.05))
+    ref.fused_decode = False  # op-by-op module path
     eng_m = quantize_model_int8(G.build_synthetic_model("tiny-test", DEV, dtype, seed=3, std=0.05))
     ths = G.apply_sparsity(ref, sparsity=sparsity, hist_path=None, greedy_lookup=None, synthetic=True)
     G.apply_sparsity(eng_m, sparsity=sparsity, hist_path=None, greedy_lookup=None, synthetic=True)
