@@ -21,6 +21,8 @@ Fixtures written:
   F5 kat_boundary.npz        compare-rule edge values run through the reference kernel
   F6 hist/…/histograms.pt, lookup/…/results.csv   raw calibration data files (MIT, data only)
   F7 kat_hist_producer.npz   ActivationModule.find_histogram on seeded activations (producer-side KAT)
+  F9 greedy_driver/          teal/greedyopt.py process_layer (the greedy driver + the reference's SparsifyFn wiring) run
+                             on a tiny seeded block: model.pt, histograms/, activations/, lookup/layer-i/results.csv
 
 Usage:  python oracle/gen_golden.py [--quick]
 """
@@ -294,6 +296,79 @@ def gen_hist_producer():
     print("  F7 find_histogram:", {k: tuple(v.shape) for k, v in hist.items()})
 
 
+def gen_greedy_driver():
+    """F9: the reference's block-wise greedy optimiser DRIVER (teal/greedyopt.py:99-159 process_layer, with its own
+    f(), step sizes, calculate_activation_error / calculate_baseline_error and CSV writer) and its own SparsifyFn /
+    Distribution wiring (teal/mlp.py:14-35, teal/self_attn.py:21-44 _monkeypatch_* on holder modules), executed here
+    on a tiny seeded gpt-fast-shaped block.  The reference's HF decoder-layer forward cannot run in this image
+    (transformers 5.x changed LlamaDecoderLayer.forward's signature: 'takes from 2 to 7 positional arguments but 8 were
+    given'), so the block arithmetic behind the driver is teal_amd.calibrate.layer_forward — the same on both sides of
+    the test; what the fixture pins is every decision the optimiser takes and every number it writes."""
+    import teal.greedyopt as RG  # type: ignore
+    import teal.mlp as RM  # type: ignore
+    import teal.self_attn as RS  # type: ignore
+    from teal_amd.calibrate import _prefill_tables, grab_histograms, layer_forward
+    from teal_amd.gpt_fast.model import ModelArgs, Transformer
+    out = os.path.join(OUT, "greedy_driver")
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(out)
+    cfg = ModelArgs(block_size=64, vocab_size=128, n_layer=2, n_head=4, dim=64, intermediate_size=128, n_local_heads=2)
+    torch.manual_seed(20240907)
+    model = Transformer(cfg).eval()
+    with torch.no_grad():
+        for n, prm in model.named_parameters():
+            prm.copy_(torch.ones_like(prm) if n.endswith("norm.weight") else torch.randn_like(prm) * 0.08)
+    torch.save(model.state_dict(), os.path.join(out, "model.pt"))
+    ids = torch.randint(0, cfg.vocab_size, (2, 48), generator=torch.Generator().manual_seed(5))
+    grab_histograms(model, ids, out, num_bins=2000)
+    meta = dict(config=dict(block_size=64, vocab_size=128, n_layer=2, n_head=4, dim=64, intermediate_size=128, n_local_heads=2),
+                model_type="Llama-2-7B", target_sparsity=0.6, base_step_size=0.05, last_fraction=0.25, num_bins=2000)
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.anchor = torch.nn.Parameter(torch.zeros(1))
+
+    class Block(torch.nn.Module):
+        """what process_layer needs from a decoder layer: .mlp.sparse_fns, .self_attn.sparse_fns, .to(), __call__"""
+
+        def __init__(self, blk, i, fc, mask):
+            super().__init__()
+            self.blk, self.fc, self.mask = blk, fc, mask
+            self.mlp = RM._monkeypatch_mlp(Holder(), os.path.join(out, "histograms", f"layer-{i}", "mlp"))
+            self.self_attn = RS._monkeypatch_self_attn(Holder(), os.path.join(out, "histograms", f"layer-{i}", "self_attn"))
+
+        def to(self, *a, **k):
+            return self
+
+        def forward(self, hidden_states, attention_mask, position_ids, past_key_value, output_attentions, use_cache, cache_position):
+            sp = {**dict(self.self_attn.sparse_fns.items()), **dict(self.mlp.sparse_fns.items())}
+            return (layer_forward(self.blk, hidden_states, self.fc, self.mask, sp),)
+
+    orig_to = torch.Tensor.to
+
+    def to_no_cuda(self, *a, **k):
+        if a and a[0] == "cuda":
+            return self
+        return orig_to(self, *a, **k)
+
+    torch.Tensor.to = to_no_cuda
+    try:
+        with torch.no_grad():
+            for i, blk in enumerate(model.layers):
+                acts = torch.load(os.path.join(out, "activations", f"act_{i}.pt"))
+                fc, mask = _prefill_tables(model, acts.shape[1], acts.device)
+                final = RG.process_layer(Block(blk, i, fc, mask), meta["model_type"], i, meta["target_sparsity"],
+                                         meta["base_step_size"], meta["last_fraction"], out)
+                meta[f"final_{i}"] = final
+    finally:
+        torch.Tensor.to = orig_to
+    with open(os.path.join(out, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    rows = sum(1 for _ in open(os.path.join(out, "lookup", "layer-0", "results.csv"))) - 1
+    print(f"  F9 greedy driver: {rows} steps for layer 0; final {meta['final_0']}")
+
+
 def gen_int8():
     """F8: the reference's int8 weight-only quantiser and module (gpt-fast/quantize.py:24-56, :339-357), run here:
     q / scales of a seeded weight (incl. an all-zero row, a row whose extreme is negative, a row of tiny values),
@@ -373,6 +448,7 @@ def main():
         "qkv": lambda: gen_qkv_kats(qkv_inner, a.quick),
         "hist_producer": gen_hist_producer,
         "int8": gen_int8,
+        "greedy_driver": gen_greedy_driver,
         "raw": copy_raw_data,
     }
     for name, fn in steps.items():

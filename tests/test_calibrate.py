@@ -70,3 +70,35 @@ def test_greedy_optimiser_csv_and_monotonicity(tmp_path):
     # the table is consumable by the reference-shaped lookup reader
     sp = get_layer_greedy_sparsities([0.2, 0.2], str(tmp_path / "lookup"))
     assert set(sp) == {"q", "k", "v", "o", "gate", "up", "down"} and len(sp["q"]) == 2
+
+
+def test_greedy_optimiser_reproduces_the_reference_driver(tmp_path):
+    """F9 (oracle/gen_golden.py:gen_greedy_driver): the reference's own process_layer (teal/greedyopt.py:99-159) ran on
+    this tiny seeded block with the reference's SparsifyFn / Distribution wiring; greedy_optimize_layer must take the same
+    decisions step by step (which projection is raised, by how much) and write the same rows."""
+    import json
+    import os
+
+    from helpers import GOLDEN
+    from teal_amd.calibrate import WEIGHT_DICT, _prefill_tables, greedy_optimize_layer
+    from teal_amd.gpt_fast.model import ModelArgs, Transformer
+    fx = os.path.join(GOLDEN, "greedy_driver")
+    meta = json.load(open(os.path.join(fx, "meta.json")))
+    model = Transformer(ModelArgs(**meta["config"])).eval()
+    model.load_state_dict(torch.load(os.path.join(fx, "model.pt"), weights_only=True))
+    weights = WEIGHT_DICT[meta["model_type"]]
+    for i, layer in enumerate(model.layers):
+        acts = torch.load(os.path.join(fx, "activations", f"act_{i}.pt"), weights_only=True)
+        fc, mask = _prefill_tables(model, acts.shape[1], acts.device)
+        out_csv = tmp_path / f"layer-{i}.csv"
+        final = greedy_optimize_layer(layer, i, acts, os.path.join(fx, "histograms"), str(out_csv), weights, fc, mask,
+                                      target_sparsity=meta["target_sparsity"], base_step_size=meta["base_step_size"],
+                                      last_fraction=meta["last_fraction"])
+        got = list(csv.reader(open(out_csv)))
+        want = list(csv.reader(open(os.path.join(fx, "lookup", f"layer-{i}", "results.csv"))))
+        assert got[0] == want[0] and len(got) == len(want) > 50
+        for g, w in zip(got[1:], want[1:]):
+            assert [float(v) for v in g[3:]] == [float(v) for v in w[3:]], "per-projection sparsities of a step"
+            assert float(g[0]) == float(w[0])                                   # effective sparsity: same arithmetic
+            assert np.allclose([float(g[1]), float(g[2])], [float(w[1]), float(w[2])], rtol=1e-4, atol=1e-6)
+        assert {k: float(v) for k, v in final.items()} == {k: float(v) for k, v in meta[f"final_{i}"].items()}
