@@ -21,8 +21,10 @@
  * Conventions
  *   - extern "C", plain pointers and sizes, no C++/torch types, no exceptions across the boundary.
  *   - All pointers are DEVICE pointers owned by the caller (PyTorch); the library borrows them for
- *     the duration of the stream-ordered launch and keeps no mutable global state (only immutable
- *     device properties cached by teal_init()).
+ *     the duration of the stream-ordered launch and never allocates.  Process-global state: the device
+ *     properties cached by teal_init() (immutable), and the diagnostics / tuning switches of the last
+ *     section (teal_set_tuning, teal_set_fast, teal_set_wave_local, teal_set_swizzle, teal_set_phase_*):
+ *     host-side variables read at launch time, NOT thread-safe, meant for benchmarks and tests.
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Every call is
  *     asynchronous, allocation-free and hipGraph-capture safe.
  *   - dtype: 0 = fp16, 1 = bf16 (x, weights and y share it; int8 weights carry scales in that dtype).
@@ -67,8 +69,10 @@ const char* teal_strerror(int code);
  * may happen during stream capture.  Returns the CU count (> 0) or a negative error. */
 int teal_init(void);
 
-/* Bytes of fp32 split-K workspace a GEMV of this shape may need (upper bound over all launch
- * geometries).  The caller allocates once and reuses; distinct streams need distinct workspaces. */
+/* Bytes of fp32 split-K workspace a GEMV with N output columns may need: an upper bound over all launch
+ * geometries (the deepest split x two N-column segments), which does not depend on Z — Z is accepted for
+ * symmetry with the GEMV entry points.  The caller allocates once and reuses; distinct streams need distinct
+ * workspaces. */
 size_t teal_workspace_bytes(int Z, int N);
 
 /* idx_out[0..count) = ascending m with float32(|x[m]|) > float32(tau); *count_out = count.
@@ -95,8 +99,6 @@ int teal_sparse_qkv_gemv_ld(const void* x, const void* wT, int ld, void* y, floa
                             float tau_v, int Z, int N, int N_q, int N_kv, int dtype, void* ws,
                             size_t ws_bytes, void* stream);
 
-/* y = x @ W^T with every row kept (prefill-free decode of un-sparsified layers, e.g. lm_head).
- * (kernels/sparse_gemv.py:301-307) */
 /* int8 weight-only variant of teal_sparse_qkv_gemv_ld (the reference ships int8 only for its
  * dense path, gpt-fast/quantize.py:339-357, and lists quantised TEAL as missing, README.md:110).  wqT = int8 image of
  * W^T, row-major [Z][ld] bytes (ld % 8 == 0, ld >= N); scale[N] in the activation dtype.  N_kv = 0, N_q = N: one
@@ -105,6 +107,8 @@ int teal_sparse_qkv_gemv_i8(const void* x, const void* wqT, const void* scale, v
                             float tau_v, int Z, int N, int N_q, int N_kv, int ld, int dtype, void* ws, size_t ws_bytes,
                             void* stream);
 
+/* y = x @ W^T with every row kept (prefill-free decode of un-sparsified layers, e.g. lm_head).
+ * (kernels/sparse_gemv.py:301-307) */
 int teal_dense_gemv(const void* x, const void* wT, void* y, int Z, int N, int dtype, void* ws,
                     size_t ws_bytes, void* stream);
 
@@ -240,7 +244,8 @@ const char* teal_last_launch_desc(void);
 /* Lean kernel for qualifying shapes (default on; 0 forces the general kernel everywhere: A/B and parity tests). */
 int teal_set_fast(int on);
 
-/* Column-tile XOR swizzle that spreads every XCD over all DRAM channel residues (default on). */
+/* Column-tile XOR swizzle that spreads every XCD over all DRAM channel residues.  Default OFF (0): measured neutral
+ * once the row stride is padded; a launch with the swizzle on uses the general kernel. */
 int teal_set_swizzle(int on);
 
 /* Diagnostics: when set (device pointer to >= 24 * workgroups uint64; the last 16 per workgroup receive each

@@ -28,7 +28,7 @@ namespace teal {
 // issued (an "s" input forces the value into an SGPR at this point of the program)
 #define TEAL_FAST_ARGS_BATCH(a)                                                                                         \
     asm volatile("" ::"s"((a).w0), "s"((a).w1), "s"((a).y), "s"((a).ws), "s"((a).mask_out), "s"((a).resid_out),          \
-                 "s"((a).phase), "s"((a).ld0), "s"((a).ld1), "s"((a).seg_tile1), "s"((a).seg_tile2), "s"((a).tau0),       \
+                 "s"((a).phase), "s"((a).ticket), "s"((a).ld0), "s"((a).ld1), "s"((a).seg_tile1), "s"((a).seg_tile2), "s"((a).tau0),       \
                  "s"((a).tau1), "s"((a).tau2), "s"((a).mask_tau), "s"((a).ws_stride), "s"((a).att_hd), "s"((a).att_ns),  \
                  "s"((a).cap))
 
@@ -365,8 +365,35 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
             if (a.mask_out && lane == 0) a.mask_out[c >> 6] = mko;
         } else if (a.ws_stride == 0) {
             reinterpret_cast<uint16_t*>(a.y)[c] = float_to_bits<BF16>(gs);
-        } else {
+        } else if (!a.ticket) {
             a.ws[c * (uint32_t)a.ws_stride + slice] = gs;
+        } else {
+            // publish the partial write-through (agent-scope relaxed atomic store = global_store ... sc1)
+            __hip_atomic_store(&a.ws[c * (uint32_t)a.ws_stride + slice], gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if constexpr (!PAIR) {
+        if (a.ticket) {
+            // Split-K with ONE launch (replaces the reference's memset + fp16 atomics, kernels/sparse_gemv.py:8-12,83, and
+            // the ordered reduce launch): every slice of a tile publishes its fp32 partial write-through, drains, and takes
+            // a ticket; the last to arrive sums the `split` partials IN SLICE ORDER (bit-identical to the reduce launch, no
+            // matter who arrives last), rounds once, stores y and re-arms the counter.
+            float* tflag = reinterpret_cast<float*>(smem);  // the RMSNorm scratch is free by now
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned t = __hip_atomic_fetch_add(&a.ticket[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tflag[0] = (t == (unsigned)split - 1u) ? 1.0f : 0.0f;
+            }
+            __syncthreads();
+            if (tflag[0] != 0.0f && tid < BN) {
+                const uint32_t c = (uint32_t)tile * BN + tid;
+                float sum = 0.0f;
+                for (int sl = 0; sl < split; ++sl)
+                    sum += __hip_atomic_load(&a.ws[c * (uint32_t)a.ws_stride + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                reinterpret_cast<uint16_t*>(a.y)[c] = float_to_bits<BF16>(sum);
+                if (tid == 0) __hip_atomic_store(&a.ticket[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     stamp(7);

@@ -12,6 +12,8 @@ struct FastArgs {
     unsigned long long* mask_out;   // PAIR: keep masks of h vs mask_tau (or null)
     void* resid_out;                // MODE 1: updated residual stream, written by workgroup (0, 0) (or null)
     unsigned long long* phase;      // PHASE instantiations: stamp buffer
+    unsigned* ticket;               // split > 1 with a rounded output: per-tile arrival counters (zero between launches);
+                                    // the last slice of a tile to arrive sums the slabs in slice order and stores y
     int ld0, ld1;                   // row strides in elements
     int seg_tile1, seg_tile2;       // first tile of threshold segments 1 and 2 (INT_MAX when absent)
     float tau0, tau1, tau2;         // thresholds (PAIR: tau0 = gate, tau1 = up)

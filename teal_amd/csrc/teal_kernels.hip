@@ -129,6 +129,9 @@ int g_phase_seq = 0;
 int g_swizzle = 0;
 int g_wave_local = 1;
 int g_fast = 1;  // lean kernel (teal_gemv_fast.h) where the shape qualifies
+unsigned* g_tickets = nullptr;  // kTicketSlots x kTicketTiles arrival counters (zeroed once; every launch re-arms its own)
+unsigned g_ticket_seq = 0;
+constexpr int kTicketSlots = 64, kTicketTiles = 4096;
 char g_last_desc[160] = "";  // template instantiation + grid of the most recent GEMV launch (teal_last_launch_desc)
 
 
@@ -203,13 +206,19 @@ Config pick_config(int Z, int ncols_total, int nseg_tiles_hint) {
 
 // Does this launch qualify for the lean kernel (teal_gemv_fast.h)?  16-bit weights, whole chunks and tiles, one weight
 // image (or the gate|up pair), interleaved slabs or a single rounded output, wave-local lists that fit.
-bool fast_eligible(const Params& p, const Config& c, bool to_ws, FastLaunch& f) {
+bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes, FastLaunch& f) {
     if (!g_fast || p.w8 || c.waves != 16 || c.unroll != 4 || (c.lpr != 8 && c.lpr != 16) || p.swizzle) return false;
     if ((p.Z & 63) || p.Z > 65536 || !p.wl) return false;
     const int mode = p.in.mode;
     if (mode != 0 && mode != 1 && mode != 3 && mode != 4) return false;
     const int bn = c.lpr * 8, nch = p.Z >> 6, owned_all = (nch + 15) / 16;
-    if (to_ws ? (!p.ws_il || c.split > 8) : (c.split != 1)) return false;
+    // outputs: interleaved slabs for the next launch; one rounded vector (split == 1); or split > 1 folded into ONE
+    // launch by arrival tickets (the last slice of a tile sums the partials in slice order)
+    const bool ticketed = !to_ws && c.split > 1;
+    if (to_ws ? (!p.ws_il || c.split > 8) : (c.split > 8)) return false;
+    if (ticketed && (!g_tickets || p.ntiles > kTicketTiles || !p.ws ||
+                     ws_bytes < (size_t)((c.split + 3) & ~3) * (size_t)p.ws_ld * sizeof(float)))
+        return false;
     const int nseg = p.pair ? 2 : p.nseg;
     int off = 0;
     for (int i = 0; i < nseg; ++i) {
@@ -261,7 +270,8 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, FastLaunch& f) 
     f.a.tau0 = p.seg[0].tau; f.a.tau1 = p.seg[1].tau; f.a.tau2 = p.seg[2].tau;
     f.a.seg_tile1 = (!p.pair && p.nseg > 1) ? p.seg[1].tile0 : INT_MAX;
     f.a.seg_tile2 = (!p.pair && p.nseg > 2) ? p.seg[2].tile0 : INT_MAX;
-    f.a.ws_stride = to_ws ? ((c.split + 3) & ~3) : 0;
+    f.a.ws_stride = (to_ws || ticketed) ? ((c.split + 3) & ~3) : 0;
+    f.a.ticket = ticketed ? g_tickets + (size_t)(g_ticket_seq++ % kTicketSlots) * kTicketTiles : nullptr;
     return true;
 }
 
@@ -407,7 +417,7 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
     if (used) *used = c;
     {
         FastLaunch f;
-        if (fast_eligible(p, c, to_ws, f)) {
+        if (fast_eligible(p, c, to_ws, ws_bytes, f)) {
             snprintf(g_last_desc, sizeof g_last_desc, "gemv_fast_kernel<%s,%d,%s,%d,%d,%s,false> grid (%d,%d) x 1024",
                      dtype == TEAL_BF16 ? "true" : "false", f.mode, f.pair ? "true" : "false", f.lpr, f.kr,
                      (f.mode == 1 && f.Z == 1024 * f.kr) ? "true" : "false", f.ntiles, f.split);
@@ -477,6 +487,15 @@ int teal_init(void) {
     if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
         return TEAL_ERR_NO_DEVICE;
     g_num_cu = cu;
+    // arrival counters of the single-launch split-K GEMV: the one allocation this library makes, once, here (so not
+    // under stream capture — see the header); without it split-K GEMVs fall back to the two-launch form
+    if (!g_tickets) {
+        if (hipMalloc(&g_tickets, (size_t)kTicketSlots * kTicketTiles * sizeof(unsigned)) != hipSuccess ||
+            hipMemset(g_tickets, 0, (size_t)kTicketSlots * kTicketTiles * sizeof(unsigned)) != hipSuccess) {
+            g_tickets = nullptr;
+            (void)hipGetLastError();
+        }
+    }
     return cu;
 }
 
