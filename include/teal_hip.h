@@ -17,6 +17,7 @@
  *   teal_decode_attention* <- gpt-fast/model.py:170-186       RoPE, kv_cache.update, SDPA at S == 1
  *   teal_sample_topk       <- gpt-fast/generate.py:49-66      logits_to_probs + multinomial_sample_one
  *   teal_sparse_qkv_gemv_i8 <- gpt-fast/quantize.py:339-357   WeightOnlyInt8Linear.forward on the masked x
+ *   teal_sparse_qkv_gemv_i4 <- gpt-fast/quantize.py:58-162,483-526 group-quantised int4 linear on the masked x
  *
  * Conventions
  *   - extern "C", plain pointers and sizes, no C++/torch types, no exceptions across the boundary.
@@ -111,6 +112,19 @@ int teal_sparse_qkv_gemv_i8(const void* x, const void* wqT, const void* scale, v
  * (kernels/sparse_gemv.py:301-307) */
 int teal_dense_gemv(const void* x, const void* wT, void* y, int Z, int N, int dtype, void* ws,
                     size_t ws_bytes, void* stream);
+
+/* int4 group-quantised weight-only variant (the reference ships int4-g32/64/128/256 for its dense
+ * path only: gpt-fast/quantize.py:58-162 group q-params / quantise / dequantise, :483-526 WeightOnlyInt4Linear over a
+ * CUDA-only packed layout).  w[n][m] = (q - 8) * scale[m / G][n] + zero[m / G][n], q in 0..15.
+ *   wq               column-gathered nibble image of W^T: row-major [Z][ldb] BYTES (ldb >= N / 2, ldb % 4 == 0), byte j of
+ *                    row m = columns 2j (low nibble) and 2j + 1 (high nibble)
+ *   scales_and_zeros bf16 [Z / G][N][2] = {scale, zero}, exactly the reference's tensor (quantize.py:79-93)
+ * N, N_q, N_kv multiples of 128; Z a multiple of G; x / y fp16 or bf16 (dtype).  N_kv = 0, N_q = N: one threshold.
+ * One launch (split-K over groups folded in by arrival tickets); fp32 accumulation, scale / zero applied once per
+ * (group, column), one rounding. */
+int teal_sparse_qkv_gemv_i4(const void* x, const void* wq, const void* scales_and_zeros, void* y, float tau_q, float tau_k,
+                            float tau_v, int Z, int N, int N_q, int N_kv, int ldb, int groupsize, int dtype, void* ws,
+                            size_t ws_bytes, void* stream);
 
 /* ---- fusions around the path ------------------------------------------ */
 

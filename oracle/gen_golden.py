@@ -21,6 +21,7 @@ Fixtures written:
   F5 kat_boundary.npz        compare-rule edge values run through the reference kernel
   F6 hist/…/histograms.pt, lookup/…/results.csv   raw calibration data files (MIT, data only)
   F7 kat_hist_producer.npz   ActivationModule.find_histogram on seeded activations (producer-side KAT)
+  F10 kat_int4.npz          group_quantize_tensor / group_dequantize_tensor (gpt-fast/quantize.py:58-162) for G = 32, 128
   F9 greedy_driver/          teal/greedyopt.py process_layer (the greedy driver + the reference's SparsifyFn wiring) run
                              on a tiny seeded block: model.pt, histograms/, activations/, lookup/layer-i/results.csv
 
@@ -416,6 +417,51 @@ def gen_int8():
     np.savez_compressed(os.path.join(OUT, "kat_int8.npz"), **out)
 
 
+def gen_int4():
+    """F10: the reference's int4 group quantiser (gpt-fast/quantize.py:58-162: get_group_qparams,
+    group_quantize_tensor(+_from_qparams, pack_scales_and_zeros), group_dequantize_tensor), run here on seeded weights
+    for group sizes 32 and 128: q, scales_and_zeros (bf16 [Z / G][N][2]), the dequantised weight, and — the composition
+    the int4 sparse GEMV implements — y = masked(x) @ dequant(W).T in float64 for a 3-threshold and a 1-threshold case.
+    (The reference module's own forward is a CUDA-only packed matmul, quantize.py:366-372; it cannot run here.)"""
+    sys.modules.setdefault("tiktoken", types.ModuleType("tiktoken"))
+    tl = types.ModuleType("tiktoken.load")
+    tl.load_tiktoken_bpe = lambda *a, **k: {}
+    sys.modules.setdefault("tiktoken.load", tl)
+    gf = os.path.join(REF, "gpt-fast")
+    if gf not in sys.path:
+        sys.path.insert(0, gf)
+    import quantize as RQ  # type: ignore
+
+    out = {}
+    for tag, G, N, Z, N_q, N_kv in (("g32", 32, 512, 1024, 256, 128), ("g128", 128, 128, 2048, 128, 0)):
+        wb = O.hash_uniform_c(N * Z, 501 + G, 0.1, O.BF16)
+        w = t16(wb, O.BF16).view(Z, N).T.contiguous().clone()  # [N, Z] bf16
+        w[3, :G] = 0                       # an all-zero group -> scale clamps to 1e-6
+        w[5, G:2 * G] = w[5, G:2 * G].abs() + 0.01   # an all-positive group
+        q, sz = RQ.group_quantize_tensor(w, n_bit=4, groupsize=G)
+        wdq = RQ.group_dequantize_tensor(q, sz.float(), 4, G)  # unpack_scales_and_zeros asserts float (quantize.py:96-98)
+        xb = O.hash_uniform(Z, 502 + G, 2.0, O.BF16)
+        x = t16(xb, O.BF16).float().view(Z)
+        taus = (0.5, 0.7, 0.3) if N_kv else (0.6, 0.6, 0.6)
+        cols = [(0, N_q, taus[0]), (N_q, N_q + N_kv, taus[1]), (N_q + N_kv, N, taus[2])]
+        y = np.zeros(N, np.float64)
+        for c0, c1, tau in cols:
+            if c1 > c0:
+                keep = x.abs() > torch.tensor(tau, dtype=torch.float32)
+                xm = torch.where(keep, x, torch.zeros_like(x)).double()
+                y[c0:c1] = (wdq[c0:c1].double() @ xm).numpy()
+        out[f"{tag}_w"] = w.view(torch.int16).numpy().view(np.uint16)
+        out[f"{tag}_q"] = q.numpy().astype(np.uint8)
+        out[f"{tag}_sz"] = sz.view(torch.int16).numpy().view(np.uint16)
+        out[f"{tag}_wdq_rows16"] = wdq[:16].float().numpy()  # a slice of the dequantised weight; y pins all of it
+        out[f"{tag}_x"] = xb
+        out[f"{tag}_taus"] = np.array(taus, np.float32)
+        out[f"{tag}_shape"] = np.array([N, Z, G, N_q, N_kv])
+        out[f"{tag}_y"] = y
+        print(f"  F10 int4 {tag}: N={N} Z={Z} q range {int(q.min())}..{int(q.max())}")
+    np.savez_compressed(os.path.join(OUT, "kat_int4.npz"), **out)
+
+
 def copy_raw_data():
     for sub in ("mlp", "self_attn"):
         for layer in (0, 15):
@@ -449,6 +495,7 @@ def main():
         "hist_producer": gen_hist_producer,
         "int8": gen_int8,
         "greedy_driver": gen_greedy_driver,
+        "int4": gen_int4,
         "raw": copy_raw_data,
     }
     for name, fn in steps.items():

@@ -11,14 +11,36 @@
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // lists: [16 waves][cap] row ids per wave (same for every workgroup, like one activation mask)
-template <int MODE, int NMAT, bool NT>
+// PFR > 0: before an idle window of `idle_ticks` (x 10 ns; stands for the producer + compaction phase, during which HBM
+// idles), every wave requests the first PFR rows of each of its 4 chunks DENSELY (default cache policy, so they stay in
+// L2); PFR == 0: the same idle window, no prefetch.  Then the kept rows are streamed as usual.
+template <int MODE, int NMAT, bool NT, int PFR = 0>
 __global__ __launch_bounds__(1024) void probe(const char* __restrict__ w0, const char* __restrict__ w1, const int* __restrict__ lists,
-                                              const int* __restrict__ counts, int cap, size_t ldb, size_t tile_bytes, unsigned* sink) {
+                                              const int* __restrict__ counts, int cap, size_t ldb, size_t tile_bytes, unsigned* sink,
+                                              int idle_ticks = 0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, cl = lane & 7;
     const int tile = blockIdx.x;
     const int n = counts[wave];
     const int* lp = lists + wave * cap;
     u32x4 acc = {0, 0, 0, 0};
+    if (idle_ticks > 0) {
+        const unsigned long long t0 = wall_clock64();
+        if constexpr (PFR > 0) {
+            u32x4 pv[4 * (PFR / 8) * NMAT];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int r = 0; r < PFR / 8; ++r) {
+                    const int row = (wave + 16 * k) * 64 + r * 8 + g;
+                    const char* p0 = w0 + (size_t)row * ldb + (size_t)tile * 128 + cl * 16;
+                    pv[(k * (PFR / 8) + r) * NMAT] = *reinterpret_cast<const u32x4*>(p0);
+                    if (NMAT == 2) pv[(k * (PFR / 8) + r) * NMAT + 1] = *reinterpret_cast<const u32x4*>(w1 + (size_t)row * ldb + (size_t)tile * 128 + cl * 16);
+                }
+#pragma unroll
+            for (int u = 0; u < 4 * (PFR / 8) * NMAT; ++u) acc ^= pv[u];
+        }
+        while (wall_clock64() - t0 < (unsigned long long)idle_ticks) {}
+    }
     auto ld = [&](const char* base, int row) {
         const char* p;
         if (MODE == 0) p = base + (size_t)row * ldb + (size_t)tile * 128 + cl * 16;
@@ -98,6 +120,17 @@ int main() {
     timeit("B tile-major  pair   nt (256 wgs)", [&](int i) { hipLaunchKernelGGL((probe<1, 2, true>), dim3(256), dim3(1024), 0, 0, bufs[2 * i], bufs[2 * i + 1], dl, dc, 256, 0, (size_t)Z * 128, sink); }, b2 * 256 / tiles);
     // row-major with a short row stride (the down projection's shape: ld = 4160): 172 / 256 workgroups... needs 256 * 128 B
     // = 32 KB of columns per row; use ld = 16448 elements (256 tiles + pad) within the same buffers (Z * 16448 * 2 = 134 MB > mat?)
+    for (int idle : {200, 300}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "A pair nt, idle %d0 ns, no prefetch", idle);
+        timeit(nm, [&](int i) { hipLaunchKernelGGL((probe<0, 2, true, 0>), dim3(tiles), dim3(1024), 0, 0, bufs[2 * i], bufs[2 * i + 1], dl, dc, 256, (size_t)ld * 2, 0, sink, idle); }, b2);
+        snprintf(nm, sizeof nm, "A pair nt, idle %d0 ns, prefetch 8 rows/chunk", idle);
+        timeit(nm, [&](int i) { hipLaunchKernelGGL((probe<0, 2, true, 8>), dim3(tiles), dim3(1024), 0, 0, bufs[2 * i], bufs[2 * i + 1], dl, dc, 256, (size_t)ld * 2, 0, sink, idle); }, b2);
+        snprintf(nm, sizeof nm, "A pair nt, idle %d0 ns, prefetch 16 rows/chunk", idle);
+        timeit(nm, [&](int i) { hipLaunchKernelGGL((probe<0, 2, true, 16>), dim3(tiles), dim3(1024), 0, 0, bufs[2 * i], bufs[2 * i + 1], dl, dc, 256, (size_t)ld * 2, 0, sink, idle); }, b2);
+        snprintf(nm, sizeof nm, "A pair nt, idle %d0 ns, prefetch 32 rows/chunk", idle);
+        timeit(nm, [&](int i) { hipLaunchKernelGGL((probe<0, 2, true, 32>), dim3(tiles), dim3(1024), 0, 0, bufs[2 * i], bufs[2 * i + 1], dl, dc, 256, (size_t)ld * 2, 0, sink, idle); }, b2);
+    }
     timeit("C contiguous 90 MB, 256 wgs", [&](int i) { hipLaunchKernelGGL(contig, dim3(256), dim3(1024), 0, 0, bufs[2 * i], (size_t)(90u << 20) / 256 / 65536 * 65536, sink); }, (double)((size_t)(90u << 20) / 256 / 65536 * 65536) * 256);
     timeit("C contiguous 90 MB, 172 wgs", [&](int i) { hipLaunchKernelGGL(contig, dim3(172), dim3(1024), 0, 0, bufs[2 * i], (size_t)(90u << 20) / 172 / 65536 * 65536, sink); }, (double)((size_t)(90u << 20) / 172 / 65536 * 65536) * 172);
     return 0;

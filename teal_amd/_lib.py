@@ -18,7 +18,7 @@ CSRC = os.path.join(_PKG, "csrc")
 # translation units: host logic + GEMV ABI, attention + sampler, and the GEMV kernel instantiations split by
 # (weight width, activation dtype) so that they compile in parallel
 SOURCES = ("teal_kernels.hip", "teal_attention.hip", "teal_gemv_w16_f16.hip", "teal_gemv_w16_bf16.hip",
-           "teal_gemv_w8_f16.hip", "teal_gemv_w8_bf16.hip", "teal_gemv_fast_f16.hip", "teal_gemv_fast_bf16.hip")
+           "teal_gemv_w8_f16.hip", "teal_gemv_w8_bf16.hip", "teal_gemv_fast_f16.hip", "teal_gemv_fast_bf16.hip", "teal_gemv_int4.hip")
 # translation units whose kernels take their hot arguments as scalar parameters: the command processor preloads the
 # first 11 dwords into SGPRs at wave launch (no scalar-cache miss before the first activation load)
 PRELOAD = {"teal_gemv_fast_f16.hip": 11, "teal_gemv_fast_bf16.hip": 11, "teal_attention.hip": 12}
@@ -30,7 +30,7 @@ LIB_PATH = os.path.join(_PKG, "libteal_hip.so")
 EXPORTS = (
     "teal_version", "teal_strerror", "teal_init", "teal_workspace_bytes", "teal_compact",
     "teal_sparse_gemv", "teal_sparse_qkv_gemv", "teal_dense_gemv", "teal_sparse_gateup_silu",
-    "teal_set_tuning", "teal_get_config", "teal_set_phase_buffer", "teal_fused_gemv", "teal_decode_attention", "teal_sample_topk", "teal_set_swizzle", "teal_set_wave_local", "teal_sparse_qkv_gemv_ld", "teal_decode_attention_masked", "teal_decode_attention_split", "teal_sparse_qkv_gemv_i8", "teal_decode_attention_split_slabs", "teal_set_phase_stride", "teal_set_fast", "teal_last_launch_desc",
+    "teal_set_tuning", "teal_get_config", "teal_set_phase_buffer", "teal_fused_gemv", "teal_decode_attention", "teal_sample_topk", "teal_set_swizzle", "teal_set_wave_local", "teal_sparse_qkv_gemv_ld", "teal_decode_attention_masked", "teal_decode_attention_split", "teal_sparse_qkv_gemv_i8", "teal_decode_attention_split_slabs", "teal_set_phase_stride", "teal_set_fast", "teal_last_launch_desc", "teal_sparse_qkv_gemv_i4",
 )
 
 _lib = None
@@ -106,6 +106,7 @@ def load() -> ctypes.CDLL:
     L.teal_sparse_qkv_gemv_ld.argtypes = [vp, vp, ci, vp, cf, cf, cf, ci, ci, ci, ci, ci, vp, sz, vp]
     L.teal_sparse_qkv_gemv_i8.argtypes = [vp, vp, vp, vp, cf, cf, cf, ci, ci, ci, ci, ci, ci, vp, sz, vp]
     L.teal_dense_gemv.argtypes = [vp, vp, vp, ci, ci, ci, vp, sz, vp]
+    L.teal_sparse_qkv_gemv_i4.argtypes = [vp, vp, vp, vp, cf, cf, cf, ci, ci, ci, ci, ci, ci, ci, vp, sz, vp]
     L.teal_sparse_gateup_silu.argtypes = [vp, vp, vp, vp, cf, cf, ci, ci, ci, vp, sz, vp]
     L.teal_set_tuning.argtypes = [ci, ci, ci, ci]
     L.teal_set_phase_buffer.argtypes = [vp]

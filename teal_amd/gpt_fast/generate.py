@@ -195,7 +195,8 @@ def apply_sparsity(model: Transformer, *, sparsity: float, hist_path: Optional[s
         ths = calibrate_thresholds(model, sparsities)
         for i, layer in enumerate(model.layers):
             monkeypatch_layer(i, layer, sparsity, None, device, thresholds=ths[i])
-        if decode_calibration and device == "cuda" and any(float(v) > 0 for vals in sparsities.values() for v in vals):
+        int4 = hasattr(model.layers[0].attention.wqkv, "scales_and_zeros")  # int4 blocks run op by op: no fused engine
+        if decode_calibration and device == "cuda" and not int4 and any(float(v) > 0 for vals in sparsities.values() for v in vals):
             ths = refine_thresholds_on_decode(model, sparsities, ths)
     else:
         ths = [monkeypatch_layer(i, layer, sparsity, hist_path, device, sparsities=sparsities)

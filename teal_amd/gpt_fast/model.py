@@ -164,6 +164,11 @@ def _sparse_attn_forward(self: Attention, x: Tensor, freqs_cis: Tensor, mask: Te
                          input_pos: Optional[Tensor] = None) -> Tensor:
     """gemv1 = teal::sparse_qkv_gemv, gemv2 = teal::sparse_gemv (prefill handled inside the ops)."""
     kv_size = self.n_local_heads * self.head_dim
+    if getattr(self, "int4", False):  # int4 group-quantised projections: the ops take scales_and_zeros next to the packed weight
+        qkv = self.gemv1(x, self.wqkv.weight, self.wqkv.scales_and_zeros, self.thresh_q, self.thresh_k, self.thresh_v,
+                         self.sparsity_bin, kv_size)
+        y = self._attend(qkv, freqs_cis, mask, input_pos)
+        return self.gemv2(y, self.wo.weight, self.wo.scales_and_zeros, self.thresh_o, self.sparsity_bin)
     if getattr(self, "int8", False):  # int8 weight-only projections: the ops take the scales next to the weight
         qkv = self.gemv1(x, self.wqkv.weight, self.wqkv.scales, self.thresh_q, self.thresh_k, self.thresh_v,
                          self.sparsity_bin, kv_size)
@@ -190,6 +195,10 @@ class FeedForward(nn.Module):
 
 
 def _sparse_ffn_forward(self: FeedForward, x: Tensor) -> Tensor:
+    if getattr(self, "int4", False):
+        gate = self.gemv1(x, self.w1.weight, self.w1.scales_and_zeros, self.thresh_gate, self.sparsity_bin)
+        up = self.gemv1(x, self.w3.weight, self.w3.scales_and_zeros, self.thresh_up, self.sparsity_bin)
+        return self.gemv2(F.silu(gate) * up, self.w2.weight, self.w2.scales_and_zeros, self.thresh_down, self.sparsity_bin)
     if getattr(self, "int8", False):
         gate = self.gemv1(x, self.w1.weight, self.w1.scales, self.thresh_gate, self.sparsity_bin)
         up = self.gemv1(x, self.w3.weight, self.w3.scales, self.thresh_up, self.sparsity_bin)
@@ -256,6 +265,8 @@ class Transformer(nn.Module):
         for layer in self.layers:
             at, ff = layer.attention, layer.feed_forward
             if not (hasattr(at, "thresh_q") and hasattr(at, "gemv1") and hasattr(ff, "thresh_gate") and hasattr(ff, "gemv2")):
+                return None
+            if getattr(at, "int4", False):  # int4 projections run op by op (the fused step covers 16-bit and int8 weights)
                 return None
             ths.append({"q": float(at.thresh_q), "k": float(at.thresh_k), "v": float(at.thresh_v), "o": float(at.thresh_o),
                         "gate": float(ff.thresh_gate), "up": float(ff.thresh_up), "down": float(ff.thresh_down)})

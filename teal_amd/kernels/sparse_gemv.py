@@ -144,6 +144,40 @@ def splitk_sparse_gemv_int8(x: torch.Tensor, weight: torch.Tensor, scales: torch
     return qkv_gemv_int8(x, weight, scales, t, t, t, sparsity_bin, 0)
 
 
+def qkv_gemv_int4(x: torch.Tensor, weight: torch.Tensor, scales_and_zeros: torch.Tensor, threshold_q: float, threshold_k: float,
+                  threshold_v: float, sparsity_bin: int, kv_size: int) -> torch.Tensor:
+    """qkv_gemv on int4 group-quantised weights: weight = packed nibble image of W^T, uint8
+    [Z][N / 2 + pad] (quantize.pack_int4_colmajor); scales_and_zeros bf16 [Z / G][N][2] (the reference's tensor,
+    gpt-fast/quantize.py:79-93).  y = sparse(x) @ dequant(W).T, fp32 accumulation, one rounding.  kv_size = 0: one threshold."""
+    if not x.is_cuda or not weight.is_cuda or not scales_and_zeros.is_cuda:
+        raise RuntimeError("teal_amd sparse GEMV runs on the GPU only (HIP kernels; there is no CPU fallback)")
+    if weight.dtype != torch.uint8 or weight.dim() != 2 or weight.stride(1) != 1:
+        raise RuntimeError("int4 weight must be the packed uint8 image [Z][bytes] (quantize.pack_int4_colmajor)")
+    if scales_and_zeros.dtype != torch.bfloat16 or scales_and_zeros.dim() != 3 or scales_and_zeros.shape[2] != 2 or not scales_and_zeros.is_contiguous():
+        raise TypeError("scales_and_zeros must be a contiguous bf16 [Z / G][N][2] tensor")
+    Z, N = weight.shape[0], scales_and_zeros.shape[1]
+    G = Z // scales_and_zeros.shape[0]
+    assert x.shape[2] == Z and scales_and_zeros.shape[0] * G == Z
+    B, S, _ = x.shape
+    if B * S != 1:
+        raise RuntimeError("qkv_gemv_int4 is the single-token path: x must be [1, 1, Z]")
+    x = x.contiguous()
+    L = _lib.load()
+    ws = runtime.workspace(x.device, int(L.teal_workspace_bytes(Z, N)))
+    y = torch.empty(B, S, N, device=x.device, dtype=x.dtype)
+    rc = L.teal_sparse_qkv_gemv_i4(x.data_ptr(), weight.data_ptr(), scales_and_zeros.data_ptr(), y.data_ptr(), float(threshold_q),
+                                   float(threshold_k), float(threshold_v), Z, N, N - 2 * kv_size, kv_size, weight.stride(0), G,
+                                   runtime.dtype_code(x.dtype), ws.data_ptr(), ws.numel() * 4, runtime.stream_ptr())
+    _lib.check(rc, "teal_sparse_qkv_gemv_i4")
+    return y
+
+
+def splitk_sparse_gemv_int4(x: torch.Tensor, weight: torch.Tensor, scales_and_zeros: torch.Tensor, threshold: float,
+                            sparsity_bin: int = 0) -> torch.Tensor:
+    t = float(threshold)
+    return qkv_gemv_int4(x, weight, scales_and_zeros, t, t, t, sparsity_bin, 0)
+
+
 def compact(x: torch.Tensor, threshold: float):
     """(ascending kept indices int32 [count], count) of float32(|x|) > float32(threshold) — the
     index set the GEMV consumes, exposed for bit-exact parity tests."""
@@ -228,3 +262,36 @@ class SparseQKVGEMVInt8(BaseKernel):
         if x.shape[1] == 1 and x.shape[0] == 1:
             return qkv_gemv_int8(x, weight, scales, threshold_q, threshold_k, threshold_v, sparsity_bin, kv_size)
         return _int8_prefill(x, weight, scales)
+
+
+def _int4_prefill(x: torch.Tensor, weight: torch.Tensor, scales_and_zeros: torch.Tensor) -> torch.Tensor:
+    # F.linear on the dequantised weight (quantize.WeightOnlyInt4Linear.forward)
+    from ..quantize import group_dequantize_tensor, unpack_int4_colmajor
+    N = scales_and_zeros.shape[1]
+    G = weight.shape[0] // scales_and_zeros.shape[0]
+    w = group_dequantize_tensor(unpack_int4_colmajor(weight, N), scales_and_zeros.float(), 4, G).to(x.dtype)
+    return torch.matmul(x, w.T)
+
+
+class SparseGEMVInt4(BaseKernel):
+    def meta(self, hidden_states: torch.Tensor, weights: torch.Tensor, scales_and_zeros: torch.Tensor, threshold: float,
+             sparsity_bin: int) -> torch.Tensor:
+        return hidden_states.new_empty((hidden_states.size(0), hidden_states.size(1), scales_and_zeros.size(1)))
+
+    def forward(self, hidden_states: torch.Tensor, weights: torch.Tensor, scales_and_zeros: torch.Tensor, threshold: float,
+                sparsity_bin: int) -> torch.Tensor:
+        if hidden_states.shape[1] == 1 and hidden_states.shape[0] == 1:
+            return splitk_sparse_gemv_int4(hidden_states, weights, scales_and_zeros, threshold, sparsity_bin)
+        return _int4_prefill(hidden_states, weights, scales_and_zeros)
+
+
+class SparseQKVGEMVInt4(BaseKernel):
+    def meta(self, x: torch.Tensor, weight: torch.Tensor, scales_and_zeros: torch.Tensor, threshold_q: float, threshold_k: float,
+             threshold_v: float, sparsity_bin: int, kv_size: int) -> torch.Tensor:
+        return x.new_empty(x.shape[0], x.shape[1], scales_and_zeros.shape[1])
+
+    def forward(self, x: torch.Tensor, weight: torch.Tensor, scales_and_zeros: torch.Tensor, threshold_q: float, threshold_k: float,
+                threshold_v: float, sparsity_bin: int, kv_size: int) -> torch.Tensor:
+        if x.shape[1] == 1 and x.shape[0] == 1:
+            return qkv_gemv_int4(x, weight, scales_and_zeros, threshold_q, threshold_k, threshold_v, sparsity_bin, kv_size)
+        return _int4_prefill(x, weight, scales_and_zeros)

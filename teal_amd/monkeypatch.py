@@ -18,7 +18,8 @@ from typing import Dict, Optional, Sequence
 import torch
 
 from .distribution import Distribution, threshold_for_sparsity
-from .kernels.sparse_gemv import SparseGEMV, SparseGEMVInt8, SparseQKVGEMV, SparseQKVGEMVInt8
+from .kernels.sparse_gemv import (SparseGEMV, SparseGEMVInt4, SparseGEMVInt8, SparseQKVGEMV, SparseQKVGEMVInt4,
+                                  SparseQKVGEMVInt8)
 from .utils import PROJS
 
 # projection -> (sub-directory, histogram key)   (gpt-fast/generate.py:278-287)
@@ -77,6 +78,11 @@ def monkeypatch_layer(layer_idx: int, layer, sparsity, hist_path: Optional[str],
         thresholds = layer_thresholds(layer_idx, hist_path, sparsities)
     ff, attn = layer.feed_forward, layer.attention
     lins = (ff.w1, ff.w3, ff.w2, attn.wqkv, attn.wo)
+    int4 = [hasattr(lin, "scales_and_zeros") for lin in lins]
+    if any(int4):
+        if not all(int4):
+            raise ValueError("either all five projections of a block are int4 group-quantised or none")
+        return _monkeypatch_layer_int4(layer, thresholds, device)
     int8 = [lin.weight.dtype == torch.int8 for lin in lins]
     if any(int8):
         if not all(int8):
@@ -136,4 +142,26 @@ def _monkeypatch_layer_int8(layer, thresholds: Dict[str, float], device: str) ->
     attn.apply_monkeypatch()
     if torch.cuda.is_available() and ff.w1.weight.is_cuda:
         torch.cuda.empty_cache()
+    return thresholds
+
+
+def _monkeypatch_layer_int4(layer, thresholds: Dict[str, float], device: str) -> Dict[str, float]:
+    """Same attribute bundle over int4 group-quantised projections (quantize.quantize_model_int4): gemv1 / gemv2 are
+    teal::sparse_qkv_gemv_int4 / teal::sparse_gemv_int4, which take `scales_and_zeros` next to the packed weight.  The
+    packed image is already column-gathered (quantize.pack_int4_colmajor): nothing to re-lay out."""
+    ff, attn = layer.feed_forward, layer.attention
+    ff.gemv1_kernel = SparseGEMVInt4.initialize("sparse_gemv_int4", device)
+    ff.gemv1 = ff.gemv1_kernel.operator(True)
+    ff.gemv2_kernel = SparseGEMVInt4.initialize("sparse_gemv_int4", device)
+    ff.gemv2 = ff.gemv2_kernel.operator(True)
+    ff.thresh_up, ff.thresh_gate, ff.thresh_down, ff.sparsity_bin = thresholds["up"], thresholds["gate"], thresholds["down"], 0
+    attn.gemv1_kernel = SparseQKVGEMVInt4.initialize("sparse_qkv_gemv_int4", device)
+    attn.gemv1 = attn.gemv1_kernel.operator(True)
+    attn.gemv2_kernel = SparseGEMVInt4.initialize("sparse_gemv_int4", device)
+    attn.gemv2 = attn.gemv2_kernel.operator(True)
+    attn.thresh_q, attn.thresh_k, attn.thresh_v, attn.thresh_o = (thresholds[k] for k in ("q", "k", "v", "o"))
+    attn.sparsity_bin = 0
+    ff.int4 = attn.int4 = True
+    ff.apply_monkeypatch()
+    attn.apply_monkeypatch()
     return thresholds

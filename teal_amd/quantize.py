@@ -8,6 +8,14 @@ GEMV: kept rows of an int8 W^T are half the bytes of fp16, and the per-column sc
     quantize_per_channel(w)         <- dynamically_quantize_per_channel(w.float(), -128, 127, torch.int8)
     WeightOnlyInt8Linear            <- quantize.py:339-357 (buffers `weight` int8 [N, Z], `scales` [N])
     quantize_model_int8(model)      <- WeightOnlyInt8QuantHandler.create_quantized_state_dict + convert_for_runtime
+
+int4 group-wise (gpt-fast/quantize.py:58-162, 359-443, 483-526), same story: the reference's WeightOnlyInt4Linear runs a
+CUDA-only packed matmul on its dense path; here the same group quantiser feeds `teal::sparse_gemv_int4`:
+
+    get_group_qparams / group_quantize_tensor / group_dequantize_tensor   <- quantize.py:58-162 (same arithmetic)
+    pack_int4_colmajor(q)           our layout: the nibble image of W^T, [Z][N / 2 + pad] bytes (the reference packs for tinygemm)
+    WeightOnlyInt4Linear            buffers `weight` (packed uint8) and `scales_and_zeros` bf16 [Z / G][N][2] (the reference's tensor)
+    quantize_model_int4(model, G)   <- WeightOnlyInt4QuantHandler (no padding branch: Llama shapes divide by every G)
 """
 from __future__ import annotations
 
@@ -79,3 +87,109 @@ def convert_for_runtime_int8(model: nn.Module, dtype=torch.bfloat16) -> nn.Modul
 
 def is_int8(lin: nn.Module) -> bool:
     return isinstance(lin, WeightOnlyInt8Linear)
+
+
+# ------------------------------------------------------------------------------------------------
+# int4 group-wise
+# ------------------------------------------------------------------------------------------------
+INT4_ROW_PAD_BYTES = 64  # row padding of the packed W^T image (same reason as monkeypatch.ROW_PAD: rotate DRAM channel residues)
+
+
+def get_group_qparams(w: torch.Tensor, n_bit: int = 4, groupsize: int = 128):
+    """per (output row, group of `groupsize` input features): scale = (max - min) / 15 clamped to >= 1e-6,
+    zero = min + scale * 8, both rounded to bf16 (quantize.py:58-76)."""
+    assert groupsize > 1 and w.dim() == 2 and w.shape[-1] % groupsize == 0
+    g = w.reshape(-1, groupsize)
+    assert torch.isnan(g).sum() == 0
+    max_val, min_val = g.amax(dim=1, keepdim=True), g.amin(dim=1, keepdim=True)
+    max_int = 2 ** n_bit - 1
+    scales = (max_val - min_val).clamp(min=1e-6) / max_int
+    zeros = min_val + scales * (2 ** (n_bit - 1))
+    return scales.to(torch.bfloat16).reshape(w.shape[0], -1), zeros.to(torch.bfloat16).reshape(w.shape[0], -1)
+
+
+def group_quantize_tensor_from_qparams(w, scales, zeros, n_bit: int = 4, groupsize: int = 128) -> torch.Tensor:
+    """q = clamp(round((w - (zero - 8 scale)) / scale), 0, 15) as int32 [N, Z] (quantize.py:101-128)."""
+    assert w.dim() == 2 and w.shape[-1] % groupsize == 0
+    g = w.reshape(-1, groupsize)
+    scales, zeros = scales.reshape(-1, 1), zeros.reshape(-1, 1)
+    min_val = zeros - scales * (2 ** (n_bit - 1))
+    return g.sub(min_val).div(scales).round().clamp_(0, 2 ** n_bit - 1).to(torch.int32).reshape_as(w)
+
+
+def group_quantize_tensor(w: torch.Tensor, n_bit: int = 4, groupsize: int = 128):
+    """(q int32 [N, Z], scales_and_zeros bf16 [Z / G][N][2]) — quantize.py:131-135 with pack_scales_and_zeros (:79-93)."""
+    scales, zeros = get_group_qparams(w, n_bit, groupsize)
+    q = group_quantize_tensor_from_qparams(w, scales, zeros, n_bit, groupsize)
+    sz = torch.cat([scales.reshape(scales.size(0), scales.size(1), 1), zeros.reshape(zeros.size(0), zeros.size(1), 1)], 2)
+    return q, sz.transpose(0, 1).contiguous()
+
+
+def group_dequantize_tensor(q: torch.Tensor, scales_and_zeros: torch.Tensor, n_bit: int = 4, groupsize: int = 128) -> torch.Tensor:
+    """w = (q - 8) * scale + zero, [N, Z] in the dtype of scales_and_zeros (quantize.py:138-162)."""
+    scales, zeros = torch.split(scales_and_zeros.transpose(0, 1), 1, 2)
+    g = q.reshape(-1, groupsize)
+    return g.sub(2 ** (n_bit - 1)).mul(scales.reshape(-1, 1)).add(zeros.reshape(-1, 1)).reshape_as(q)
+
+
+def pack_int4_colmajor(q: torch.Tensor, pad_bytes: int = INT4_ROW_PAD_BYTES) -> torch.Tensor:
+    """q int [N, Z] in 0..15 -> uint8 [Z][N / 2 + pad]: byte j of row m = columns 2j (low nibble), 2j + 1 (high nibble)."""
+    N, Z = q.shape
+    assert N % 2 == 0
+    qt = q.T.contiguous().to(torch.uint8)  # [Z, N]
+    out = torch.zeros(Z, N // 2 + pad_bytes, dtype=torch.uint8, device=q.device)
+    out[:, : N // 2] = qt[:, 0::2] | (qt[:, 1::2] << 4)
+    return out
+
+
+def unpack_int4_colmajor(packed: torch.Tensor, N: int) -> torch.Tensor:
+    """inverse of pack_int4_colmajor -> int32 [N, Z]"""
+    b = packed[:, : N // 2]
+    qt = torch.stack((b & 0xF, b >> 4), dim=-1).reshape(b.shape[0], N)
+    return qt.T.contiguous().to(torch.int32)
+
+
+class WeightOnlyInt4Linear(nn.Module):
+    """Group-quantised int4 weight-only linear for the sparse decode path.  Dense forward (prefill, any shape) =
+    F.linear(x, dequantised weight): what the reference's module computes through its packed matmul
+    (quantize.py:483-526), without the CUDA-only packed layout."""
+
+    def __init__(self, in_features: int, out_features: int, groupsize: int = 128, device=None):
+        super().__init__()
+        assert in_features % groupsize == 0 and out_features % 8 == 0
+        self.in_features, self.out_features, self.groupsize = in_features, out_features, groupsize
+        self.register_buffer("weight", torch.zeros((in_features, out_features // 2 + INT4_ROW_PAD_BYTES), dtype=torch.uint8, device=device))
+        self.register_buffer("scales_and_zeros", torch.zeros((in_features // groupsize, out_features, 2), dtype=torch.bfloat16, device=device))
+
+    def dequantized(self, dtype) -> torch.Tensor:
+        q = unpack_int4_colmajor(self.weight, self.out_features)
+        return group_dequantize_tensor(q, self.scales_and_zeros.float(), 4, self.groupsize).to(dtype)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return F.linear(x, self.dequantized(x.dtype))
+
+    @classmethod
+    def from_linear(cls, lin: nn.Linear, groupsize: int = 128) -> "WeightOnlyInt4Linear":
+        assert lin.bias is None
+        q, sz = group_quantize_tensor(lin.weight.data.to(torch.bfloat16), 4, groupsize)  # quantize.py:421: quantised from bf16
+        m = cls(lin.in_features, lin.out_features, groupsize, device=lin.weight.device)
+        m.weight.copy_(pack_int4_colmajor(q))
+        m.scales_and_zeros.copy_(sz)
+        return m
+
+
+def quantize_model_int4(model: nn.Module, groupsize: int = 32, skip=("output",)) -> nn.Module:
+    """Replace the projections' nn.Linear by WeightOnlyInt4Linear in place.  `skip`: child names kept in 16 bits (the
+    lm_head: its 32000 / 128256 columns are no multiple of the kernel's 128-column tile for every vocabulary, and the
+    reference's handler pads / skips shapes it cannot pack, quantize.py:404-415)."""
+    for name, child in list(model.named_children()):
+        if isinstance(child, nn.Linear) and name not in skip:
+            setattr(model, name, WeightOnlyInt4Linear.from_linear(child, groupsize))
+            del child
+        else:
+            quantize_model_int4(child, groupsize, skip)
+    return model
+
+
+def is_int4(lin: nn.Module) -> bool:
+    return isinstance(lin, WeightOnlyInt4Linear)
