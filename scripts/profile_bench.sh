@@ -7,7 +7,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-OUT=gpurun_out/prof_r01
+OUT=gpurun_out/prof_${ROUND:-r02}
 rm -rf "$OUT"; mkdir -p "$OUT"
 ARGS="--steps 40 --warmup 5 --no-dense --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python bench.py $ARGS > "$OUT/trace.log" 2>&1

@@ -9,10 +9,11 @@ from collections import defaultdict
 
 
 def short(n):
-    m = re.search(r"sparse_gemv_kernel<([^>]*)>", n)
-    if m:
-        return "sparse_gemv_kernel<" + m.group(1).replace(" ", "") + ">"
-    for k in ("decode_attention_kernel", "sample_topk_kernel", "splitk_reduce_kernel", "compact_kernel", "gateup_silu_epilogue_kernel"):
+    for kn in ("gemv_fast_kernel", "sparse_gemv_kernel", "decode_attention_split_kernel", "sample_topk_window_kernel"):
+        m = re.search(kn + r"<([^>]*)>", n)
+        if m:
+            return kn + "<" + m.group(1).replace(" ", "") + ">"
+    for k in ("decode_attention_kernel", "sparse_gemv_int4_kernel", "sample_topk_kernel", "splitk_reduce_kernel", "compact_kernel", "gateup_silu_epilogue_kernel"):
         if k in n:
             return k
     return n[:70]
