@@ -255,6 +255,10 @@ int teal_set_wave_local(int on);
  * string; e.g. for naming the kernel in a benchmark record). */
 const char* teal_last_launch_desc(void);
 
+/* Experiment switches of the lean kernel, for A/B timing inside one process (0 = production behaviour).
+ * bit 0: do not issue the first weight batch before the compaction has finished. */
+int teal_set_experiment(int mask);
+
 /* Lean kernel for qualifying shapes (default on; 0 forces the general kernel everywhere: A/B and parity tests). */
 int teal_set_fast(int on);
 

@@ -320,10 +320,13 @@ int main(int argc, char** argv) {
         // lean kernel vs general kernel on the same inputs: bit-identical outputs expected (same arithmetic, same order)
         auto snap = [&](const void* d, size_t bytes) { std::vector<unsigned char> h(bytes); CK(hipStreamSynchronize(st)); CK(hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost)); return h; };
         int bad = 0;
+        const int vrounds = std::max(1, atoi(getenv("LB_VERIFY")));
         auto cmp = [&](const char* what, const std::vector<unsigned char>& a, const std::vector<unsigned char>& b) {
-            size_t nd = 0; for (size_t i = 0; i < a.size(); ++i) nd += a[i] != b[i];
-            printf("  verify %-22s %s (%zu of %zu bytes differ)\n", what, nd ? "DIFF" : "same", nd, a.size()); bad += nd != 0;
+            size_t nd = 0, first = 0; for (size_t i = 0; i < a.size(); ++i) if (a[i] != b[i]) { if (!nd) first = i; ++nd; }
+            if (nd || vrounds == 1) printf("  verify %-22s %s (%zu of %zu bytes differ, first at byte %zu)\n", what, nd ? "DIFF" : "same", nd, a.size(), first);
+            bad += nd != 0;
         };
+        for (int vr = 0; vr < vrounds; ++vr)
         for (int i : {0, 1, n_layer - 1}) {
             Layer& l = Ls[i];
             // chain state: run the layers before i
@@ -382,6 +385,48 @@ int main(int argc, char** argv) {
     CK(hipGraphLaunch(gtok, st)); CK(hipStreamSynchronize(st));
     mark("timed replays");
     const double us_tok = time_graph(gtok, steps, true);
+    if (getenv("LB_STRESS")) {
+        // determinism stress: every GEMV stage of a middle layer re-run many times on the same inputs, both kernels
+        const int N = atoi(getenv("LB_STRESS"));
+        auto snap = [&](const void* d, size_t bytes) { std::vector<unsigned char> h(bytes); CK(hipStreamSynchronize(st)); CK(hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost)); return h; };
+        const int li = n_layer / 2;
+        Layer& l = Ls[li];
+        for (int e = 0; e < li; ++e) { Layer& q = Ls[e]; k_qkv(e, q.tq); k_attn(e, !fused_merge, q.to); k_wo(e, q.to); k_gu(e, q.tg, q.td); k_down(e, q.td); }
+        k_qkv(li, l.tq); k_attn(li, !fused_merge, l.to);
+        for (int fast = 1; fast >= 0; --fast) {
+            TK(teal_set_fast(fast));
+            k_wo(li, l.to);
+            auto ref = snap(s_wo, (size_t)4 * dim * 4);
+            int bad = 0; size_t worst = 0;
+            for (int it = 0; it < N; ++it) {
+                // other launches in between, like the real chain
+                k_gu(li, l.tg, l.td); k_down(li, l.td);
+                k_wo(li, l.to);
+                auto cur = snap(s_wo, (size_t)4 * dim * 4);
+                size_t nd = 0; for (size_t i = 0; i < cur.size(); ++i) nd += cur[i] != ref[i];
+                if (nd) { ++bad; worst = std::max(worst, nd); }
+            }
+            printf("stress wo fast=%d: %d of %d runs differ from the first (worst %zu bytes)\n", fast, bad, N, worst);
+        }
+        TK(teal_set_fast(1));
+        return 0;
+    }
+    if (getenv("LB_AB")) {
+        // A/B inside one process: the same token step captured with teal_set_experiment(0) and (mask), timed alternately
+        const int mask = atoi(getenv("LB_AB"));
+        TK(teal_set_experiment(mask));
+        hipGraphExec_t gexp = capture(token_step);
+        TK(teal_set_experiment(0));
+        double sa = 0, sb = 0; const int rounds = 6;
+        for (int r = 0; r < rounds; ++r) {
+            const double ta = time_graph(gtok, steps, true), tb = time_graph(gexp, steps, true);
+            printf("  A/B round %d: base %.1f us  exp(%d) %.1f us\n", r, ta, mask, tb);
+            if (r) { sa += ta; sb += tb; }
+        }
+        printf("A/B mean (rounds 1..): base %.1f us/token, exp(%d) %.1f us/token  -> %+.2f %%\n", sa / (rounds - 1), mask, sb / (rounds - 1),
+               (sb / sa - 1.0) * 100.0);
+        return 0;
+    }
     mark("stage graphs");
     // per-stage cost: the same graph without one stage kind (the remaining launches still see correct-shaped inputs)
     auto stage_graph = [&](int skip) {

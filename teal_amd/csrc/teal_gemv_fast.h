@@ -30,7 +30,7 @@ namespace teal {
     asm volatile("" ::"s"((a).w0), "s"((a).w1), "s"((a).y), "s"((a).ws), "s"((a).mask_out), "s"((a).resid_out),          \
                  "s"((a).phase), "s"((a).ticket), "s"((a).ld0), "s"((a).ld1), "s"((a).seg_tile1), "s"((a).seg_tile2), "s"((a).tau0),       \
                  "s"((a).tau1), "s"((a).tau2), "s"((a).mask_tau), "s"((a).ws_stride), "s"((a).att_hd), "s"((a).att_ns),  \
-                 "s"((a).cap))
+                 "s"((a).cap), "s"((a).exp))
 
 
 // LPR lanes x 16 B = BN columns per tile; KR = register-cached 64-element chunks per wave.
@@ -218,26 +218,9 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
     uint32_t* list = reinterpret_cast<uint32_t*>(smem + 64) + (size_t)wave * a.cap;
     float* red = reinterpret_cast<float*>(smem + 64 + (size_t)WAVES * a.cap * 4);
     int nloc = 0;
-#pragma unroll
-    for (int k = 0; k < KR; ++k) {
-        if (own[k]) {
-            unsigned long long mask;
-            if constexpr (MODE == 3) {
-                mask = mk[k];
-            } else {
-                const float v = bits_to_float(xr[k], BF16);
-                mask = __ballot(keep_rule(v, tau) || (v != v));  // NaN propagates like the reference's 0 * NaN
-            }
-            if ((mask >> lane) & 1ull) list[nloc + lane_rank(mask)] = (((uint32_t)cidx[k] * 64u + lane) << 16) | xr[k];
-            nloc += __popcll(mask);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    stamp(3);
-
-    // ---- stream the kept rows: U independent non-temporal 16-byte loads per lane, two batches in flight -------
+    // ---- stream set-up first: the loads of the first batch leave as soon as the wave's FIRST chunk is compacted, while
+    //      the remaining chunks are still being balloted (the launch is bound by HBM from the first request on, so every
+    //      100 ns the pipeline starts earlier is 100 ns off the launch) -------------------------------------------------
     const int g = lane / LPR, cl = lane % LPR;
     const uint32_t col = (uint32_t)tile * BN + cl * 8;
     const char* wp = reinterpret_cast<const char*>(a.w0) + (size_t)col * 2;
@@ -282,10 +265,39 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
         };
         u32x4 wa[U], wbb[U], w2a[PAIR ? U : 1], w2b[PAIR ? U : 1];
         float xa[U], xb[U];
+        bool early = false;
+        // ---- mask + wave-local compaction ----------------------------------------------------------------------
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            if (own[k]) {
+                unsigned long long mask;
+                if constexpr (MODE == 3) {
+                    mask = mk[k];
+                } else {
+                    const float v = bits_to_float(xr[k], BF16);
+                    mask = __ballot(keep_rule(v, tau) || (v != v));  // NaN propagates like the reference's 0 * NaN
+                }
+                if ((mask >> lane) & 1ull) list[nloc + lane_rank(mask)] = (((uint32_t)cidx[k] * 64u + lane) << 16) | xr[k];
+                nloc += __popcll(mask);
+            }
+            if (k == 0 && KR > 1 && !(a.exp & 1)) {  // exp bit 0: no early issue (A/B)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (full(0)) {
+                    issue(wa, w2a, xa, 0);
+                    early = true;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        stamp(3);
         int eb = 0;
-        bool fa = full(eb);
+        bool fa = early || full(eb);
         bool first_done = false;
-        if (fa) issue(wa, w2a, xa, eb);
+        if (fa && !early) issue(wa, w2a, xa, eb);
         while (fa) {
             int ebn = eb + STEP;
             const bool fb = full(ebn);

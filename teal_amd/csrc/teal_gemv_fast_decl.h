@@ -21,6 +21,7 @@ struct FastArgs {
     int ws_stride;                  // (split + 3) & ~3, or 0: round and store y (split == 1)
     int att_hd, att_ns;             // MODE 4
     int cap;                        // list entries one wave can own
+    int exp;                        // experiment switches (teal_set_experiment; 0 in production): A/B inside one process
 };
 
 // Launch description filled by run_gemv when the shape qualifies (teal_kernels.hip: fast_eligible)

@@ -129,6 +129,7 @@ int g_phase_seq = 0;
 int g_swizzle = 0;
 int g_wave_local = 1;
 int g_fast = 1;  // lean kernel (teal_gemv_fast.h) where the shape qualifies
+int g_exp = 0;   // experiment switches handed to the lean kernel (teal_set_experiment)
 unsigned* g_tickets = nullptr;  // kTicketSlots x kTicketTiles arrival counters (zeroed once; every launch re-arms its own)
 unsigned g_ticket_seq = 0;
 constexpr int kTicketSlots = 64, kTicketTiles = 4096;
@@ -270,6 +271,7 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
     f.a.tau0 = p.seg[0].tau; f.a.tau1 = p.seg[1].tau; f.a.tau2 = p.seg[2].tau;
     f.a.seg_tile1 = (!p.pair && p.nseg > 1) ? p.seg[1].tile0 : INT_MAX;
     f.a.seg_tile2 = (!p.pair && p.nseg > 2) ? p.seg[2].tile0 : INT_MAX;
+    f.a.exp = g_exp;
     f.a.ws_stride = (to_ws || ticketed) ? ((c.split + 3) & ~3) : 0;
     f.a.ticket = ticketed ? g_tickets + (size_t)(g_ticket_seq++ % kTicketSlots) * kTicketTiles : nullptr;
     return true;
@@ -519,6 +521,11 @@ int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll) {
 }
 
 const char* teal_last_launch_desc(void) { return g_last_desc; }
+
+int teal_set_experiment(int mask) {
+    g_exp = mask;
+    return TEAL_OK;
+}
 
 int teal_set_fast(int on) {
     g_fast = on ? 1 : 0;

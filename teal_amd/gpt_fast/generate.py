@@ -75,15 +75,17 @@ def build_synthetic_model(name: str, device: str, dtype: torch.dtype, seed: int 
     if n_layer is not None:
         cfg.n_layer = n_layer
     with torch.device("meta"):
-        model = Transformer(cfg)
+        model = Transformer(cfg).to(dtype)
     g = torch.Generator(device=device).manual_seed(seed)
+    # storage is allocated ONCE, in the target dtype, and filled in place: Llama-2-70B peaks at its 137 GB of weights plus
+    # one fp32 temporary (it used to materialise the fp32 meta model first: 279 GB reserved of the GPU's 288 GB)
     model = model.to_empty(device=device)
     with torch.no_grad():
         for pname, p in model.named_parameters():
             if pname.endswith("norm.weight"):
-                p.data = torch.ones(p.shape, device=device, dtype=dtype)
+                p.data.fill_(1.0)
             else:
-                p.data = (torch.randn(p.shape, device=device, dtype=torch.float32, generator=g) * std).to(dtype)
+                p.data.copy_(torch.randn(p.shape, device=device, dtype=torch.float32, generator=g) * std)
     return model.eval()
 
 
