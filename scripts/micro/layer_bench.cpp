@@ -42,6 +42,8 @@ __global__ void fill_uniform(uint16_t* p, size_t n, uint32_t seed, float amp, in
     }
 }
 
+__global__ void bump_epoch(unsigned* e) { e[0] = e[0] + 1u; }
+
 static float h2f(uint16_t b, bool bf) {
     if (bf) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
     const int s = b >> 15, e = (b >> 10) & 31, m = b & 1023;
@@ -119,6 +121,8 @@ int main(int argc, char** argv) {
     if (ncu <= 0) { fprintf(stderr, "no device\n"); return 1; }
     hipStream_t st; CK(hipStreamCreate(&st));
     g_st = st; g_trace = getenv("LB_TRACE") != nullptr;
+    hipStream_t st2; CK(hipStreamCreate(&st2));
+    hipStream_t ls = st;  // the stream the k_* launch helpers use
     auto alloc16 = [&](size_t n, uint32_t seed, float amp) {
         uint16_t* p; CK(hipMalloc(&p, n * 2));
         hipLaunchKernelGGL(fill_uniform, dim3(2048), dim3(256), 0, st, p, n, seed, amp, bf ? 1 : 0);
@@ -203,13 +207,13 @@ int main(int argc, char** argv) {
         teal_gemv_out_t o = mk_out(3, w, ld, c0, nc, tau, nullptr, TEAL_OUT_SLABS, s_qkv);
         o.slabs_bytes = (size_t)8 * nqkv * 4;
         apply_tune("qkv");
-        TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, &n_qkv, st));
+        TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, &n_qkv, ls));
     };
     auto k_attn = [&](int i, bool to_y, float tau_o) {
         Layer& l = Ls[i];
         apply_tune("attn");
         TK(teal_decode_attention_split_slabs(s_qkv, n_qkv, rope, pos, l.kc, l.vc, to_y ? y_attn : nullptr, y_mask, tau_o, S.n_head, S.n_kv,
-                                             hd, max_seq, att_split, att_ws, att_bytes, dt, st));
+                                             hd, max_seq, att_split, att_ws, att_bytes, dt, ls));
     };
     auto k_wo = [&](int i, float to) {
         Layer& l = Ls[i];
@@ -219,7 +223,7 @@ int main(int argc, char** argv) {
         const void* w[1] = {l.wo}; const int ld[1] = {ldo}; const int c0[1] = {0}; const int nc[1] = {dim}; const float tau[1] = {to};
         teal_gemv_out_t o = mk_out(1, w, ld, c0, nc, tau, nullptr, TEAL_OUT_SLABS, s_wo);
         apply_tune("wo");
-        TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, &n_wo, st));
+        TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, &n_wo, ls));
     };
     auto k_gu = [&](int i, float tg, float td) {
         Layer& l = Ls[i];
@@ -233,11 +237,11 @@ int main(int argc, char** argv) {
             void* y[2] = {h_mlp, nullptr};
             teal_gemv_out_t o = mk_out(2, w, ld, c0, nc, tau, y, TEAL_OUT_PAIR_SILU, nullptr);
             o.mask_out = h_mask; o.mask_tau = td;
-            TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, nullptr, st));
+            TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, nullptr, ls));
         } else {
             void* y[2] = {gu, gu + inter};
             teal_gemv_out_t o = mk_out(2, w, ld, c0, nc, tau, y, TEAL_OUT_ROUNDED, nullptr);
-            TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, nullptr, st));
+            TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, nullptr, ls));
         }
     };
     auto k_down = [&](int i, float td) {
@@ -248,7 +252,7 @@ int main(int argc, char** argv) {
         const void* w[1] = {l.w2}; const int ld[1] = {ldd}; const int c0[1] = {0}; const int nc[1] = {dim}; const float tau[1] = {td};
         teal_gemv_out_t o = mk_out(1, w, ld, c0, nc, tau, nullptr, TEAL_OUT_SLABS, s_down);
         apply_tune("down");
-        TK(teal_fused_gemv(&in, &o, inter, dt, ws, ws_bytes, &n_down, st));
+        TK(teal_fused_gemv(&in, &o, inter, dt, ws, ws_bytes, &n_down, ls));
     };
     auto k_head = [&]() {
         teal_gemv_in_t in; memset(&in, 0, sizeof in);
@@ -258,7 +262,7 @@ int main(int argc, char** argv) {
         void* y[1] = {logits};
         teal_gemv_out_t o = mk_out(1, w, ld, c0, nc, tau, y, TEAL_OUT_ROUNDED, nullptr);
         apply_tune("head");
-        TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, nullptr, st));
+        TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, nullptr, ls));
     };
 
     // ---- calibration: median |x| of every projection input, layer by layer, on the sparse path itself ----
@@ -409,6 +413,75 @@ int main(int argc, char** argv) {
             printf("stress wo fast=%d: %d of %d runs differ from the first (worst %zu bytes)\n", fast, bad, N, worst);
         }
         TK(teal_set_fast(1));
+        return 0;
+    }
+    if (getenv("LB_FLOW")) {
+        // Two hardware queues WITH real dependencies: the chain gate|up(l) -> down(l) -> gate|up(l+1) ... alternates between two
+        // streams; every hand-off goes through per-workgroup flags (teal_set_flow) instead of the kernel boundary.
+        unsigned *epoch, *flags1, *flags2, *ferr;
+        CK(hipMalloc(&epoch, 4)); CK(hipMalloc(&flags1, 4096)); CK(hipMalloc(&flags2, 4096)); CK(hipMalloc(&ferr, 4));
+        CK(hipMemset(epoch, 0, 4)); CK(hipMemset(flags1, 0, 4096)); CK(hipMemset(flags2, 0, 4096)); CK(hipMemset(ferr, 0, 4));
+        const int ntd = dim / 64;  // down's column tiles
+        auto chain = [&](bool flow, hipStream_t sa, hipStream_t sb) {
+            ls = sa;
+            hipLaunchKernelGGL(bump_epoch, dim3(1), dim3(1), 0, sa, epoch);
+            hipEvent_t ef = nullptr, ej = nullptr;
+            if (sa != sb) { CK(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+                            CK(hipEventRecord(ef, sa)); CK(hipStreamWaitEvent(sb, ef, 0)); }
+            for (int i = 0; i < n_layer; ++i) {
+                Layer& l = Ls[i];
+                ls = sa;
+                if (flow) TK(teal_set_flow(epoch, flags1, 2 * i + 1, i ? flags2 : nullptr, 2 * i, 0, 1, ntd, n_down, ferr));
+                k_gu(i, l.tg, l.td);
+                ls = sb;
+                if (flow) TK(teal_set_flow(epoch, flags2, 2 * i + 2, flags1, 2 * i + 1, 0, 1, 0, 1, ferr));
+                k_down(i, l.td);
+            }
+            ls = sa;
+            if (sa != sb) { CK(hipEventRecord(ej, sb)); CK(hipStreamWaitEvent(sa, ej, 0)); }
+        };
+        auto snap = [&](const void* d, size_t bytes) { std::vector<unsigned char> h(bytes); CK(hipStreamSynchronize(st)); CK(hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost)); return h; };
+        k_down(0, Ls[0].td);  // sets n_down; state for layer 0's gate|up
+        hipGraphExec_t gbase = capture([&]() { chain(false, st, st); });
+        hipGraphExec_t gflow1 = capture([&]() { chain(true, st, st); });
+        hipGraphExec_t gflow2 = capture([&]() { chain(true, st, st2); });
+        CK(hipGraphLaunch(gbase, st)); auto r0 = snap(s_down, (size_t)4 * dim * 4); auto h0 = snap(h_mlp, inter * 2);
+        CK(hipGraphLaunch(gflow1, st)); auto r1 = snap(s_down, (size_t)4 * dim * 4);
+        CK(hipGraphLaunch(gflow2, st)); auto r2 = snap(s_down, (size_t)4 * dim * 4); auto h2 = snap(h_mlp, inter * 2);
+        unsigned e = 0; CK(hipMemcpy(&e, ferr, 4, hipMemcpyDeviceToHost));
+        printf("flow check: one queue %s, two queues %s (h %s), timeout flag %u\n", r0 == r1 ? "same" : "DIFF", r0 == r2 ? "same" : "DIFF", h0 == h2 ? "same" : "DIFF", e);
+        for (int r = 0; r < 4; ++r) {
+            const double ta = time_graph(gbase, steps, true), tb = time_graph(gflow1, steps, true), tc = time_graph(gflow2, steps, true);
+            printf("  gate|up+down chain, per layer: in order %.2f us | flags, one queue %.2f us | flags, two queues %.2f us\n", ta / n_layer, tb / n_layer, tc / n_layer);
+        }
+        CK(hipMemcpy(&e, ferr, 4, hipMemcpyDeviceToHost));
+        auto r3 = snap(s_down, (size_t)4 * dim * 4);
+        printf("flow after timing: two queues %s, timeout flag %u\n", r0 == r3 ? "same" : "DIFF", e);
+        return 0;
+    }
+    if (getenv("LB_TWOQ")) {
+        // Upper bound of what overlapping consecutive launches on two hardware queues could buy: the token's launches
+        // alternate between two streams with NO dependencies between them (results are garbage; only the timing means
+        // something: with real dependencies enforced by device-side flags the overlap can only be smaller)
+        hipEvent_t ef, ej; CK(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+        hipGraph_t g2; hipGraphExec_t ge2;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+        CK(hipEventRecord(ef, st)); CK(hipStreamWaitEvent(st2, ef, 0));
+        int flip = 0;
+        auto nxt = [&]() { ls = (flip++ & 1) ? st2 : st; };
+        for (int i = 0; i < n_layer; ++i) {
+            Layer& l = Ls[i];
+            nxt(); k_qkv(i, l.tq); nxt(); k_attn(i, !fused_merge, l.to); nxt(); k_wo(i, l.to); nxt(); k_gu(i, l.tg, l.td); nxt(); k_down(i, l.td);
+        }
+        ls = st;
+        CK(hipEventRecord(ej, st2)); CK(hipStreamWaitEvent(st, ej, 0));
+        CK(hipStreamEndCapture(st, &g2));
+        CK(hipGraphInstantiate(&ge2, g2, nullptr, nullptr, 0));
+        hipGraphExec_t g1 = capture([&]() { for (int i = 0; i < n_layer; ++i) { Layer& l = Ls[i]; k_qkv(i, l.tq); k_attn(i, !fused_merge, l.to); k_wo(i, l.to); k_gu(i, l.tg, l.td); k_down(i, l.td); } });
+        for (int r = 0; r < 4; ++r) {
+            const double ta = time_graph(g1, steps, true), tb = time_graph(ge2, steps, true);
+            printf("  two-queue bound round %d: one stream %.1f us (%.2f/layer)   two streams, no dependencies %.1f us (%.2f/layer)\n", r, ta, ta / n_layer, tb, tb / n_layer);
+        }
         return 0;
     }
     if (getenv("LB_AB")) {
