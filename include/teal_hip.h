@@ -255,13 +255,6 @@ int teal_set_wave_local(int on);
  * string; e.g. for naming the kernel in a benchmark record). */
 const char* teal_last_launch_desc(void);
 
-/* EXPERIMENTAL (two-queue overlap of consecutive launches): describe the flag-based hand-off of the NEXT
- * lean GEMV launch — it publishes flag_out[workgroup] = *epoch * 1024 + tag_out after its (write-through) outputs, and/or
- * its waves wait for flag_in[(chunk >> fshift) * fmul + j * fstride] == *epoch * 1024 + tag_in, j < fcount, before reading
- * their (system-scope) inputs.  Cleared after one launch. */
-int teal_set_flow(const void* epoch, void* flag_out, int tag_out, const void* flag_in, int tag_in, int fshift, int fmul,
-                  int fstride, int fcount, void* err);
-
 /* Experiment switches of the lean kernel, for A/B timing inside one process (0 = production behaviour).
  * bit 0: do not issue the first weight batch before the compaction has finished. */
 int teal_set_experiment(int mask);

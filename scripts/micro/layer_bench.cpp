@@ -42,8 +42,6 @@ __global__ void fill_uniform(uint16_t* p, size_t n, uint32_t seed, float amp, in
     }
 }
 
-__global__ void bump_epoch(unsigned* e) { e[0] = e[0] + 1u; }
-
 static float h2f(uint16_t b, bool bf) {
     if (bf) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
     const int s = b >> 15, e = (b >> 10) & 31, m = b & 1023;
@@ -413,50 +411,6 @@ int main(int argc, char** argv) {
             printf("stress wo fast=%d: %d of %d runs differ from the first (worst %zu bytes)\n", fast, bad, N, worst);
         }
         TK(teal_set_fast(1));
-        return 0;
-    }
-    if (getenv("LB_FLOW")) {
-        // Two hardware queues WITH real dependencies: the chain gate|up(l) -> down(l) -> gate|up(l+1) ... alternates between two
-        // streams; every hand-off goes through per-workgroup flags (teal_set_flow) instead of the kernel boundary.
-        unsigned *epoch, *flags1, *flags2, *ferr;
-        CK(hipMalloc(&epoch, 4)); CK(hipMalloc(&flags1, 4096)); CK(hipMalloc(&flags2, 4096)); CK(hipMalloc(&ferr, 4));
-        CK(hipMemset(epoch, 0, 4)); CK(hipMemset(flags1, 0, 4096)); CK(hipMemset(flags2, 0, 4096)); CK(hipMemset(ferr, 0, 4));
-        const int ntd = dim / 64;  // down's column tiles
-        auto chain = [&](bool flow, hipStream_t sa, hipStream_t sb) {
-            ls = sa;
-            hipLaunchKernelGGL(bump_epoch, dim3(1), dim3(1), 0, sa, epoch);
-            hipEvent_t ef = nullptr, ej = nullptr;
-            if (sa != sb) { CK(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
-                            CK(hipEventRecord(ef, sa)); CK(hipStreamWaitEvent(sb, ef, 0)); }
-            for (int i = 0; i < n_layer; ++i) {
-                Layer& l = Ls[i];
-                ls = sa;
-                if (flow) TK(teal_set_flow(epoch, flags1, 2 * i + 1, i ? flags2 : nullptr, 2 * i, 0, 1, ntd, n_down, ferr));
-                k_gu(i, l.tg, l.td);
-                ls = sb;
-                if (flow) TK(teal_set_flow(epoch, flags2, 2 * i + 2, flags1, 2 * i + 1, 0, 1, 0, 1, ferr));
-                k_down(i, l.td);
-            }
-            ls = sa;
-            if (sa != sb) { CK(hipEventRecord(ej, sb)); CK(hipStreamWaitEvent(sa, ej, 0)); }
-        };
-        auto snap = [&](const void* d, size_t bytes) { std::vector<unsigned char> h(bytes); CK(hipStreamSynchronize(st)); CK(hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost)); return h; };
-        k_down(0, Ls[0].td);  // sets n_down; state for layer 0's gate|up
-        hipGraphExec_t gbase = capture([&]() { chain(false, st, st); });
-        hipGraphExec_t gflow1 = capture([&]() { chain(true, st, st); });
-        hipGraphExec_t gflow2 = capture([&]() { chain(true, st, st2); });
-        CK(hipGraphLaunch(gbase, st)); auto r0 = snap(s_down, (size_t)4 * dim * 4); auto h0 = snap(h_mlp, inter * 2);
-        CK(hipGraphLaunch(gflow1, st)); auto r1 = snap(s_down, (size_t)4 * dim * 4);
-        CK(hipGraphLaunch(gflow2, st)); auto r2 = snap(s_down, (size_t)4 * dim * 4); auto h2 = snap(h_mlp, inter * 2);
-        unsigned e = 0; CK(hipMemcpy(&e, ferr, 4, hipMemcpyDeviceToHost));
-        printf("flow check: one queue %s, two queues %s (h %s), timeout flag %u\n", r0 == r1 ? "same" : "DIFF", r0 == r2 ? "same" : "DIFF", h0 == h2 ? "same" : "DIFF", e);
-        for (int r = 0; r < 4; ++r) {
-            const double ta = time_graph(gbase, steps, true), tb = time_graph(gflow1, steps, true), tc = time_graph(gflow2, steps, true);
-            printf("  gate|up+down chain, per layer: in order %.2f us | flags, one queue %.2f us | flags, two queues %.2f us\n", ta / n_layer, tb / n_layer, tc / n_layer);
-        }
-        CK(hipMemcpy(&e, ferr, 4, hipMemcpyDeviceToHost));
-        auto r3 = snap(s_down, (size_t)4 * dim * 4);
-        printf("flow after timing: two queues %s, timeout flag %u\n", r0 == r3 ? "same" : "DIFF", e);
         return 0;
     }
     if (getenv("LB_TWOQ")) {

@@ -30,7 +30,7 @@ namespace teal {
     asm volatile("" ::"s"((a).w0), "s"((a).w1), "s"((a).y), "s"((a).ws), "s"((a).mask_out), "s"((a).resid_out),          \
                  "s"((a).phase), "s"((a).ticket), "s"((a).ld0), "s"((a).ld1), "s"((a).seg_tile1), "s"((a).seg_tile2), "s"((a).tau0),       \
                  "s"((a).tau1), "s"((a).tau2), "s"((a).mask_tau), "s"((a).ws_stride), "s"((a).att_hd), "s"((a).att_ns),  \
-                 "s"((a).cap), "s"((a).exp), "s"((a).flag_out), "s"((a).tag_out))
+                 "s"((a).cap), "s"((a).exp))
 
 
 // LPR lanes x 16 B = BN columns per tile; KR = register-cached 64-element chunks per wave.
@@ -78,32 +78,6 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
             kmod = (kmod + 1 == split) ? 0 : kmod + 1;
         }
     }
-    // ---- flag-based hand-off (a.flag_in): this launch runs on another hardware queue than its producer and may have
-    //      started before it finished.  A wave waits for exactly the producer workgroups whose output its cached chunks
-    //      read (one relaxed system-scope poll per flag, bounded), then reads the handed-over data with system-scope
-    //      loads (the producer published it write-through; an L2 line cached from an earlier layer would be stale).
-    const bool flow = a.flag_in != nullptr;
-    if (flow) {
-        const unsigned want = __hip_atomic_load(a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * 1024u + (unsigned)a.tag_in;
-        const unsigned long long t0 = wall_clock64();
-        for (;;) {
-            bool ok = true;
-#pragma unroll
-            for (int k = 0; k < KR; ++k) {
-                if ((EXACT || cidx[k] < nch) && lane < a.fcount) {
-                    const unsigned v = __hip_atomic_load(a.flag_in + ((cidx[k] >> a.fshift) * a.fmul + lane * a.fstride), __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_SYSTEM);
-                    ok = ok && (v == want);
-                }
-            }
-            if (__all(ok)) break;
-            __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > 2000000ull) {  // 20 ms: give up loudly instead of hanging the GPU
-                if (lane == 0 && a.flow_err) __hip_atomic_store(a.flow_err, 1u + (unsigned)a.tag_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
-            }
-        }
-    }
     if constexpr (MODE == 1) {
         const uint16_t* resid = x16;
         if (row_index) resid += (size_t)row_index[0] * (size_t)Z;  // embedding row of the current token
@@ -120,22 +94,13 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
             rb[k] = resid[mel[k]];
             wb[k] = nw[mel[k]];
         }
-        if (flow && nslabs > 0) {  // hand-off: 16-byte loads that bypass L1 and L2 (buffer_load ... sc0 sc1)
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(slabs), 0, 0x7FFFFFFF, 0x00020000);
+        if (nslabs > 0) {
 #pragma unroll
-            for (int k = 0; k < KR; ++k) {
-                v0[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, mel[k] * stride * 4u, 0, 17));
-                if (nslabs > 4) v1[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, mel[k] * stride * 4u + 16u, 0, 17));
-            }
-        } else {
-            if (nslabs > 0) {
+            for (int k = 0; k < KR; ++k) v0[k] = *reinterpret_cast<const f32x4*>(slabs + mel[k] * stride);
+        }
+        if (nslabs > 4) {
 #pragma unroll
-                for (int k = 0; k < KR; ++k) v0[k] = *reinterpret_cast<const f32x4*>(slabs + mel[k] * stride);
-            }
-            if (nslabs > 4) {
-#pragma unroll
-                for (int k = 0; k < KR; ++k) v1[k] = *reinterpret_cast<const f32x4*>(slabs + mel[k] * stride + 4);
-            }
+            for (int k = 0; k < KR; ++k) v1[k] = *reinterpret_cast<const f32x4*>(slabs + mel[k] * stride + 4);
         }
         TEAL_FAST_ARGS_BATCH(a);
         stamp(1);
@@ -236,14 +201,8 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
             const int c = min(cidx[k], nch - 1);
-            if (flow) {
-                xr[k] = __hip_atomic_load(x16 + (uint32_t)c * 64u + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if constexpr (MODE == 3)
-                    mk[k] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(in1) + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            } else {
-                xr[k] = x16[(uint32_t)c * 64u + lane];
-                if constexpr (MODE == 3) mk[k] = reinterpret_cast<const unsigned long long*>(in1)[c];
-            }
+            xr[k] = x16[(uint32_t)c * 64u + lane];
+            if constexpr (MODE == 3) mk[k] = reinterpret_cast<const unsigned long long*>(in1)[c];
         }
         TEAL_FAST_ARGS_BATCH(a);
         stamp(1);
@@ -412,32 +371,17 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
             const float u16 = bits_to_float(float_to_bits<BF16>(us), BF16);
             const float sl = bits_to_float(float_to_bits<BF16>(g16 / (1.0f + expf(-g16))), BF16);
             const uint32_t hb = float_to_bits<BF16>(sl * u16);
+            reinterpret_cast<uint16_t*>(a.y)[c] = (uint16_t)hb;
             const float hv = bits_to_float(hb, BF16);
             const unsigned long long mko = __ballot(keep_rule(hv, a.mask_tau) || (hv != hv));
-            if (a.flag_out) {  // published write-through for a consumer on the other queue
-                __hip_atomic_store(reinterpret_cast<uint16_t*>(a.y) + c, (uint16_t)hb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (a.mask_out && lane == 0) __hip_atomic_store(a.mask_out + (c >> 6), mko, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            } else {
-                reinterpret_cast<uint16_t*>(a.y)[c] = (uint16_t)hb;
-                if (a.mask_out && lane == 0) a.mask_out[c >> 6] = mko;
-            }
+            if (a.mask_out && lane == 0) a.mask_out[c >> 6] = mko;
         } else if (a.ws_stride == 0) {
             reinterpret_cast<uint16_t*>(a.y)[c] = float_to_bits<BF16>(gs);
         } else if (!a.ticket) {
-            if (a.flag_out) __hip_atomic_store(&a.ws[c * (uint32_t)a.ws_stride + slice], gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            else a.ws[c * (uint32_t)a.ws_stride + slice] = gs;
+            a.ws[c * (uint32_t)a.ws_stride + slice] = gs;
         } else {
             // publish the partial write-through (agent-scope relaxed atomic store = global_store ... sc1)
             __hip_atomic_store(&a.ws[c * (uint32_t)a.ws_stride + slice], gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    if (a.flag_out) {
-        // every storing wave drains its write-through stores, then ONE lane raises this workgroup's flag
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (BN > 64) __syncthreads();
-        if (tid == 0) {
-            const unsigned tag = __hip_atomic_load(a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * 1024u + (unsigned)a.tag_out;
-            __hip_atomic_store(a.flag_out + bid, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     if constexpr (!PAIR) {

@@ -22,12 +22,6 @@ struct FastArgs {
     int att_hd, att_ns;             // MODE 4
     int cap;                        // list entries one wave can own
     int exp;                        // experiment switches (teal_set_experiment; 0 in production): A/B inside one process
-    // ---- flag-based hand-off (two-queue overlap of consecutive launches; teal_set_flow) -------------------------
-    const unsigned* epoch;          // device word bumped once per token; tags = *epoch * 1024 + stage id
-    unsigned* flag_out;             // this launch publishes flag_out[workgroup] = tag once its outputs are visible (or null)
-    const unsigned* flag_in;        // producer's flags this launch waits on (or null): chunk c needs
-    unsigned* flow_err;             //   flag_in[(c >> fshift) * fmul + j * fstride], j < fcount, == *epoch * 1024 + tag_in
-    int tag_out, tag_in, fshift, fmul, fstride, fcount;
 };
 
 // Launch description filled by run_gemv when the shape qualifies (teal_kernels.hip: fast_eligible)

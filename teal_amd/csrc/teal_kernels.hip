@@ -130,7 +130,6 @@ int g_swizzle = 0;
 int g_wave_local = 1;
 int g_fast = 1;  // lean kernel (teal_gemv_fast.h) where the shape qualifies
 int g_exp = 0;   // experiment switches handed to the lean kernel (teal_set_experiment)
-FastArgs g_flow = {};  // hand-off description for the NEXT lean launch (teal_set_flow), cleared after use
 unsigned* g_tickets = nullptr;  // kTicketSlots x kTicketTiles arrival counters (zeroed once; every launch re-arms its own)
 unsigned g_ticket_seq = 0;
 constexpr int kTicketSlots = 64, kTicketTiles = 4096;
@@ -273,10 +272,6 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
     f.a.seg_tile1 = (!p.pair && p.nseg > 1) ? p.seg[1].tile0 : INT_MAX;
     f.a.seg_tile2 = (!p.pair && p.nseg > 2) ? p.seg[2].tile0 : INT_MAX;
     f.a.exp = g_exp;
-    f.a.epoch = g_flow.epoch; f.a.flag_out = g_flow.flag_out; f.a.flag_in = g_flow.flag_in; f.a.flow_err = g_flow.flow_err;
-    f.a.tag_out = g_flow.tag_out; f.a.tag_in = g_flow.tag_in; f.a.fshift = g_flow.fshift; f.a.fmul = g_flow.fmul;
-    f.a.fstride = g_flow.fstride; f.a.fcount = g_flow.fcount;
-    g_flow = FastArgs{};
     f.a.ws_stride = (to_ws || ticketed) ? ((c.split + 3) & ~3) : 0;
     f.a.ticket = ticketed ? g_tickets + (size_t)(g_ticket_seq++ % kTicketSlots) * kTicketTiles : nullptr;
     return true;
@@ -526,18 +521,6 @@ int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll) {
 }
 
 const char* teal_last_launch_desc(void) { return g_last_desc; }
-
-int teal_set_flow(const void* epoch, void* flag_out, int tag_out, const void* flag_in, int tag_in, int fshift, int fmul,
-                  int fstride, int fcount, void* err) {
-    g_flow = FastArgs{};
-    g_flow.epoch = reinterpret_cast<const unsigned*>(epoch);
-    g_flow.flag_out = reinterpret_cast<unsigned*>(flag_out);
-    g_flow.flag_in = reinterpret_cast<const unsigned*>(flag_in);
-    g_flow.flow_err = reinterpret_cast<unsigned*>(err);
-    g_flow.tag_out = tag_out; g_flow.tag_in = tag_in; g_flow.fshift = fshift; g_flow.fmul = fmul; g_flow.fstride = fstride;
-    g_flow.fcount = fcount;
-    return TEAL_OK;
-}
 
 int teal_set_experiment(int mask) {
     g_exp = mask;
