@@ -7,6 +7,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from teal_amd import _lib, runtime
+from _phase import legacy_view
 
 def graph_time(fn, n, reps=9):
     s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
@@ -42,12 +43,12 @@ def main():
             import ctypes
             cfg = (ctypes.c_int * 5)(); L.teal_get_config(Z, N, 1, cfg)
             wgs = cfg[4]
-            phase = torch.zeros(wgs * 24, dtype=torch.int64, device="cuda")
+            phase = torch.zeros(wgs * 32, dtype=torch.int64, device="cuda")
             sp, smin, smax = [], [], []
             for it in range(6):
                 phase.zero_(); torch.cuda.synchronize(); L.teal_set_phase_buffer(phase.data_ptr())
                 launch(it); torch.cuda.synchronize(); L.teal_set_phase_buffer(None)
-                p = phase[: wgs * 8].view(wgs, 8).cpu().numpy()
+                p = legacy_view(phase, wgs).cpu().numpy()
                 st = (p[:, 4] - p[:, 3]) * 0.01
                 sp.append((p[:, 5].max() - p[:, 0].min()) * 0.01); smin.append(st.min()); smax.append(st.max())
             print(f"[{tag}] ld=N+{pad:3d}: graph {t:6.2f} us/launch  span {np.median(sp):6.2f}  stream min {np.median(smin):5.2f} max {np.median(smax):5.2f}")

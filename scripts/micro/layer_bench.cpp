@@ -413,6 +413,27 @@ int main(int argc, char** argv) {
         TK(teal_set_fast(1));
         return 0;
     }
+    if (getenv("LB_MULTI")) {
+        // tokens per hipGraph replay: is there a bubble between replays?
+        for (int m : {1, 2, 4, 8}) {
+            hipGraphExec_t gm = capture([&]() { for (int t = 0; t < m; ++t) token_step(); });
+            const double us = time_graph(gm, std::max(8, steps / m), true);
+            printf("  %d token(s) per graph replay: %.1f us per token\n", m, us / m);
+        }
+        return 0;
+    }
+    if (getenv("LB_HEAD")) {
+        auto layers = [&]() { for (int i = 0; i < n_layer; ++i) { Layer& l = Ls[i]; k_qkv(i, l.tq); k_attn(i, !fused_merge, l.to); k_wo(i, l.to); k_gu(i, l.tg, l.td); k_down(i, l.td); } };
+        hipGraphExec_t ga = capture([&]() { layers(); });
+        hipGraphExec_t gb = capture([&]() { layers(); k_head(); });
+        hipGraphExec_t gc = capture([&]() { layers(); k_head(); TK(teal_sample_topk(logits, S.vocab, dt, 200, 0.8f, rng, tok, pos, hist, 65536, st)); });
+        hipGraphExec_t gd = capture([&]() { layers(); TK(teal_sample_topk(logits, S.vocab, dt, 200, 0.8f, rng, tok, pos, hist, 65536, st)); });
+        for (int r = 0; r < 3; ++r) {
+            const double a = time_graph(ga, steps, true), b = time_graph(gb, steps, true), c = time_graph(gc, steps, true), d = time_graph(gd, steps, true);
+            printf("  layers %.1f | + lm_head %.1f (+%.1f) | + lm_head + sampler %.1f (+%.1f) | layers + sampler only %.1f (+%.1f)\n", a, b, b - a, c, c - b, d, d - a);
+        }
+        return 0;
+    }
     if (getenv("LB_TWOQ")) {
         // Upper bound of what overlapping consecutive launches on two hardware queues could buy: the token's launches
         // alternate between two streams with NO dependencies between them (results are garbage; only the timing means

@@ -9,7 +9,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from teal_amd import _lib, runtime  # noqa: E402
+from teal_amd import _lib, runtime
+from _phase import legacy_view  # noqa: E402
 
 NAMES = ["start->ballots", "ballots->scatter", "scatter->barrier", "rows streamed", "reduce+store"]
 
@@ -39,7 +40,7 @@ def main():
         cfg = (ctypes.c_int * 5)()
         L.teal_get_config(Z, N * nmat, 1, cfg)
         wgs = cfg[4]
-        phase = torch.zeros(wgs * 24, dtype=torch.int64, device="cuda")
+        phase = torch.zeros(wgs * 32, dtype=torch.int64, device="cuda")
         spans, rows = [], []
         for it in range(12):
             phase.zero_()
@@ -59,7 +60,7 @@ def main():
             L.teal_set_phase_buffer(None)
             if it < 2:
                 continue
-            p = phase[: wgs * 8].view(wgs, 8).cpu().double() * 10.0  # ns
+            p = legacy_view(phase, wgs).cpu().double() * 10.0  # ns
             t0 = p[:, 0].min()
             spans.append(float(p[:, 5].max() - t0) / 1e3)
             rows.append([float((p[:, 0] - t0).max()) / 1e3] + [float((p[:, i + 1] - p[:, i]).mean()) / 1e3 for i in range(5)] +
@@ -67,7 +68,7 @@ def main():
                          float((p[:, 2] - p[:, 6]).mean()) / 1e3])
         import numpy as np
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        np.save(os.path.join(ROOT, "gpurun_out", f"phase_{tag}.npy"), (phase[: wgs * 8].view(wgs, 8).cpu().numpy() - int(phase[: wgs * 8].view(wgs, 8)[:, 0].min())))
+        np.save(os.path.join(ROOT, "gpurun_out", f"phase_{tag}.npy"), (legacy_view(phase, wgs).cpu().numpy() - int(legacy_view(phase, wgs)[:, 0].min())))
         r = torch.tensor(rows).median(dim=0).values.tolist()
         print(f"[{tag}] cfg={list(cfg)} span(first start -> last end) median {sorted(spans)[len(spans) // 2]:.2f} us")
         print(f"    dispatch skew (last WG start) {r[0]:.2f} us; earliest WG end {r[6]:.2f} us")

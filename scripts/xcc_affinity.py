@@ -6,6 +6,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from teal_amd import _lib, runtime
+from _phase import legacy_view
 
 def main():
     L = _lib.load(); runtime.init()
@@ -20,7 +21,7 @@ def main():
         split = max(1, 256 // tiles)
         L.teal_set_tuning(lpr, 16, split, 4)
         wgs = tiles * split
-        phase = torch.zeros(wgs * 24, dtype=torch.int64, device="cuda")
+        phase = torch.zeros(wgs * 32, dtype=torch.int64, device="cuda")
         M = np.zeros((8, 8)); spans = []
         for rot in range(8):
             L.teal_set_swizzle(8 + rot)
@@ -32,7 +33,7 @@ def main():
                 assert rc == 0
                 torch.cuda.synchronize(); L.teal_set_phase_buffer(None)
                 if it < 2: continue
-                p = phase[: wgs * 8].view(wgs, 8).cpu().numpy()
+                p = legacy_view(phase, wgs).cpu().numpy()
                 xcc = (p[:, 7] & 0xffffffff).astype(int)
                 st = (p[:, 4] - p[:, 3]) * 0.01
                 for k in range(8): acc[k] += st[xcc == k].mean()
