@@ -242,9 +242,9 @@ int teal_sample_topk(const void* logits, int vocab, int dtype, int top_k, float 
 
 /* ---- tuning / introspection ------------------------------------------------------------------ */
 
-/* Override the launch geometry picked from (Z, N, CU count): lanes per row segment (8/16/32/64),
- * waves per workgroup (8/16), split-K factor (>= 1) and unroll depth (4/8).  0 = automatic.
- * Process-global; meant for benchmark sweeps only. */
+/* Override the launch geometry picked from (Z, N, CU count): lanes per row segment (8/16/32/64) and split-K factor
+ * (>= 1); waves per workgroup and unroll depth are fixed at 16 and 4 (the other values of round 1 were sweep-only
+ * and are no longer built: pass 0 or the fixed value).  0 = automatic.  Process-global; meant for benchmark sweeps only. */
 int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll);
 
 /* Wave-local compaction (default on): each wave streams the rows it ballots itself instead of an even share

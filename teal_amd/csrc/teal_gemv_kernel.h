@@ -677,14 +677,13 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
 // ---- launch dispatch: runtime (lanes per row, waves, unroll, producer mode, register-cache depth) -> template
 //      instantiation, for one (activation dtype, weight width) quadrant -------------------------------------
 
-// which instantiations exist.  Production geometry: 16-wave workgroups, unroll 4, every tile width / producer / cache
-// depth.  8-wave workgroups and unroll 8 exist for the plain GEMV only (geometry sweeps: measured no better, with 4-wave
-// workgroups worse — the launch is bound by HBM and by instruction issue in the prologue, not by dispatch).
+// which instantiations exist: 16-wave workgroups, unroll 4 (the production geometry), every tile width / producer /
+// cache depth.  The 8-wave and unroll-8 variants of round 1 were sweep-only (measured no better; 4-wave workgroups
+// worse: the launch is bound by HBM and by instruction issue in the prologue, not by dispatch) and are no longer built.
 template <bool W8, int LPR, int WAVES, int U, int MODE, int KRT, bool PAIR>
 constexpr bool variant_built() {
-    if (W8) return WAVES == 16 && U == 4 && LPR <= 32;
-    if (WAVES == 16) return U == 4 || (MODE == 0 && !PAIR);
-    return MODE == 0 && !PAIR && KRT == 16;
+    if (WAVES != 16 || U != 4) return false;
+    return W8 ? LPR <= 32 : true;
 }
 
 template <bool BF16, bool W8, int LPR, int WAVES, int U, int MODE, int KRT, bool PAIR>
@@ -725,7 +724,6 @@ template <bool BF16, bool W8, int LPR, int WAVES>
 hipError_t launch_gemv_u(const Params& p, size_t lds, int unroll, hipStream_t st) {
     switch (unroll) {
         case 4: return launch_gemv_t<BF16, W8, LPR, WAVES, 4>(p, lds, st);
-        case 8: return launch_gemv_t<BF16, W8, LPR, WAVES, 8>(p, lds, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -733,7 +731,6 @@ hipError_t launch_gemv_u(const Params& p, size_t lds, int unroll, hipStream_t st
 template <bool BF16, bool W8, int LPR>
 hipError_t launch_gemv_w(const Params& p, size_t lds, const Config& c, hipStream_t st) {
     switch (c.waves) {
-        case 8: return launch_gemv_u<BF16, W8, LPR, 8>(p, lds, c.unroll, st);
         case 16: return launch_gemv_u<BF16, W8, LPR, 16>(p, lds, c.unroll, st);
         default: return hipErrorInvalidValue;
     }

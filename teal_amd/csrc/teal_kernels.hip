@@ -513,8 +513,8 @@ int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll) {
         for (int o : ok) if (v == o) return true;
         return false;
     };
-    if (!in(lanes_per_row, {0, 8, 16, 32, 64}) || !in(waves, {0, 8, 16}) ||
-        !in(unroll, {0, 4, 8}) || split < 0 || split > kMaxSplit)
+    if (!in(lanes_per_row, {0, 8, 16, 32, 64}) || !in(waves, {0, 16}) ||
+        !in(unroll, {0, 4}) || split < 0 || split > kMaxSplit)
         return TEAL_ERR_CONFIG;
     g_override = {lanes_per_row, waves, split, unroll};
     return TEAL_OK;

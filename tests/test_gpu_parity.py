@@ -166,8 +166,9 @@ def test_ragged_shapes_vs_oracle(oracle, Z, N, dtype):
 
 @pytest.mark.parametrize("wave_local", [1, 0])
 def test_every_launch_geometry_agrees(oracle, wave_local):
-    """all (lanes_per_row, waves, split, unroll) variants compute the same GEMV (within rounding), with
-    the wave-local compaction and with the workgroup-wide even-share list."""
+    """all (lanes_per_row, split) geometries compute the same GEMV (within rounding), with the wave-local compaction
+    and with the workgroup-wide even-share list, through the lean and the general kernel (incl. the single-launch
+    split-K with arrival tickets)."""
     from teal_amd import _lib
     L = _lib.load()
     L.teal_set_wave_local(wave_local)
@@ -178,16 +179,18 @@ def test_every_launch_geometry_agrees(oracle, wave_local):
     W = colmajor_weight(wb, Z, N, dtype, DEV)
     truth = oracle.truth64(xb, wb, Z, N, 1.0, 0.5, 1.5, N - 2 * 256, 256, dtype)  # qkv_gemv: N_q = N - 2*kv_size
     try:
-        for lpr in (8, 16, 32, 64):
-            for waves in (8, 16):
-                for split in (1, 2, 5, 32):
-                    for unroll in (4, 8):
-                        assert L.teal_set_tuning(lpr, waves, split, unroll) == 0
-                        y = K().qkv_gemv(x, W, 1.0, 0.5, 1.5, 0, 256)
-                        check_gemv(oracle, bits_from_torch(y.view(-1)), truth, dtype, None, f"cfg {lpr},{waves},{split},{unroll}")
+        assert L.teal_set_tuning(8, 8, 1, 4) != 0 and L.teal_set_tuning(8, 16, 1, 8) != 0  # sweep-only variants are gone
+        for fast in (1, 0):  # lean kernel where the shape qualifies (8 / 16 lanes, <= 8 slices), general kernel otherwise
+            L.teal_set_fast(fast)
+            for lpr in (8, 16, 32, 64):
+                for split in (1, 2, 3, 5, 8, 32):
+                    assert L.teal_set_tuning(lpr, 16, split, 4) == 0
+                    y = K().qkv_gemv(x, W, 1.0, 0.5, 1.5, 0, 256)
+                    check_gemv(oracle, bits_from_torch(y.view(-1)), truth, dtype, None, f"cfg {lpr},{split} fast={fast}")
     finally:
         L.teal_set_tuning(0, 0, 0, 0)
         L.teal_set_wave_local(1)
+        L.teal_set_fast(1)
 
 
 @pytest.mark.parametrize("Z,N,dtype,s", [(8192, 8192, 0, 0.5), (8192, 28672, 0, 0.5), (28672, 8192, 0, 0.5),
@@ -331,7 +334,7 @@ def test_c_abi_error_codes():
     assert L.teal_sparse_gemv(x.data_ptr(), w.data_ptr(), y.data_ptr(), 0.1, 64, 64, 7, ws.data_ptr(), ws.numel() * 4, st) == -2
     assert L.teal_sparse_gemv(x.data_ptr(), w.data_ptr(), y.data_ptr(), 0.1, 64, 60, 0, ws.data_ptr(), ws.numel() * 4, st) == -3
     assert L.teal_sparse_gemv(x.data_ptr(), w.data_ptr() + 2, y.data_ptr(), 0.1, 64, 64, 0, ws.data_ptr(), ws.numel() * 4, st) == -4
-    L.teal_set_tuning(8, 8, 4, 4)
+    assert L.teal_set_tuning(8, 16, 4, 4) == 0
     try:
         assert L.teal_sparse_gemv(x.data_ptr(), w.data_ptr(), y.data_ptr(), 0.1, 64, 64, 0, ws.data_ptr(), 16, st) == -5
     finally:
