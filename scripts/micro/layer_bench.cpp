@@ -536,7 +536,11 @@ int main(int argc, char** argv) {
                 for (int b = 0; b < nwg; ++b) {
                     const unsigned long long* r = &base[(size_t)b * 32];
                     skew = std::max(skew, (double)r[0] - t0); tend = std::max(tend, (double)r[7]); first_end = std::min(first_end, (double)r[7] - t0);
-                    for (int k = 0; k < 7; ++k) d[k] += (double)r[k + 1] - (double)r[k];
+                    unsigned long long rr[8];
+                    for (int k = 0; k < 8; ++k) rr[k] = r[k];
+                    if (!rr[4]) rr[4] = rr[3];  // waves that go straight to the tail path never stamp "first batch consumed"
+                    if (!rr[6]) rr[6] = rr[5];  // the attention kernel has no stamp 6
+                    for (int k = 0; k < 7; ++k) d[k] += (double)rr[k + 1] - (double)rr[k];
                     double wmax = 0;
                     for (int w = 0; w < waves && w < 16; ++w) { we[w] += (double)r[16 + w] - (double)r[3]; wmax = std::max(wmax, (double)r[16 + w]); }
                     tail_a += (double)r[6] - wmax; tail_b += (double)r[7] - (double)r[6];
@@ -559,6 +563,12 @@ int main(int argc, char** argv) {
             const size_t nc = rows[g][0].size();
             std::vector<double> m(nc);
             for (size_t c = 0; c < nc; ++c) { std::vector<double> v; for (auto& r : rows[g]) v.push_back(r[c]); std::sort(v.begin(), v.end()); m[c] = v[v.size() / 2]; }
+            if (g == 1) {  // split attention kernel: its own phases
+                printf("[%-7s] wgs %d x %d waves | span %.2f | gap from previous launch end %.2f; entry skew %.2f; loads issued + pos %.2f; rope + barrier %.2f; "
+                       "scores + max %.2f; softmax %.2f; PV + reduce %.2f; store %.2f; earliest WG end %.2f\n", sn[g], nwgs[g], nwaves[g], m[0], m[1], m[2],
+                       m[3], m[4], m[5], m[6], m[7], m[9], m[10]);
+                continue;
+            }
             printf("[%-7s] wgs %d x %d waves | span %.2f | gap from previous GEMV end %.2f; entry skew %.2f; kernarg %.2f; x ready %.2f; list %.2f; "
                    "first batch %.2f; stream(w0) %.2f; wait+reduce %.2f; store %.2f; earliest WG end %.2f\n", sn[g], nwgs[g], nwaves[g], m[0], m[1], m[2],
                    m[3], m[4], m[5], m[6], m[7], m[8], m[9], m[10]);
