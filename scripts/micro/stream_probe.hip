@@ -62,6 +62,55 @@ __global__ __launch_bounds__(1024) void probe(const char* __restrict__ w0, const
     if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
 }
 
+// LDS-DMA variant of the row-major gather (global_load_lds_dwordx4: the data goes memory -> LDS without passing through
+// VGPRs): per wave two half-rings of 4 one-KiB slots (a slot = 8 rows x 128 B of one matrix); lanes then read their own
+// 16 bytes back with ds_read_b128.  Does this path lift the ~38 GB/s a CU sustains with register loads?
+template <int NMAT>
+__global__ __launch_bounds__(1024) void probe_ldsdma(const char* __restrict__ w0, const char* __restrict__ w1, const int* __restrict__ lists,
+                                                     const int* __restrict__ counts, int cap, size_t ldb, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) char ring[];  // 16 waves x 8 KiB
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 3, cl = lane & 7;
+    const int tile = blockIdx.x;
+    const int n = counts[wave];
+    const int* lp = lists + wave * cap;
+    char* base = ring + wave * 8192;
+    u32x4 acc = {0, 0, 0, 0};
+    constexpr int RPB = 16 / NMAT;  // rows-groups... a half-ring holds 4 slots: 4 / NMAT row groups of 8 rows
+    constexpr int GRP = 4 / NMAT;
+    auto issue = [&](int e, int half) {
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+            const int row = lp[e + u * 8 + g];
+            const char* p0 = w0 + (size_t)row * ldb + (size_t)tile * 128 + cl * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p0,
+                                             (__attribute__((address_space(3))) void*)(base + half * 4096 + (u * NMAT) * 1024), 16, 0, 2);
+            if (NMAT == 2) {
+                const char* p1 = w1 + (size_t)row * ldb + (size_t)tile * 128 + cl * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p1,
+                                                 (__attribute__((address_space(3))) void*)(base + half * 4096 + (u * NMAT + 1) * 1024), 16, 0, 2);
+            }
+        }
+    };
+    auto consume = [&](int half) {
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) acc ^= *reinterpret_cast<const u32x4*>(base + half * 4096 + sl * 1024 + lane * 16);
+    };
+    constexpr int STEP = GRP * 8;
+    int e = 0;
+    if (e + STEP <= n) issue(e, 0);
+    int half = 0;
+    for (; e + STEP <= n; e += STEP) {
+        const bool more = e + 2 * STEP <= n;
+        if (more) issue(e + STEP, half ^ 1);
+        if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        consume(half);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slots are free again before the next DMA lands in them
+        half ^= 1;
+    }
+    (void)RPB;
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[0] = 1;
+}
+
 __global__ __launch_bounds__(1024) void contig(const char* __restrict__ w, size_t bytes_per_wg, unsigned* sink) {
     const char* p = w + (size_t)blockIdx.x * bytes_per_wg + threadIdx.x * 16;
     u32x4 acc = {0, 0, 0, 0};
@@ -120,6 +169,11 @@ int main() {
     timeit("B tile-major  pair   nt (256 wgs)", [&](int i) { hipLaunchKernelGGL((probe<1, 2, true>), dim3(256), dim3(1024), 0, 0, bufs[2 * i], bufs[2 * i + 1], dl, dc, 256, 0, (size_t)Z * 128, sink); }, b2 * 256 / tiles);
     // row-major with a short row stride (the down projection's shape: ld = 4160): 172 / 256 workgroups... needs 256 * 128 B
     // = 32 KB of columns per row; use ld = 16448 elements (256 tiles + pad) within the same buffers (Z * 16448 * 2 = 134 MB > mat?)
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_ldsdma<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_ldsdma<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    timeit("A row-major   pair  LDS-DMA nt (172 wgs)", [&](int i) { hipLaunchKernelGGL((probe_ldsdma<2>), dim3(tiles), dim3(1024), 131072, 0, bufs[2 * i], bufs[2 * i + 1], dl, dc, 256, (size_t)ld * 2, sink); }, b2);
+    timeit("A row-major   single LDS-DMA nt (172 wgs)", [&](int i) { hipLaunchKernelGGL((probe_ldsdma<1>), dim3(tiles), dim3(1024), 131072, 0, bufs[2 * i], bufs[2 * i + 1], dl, dc, 256, (size_t)ld * 2, sink); }, b1);
+    timeit("A row-major   pair  nt (again)", [&](int i) { hipLaunchKernelGGL((probe<0, 2, true>), dim3(tiles), dim3(1024), 0, 0, bufs[2 * i], bufs[2 * i + 1], dl, dc, 256, (size_t)ld * 2, 0, sink); }, b2);
     for (int idle : {200, 300}) {
         char nm[96];
         snprintf(nm, sizeof nm, "A pair nt, idle %d0 ns, no prefetch", idle);

@@ -215,3 +215,37 @@ def test_engine_launches_vs_oracle_under_sparsity(oracle, name, tdt, sparsity, f
         L.teal_set_fast(1)
         del model
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("fast", [1, 0])
+def test_engine_step_bit_reproducible_at_real_width(fast):
+    """the same decode step, replayed 60 times from the same state at Llama-2-7B widths under 50 % sparsity, writes the
+    same bits into every hand-over buffer and the logits (no atomics on data; the split-K tickets only decide WHO sums)."""
+    from teal_amd import _lib
+    from teal_amd.gpt_fast import generate as G
+    from teal_amd.gpt_fast.engine import DecodeEngine
+    L = _lib.load()
+    model = G.build_synthetic_model("7B", DEV, torch.float16, seed=13, n_layer=2)
+    ths = G.apply_sparsity(model, sparsity=0.5, hist_path=None, greedy_lookup=None, synthetic=True, decode_calibration=False)
+    prompt = torch.randint(0, model.config.vocab_size, (6,), device=DEV, dtype=torch.int, generator=torch.Generator(device=DEV).manual_seed(4))
+    try:
+        L.teal_set_fast(fast)
+        with torch.no_grad():
+            model.max_seq_length = -1
+            model.setup_caches(1, 32)
+            model(prompt.view(1, -1), torch.arange(6, device=DEV))
+            eng = DecodeEngine(model, ths)
+            tok = torch.tensor([[23]], device=DEV, dtype=torch.int)
+            pos = torch.tensor([6], device=DEV, dtype=torch.int)
+            bufs = lambda: [b.clone() for b in (eng.s_qkv, eng.att_ws, eng.s_wo, eng.h_mlp, eng.h_mask, eng.s_down, eng.resid[0], eng.resid[1], eng.logits)]  # noqa: E731
+            eng(tok, pos)
+            ref = bufs()
+            for it in range(60):
+                eng(tok, pos)
+                cur = bufs()
+                for name, a, b in zip(("s_qkv", "att_ws", "s_wo", "h_mlp", "h_mask", "s_down", "resid A", "resid B", "logits"), ref, cur):
+                    assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), (it, name)
+    finally:
+        L.teal_set_fast(1)
+        del model
+        torch.cuda.empty_cache()
