@@ -272,17 +272,25 @@ class Transformer(nn.Module):
                         "gate": float(ff.thresh_gate), "up": float(ff.thresh_up), "down": float(ff.thresh_down)})
         return ths
 
+    def _engine_key(self, ths):
+        # everything the engine's launch descriptors hold raw pointers to, plus the thresholds: KV caches re-allocated by
+        # setup_caches, weights replaced by load_state_dict(assign=True) / .to(), new thresholds -> rebuild
+        return (self.max_seq_length, tuple(tuple(t.values()) for t in ths), self.output.weight.data_ptr(),
+                self.tok_embeddings.weight.data_ptr(), self.norm.weight.data_ptr()) + tuple(
+            p for layer in self.layers for p in (layer.attention.kv_cache.k_cache.data_ptr(), layer.attention.kv_cache.v_cache.data_ptr(),
+                                                 layer.attention.wqkv.weight.data_ptr(), layer.attention.wo.weight.data_ptr(),
+                                                 layer.feed_forward.w1.weight.data_ptr(), layer.feed_forward.w2.weight.data_ptr(),
+                                                 layer.feed_forward.w3.weight.data_ptr(), layer.attention_norm.weight.data_ptr(),
+                                                 layer.ffn_norm.weight.data_ptr()))
+
     def _fused_engine(self):
         ths = self._patched_thresholds()
         if ths is None:
             return None
-        # the engine's launch descriptors hold raw pointers and thresholds: rebuild when either changed
-        key = (self.max_seq_length, tuple(tuple(t.values()) for t in ths)) + tuple(
-            p for layer in self.layers for p in (layer.attention.kv_cache.k_cache.data_ptr(), layer.attention.kv_cache.v_cache.data_ptr()))
-        if getattr(self, "_eng_key", None) != key:
+        if getattr(self, "_eng_key", None) != self._engine_key(ths):
             from .engine import DecodeEngine
             object.__setattr__(self, "_eng", DecodeEngine(self, ths))  # not a submodule: it only borrows this model
-            self._eng_key = key
+            self._eng_key = self._engine_key(ths)  # after the build: the engine re-lays lm_head out column-major
         return self._eng
 
     def forward(self, idx: Tensor, input_pos: Optional[Tensor] = None) -> Tensor:

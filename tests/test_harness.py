@@ -231,3 +231,38 @@ def test_graphed_prefill_equals_eager_prefill():
         assert torch.equal(got, want) and len(junk) == 8
         assert torch.equal(m.layers[0].attention.kv_cache.k_cache[:, :, :T], kc[:, :, :T])
     assert len(pre.graphs) == 2  # one graph per prompt length
+
+
+@pytest.mark.gpu
+def test_fused_decode_follows_replaced_weights_and_caches():
+    """the fused step is rebuilt when the storage it points at goes away: weights replaced wholesale, KV caches
+    re-allocated at the same size — the logits follow, and equal the op-by-op path on the same model."""
+    dev = "cuda"
+    m = tiny(dev, torch.float16)
+    G.apply_sparsity(m, sparsity=0.0, hist_path=None, greedy_lookup=None, synthetic=True)
+    toks = torch.randint(0, 512, (6,), device=dev, dtype=torch.int)
+    t, p = torch.tensor([[7]], device=dev, dtype=torch.int), torch.tensor([6], device=dev, dtype=torch.int)
+
+    def step():
+        with torch.no_grad():
+            m(toks.view(1, -1), torch.arange(6, device=dev))
+            a = m(t, p).clone()
+            m.fused_decode = False
+            b = m(t, p).clone()
+            m.fused_decode = True
+        assert torch.allclose(a.float(), b.float(), atol=4e-3, rtol=3e-2)
+        return a
+
+    m.setup_caches(1, 32)
+    a0 = step()
+    eng0 = m._eng
+    w = m.layers[0].feed_forward.w2
+    w.weight = torch.nn.Parameter((w.weight.detach() * 0.5).contiguous(), requires_grad=False)  # new storage, row-major again
+    from teal_amd.monkeypatch import to_column_major
+    to_column_major(w)
+    a1 = step()  # (the allocator may hand the new image the old block: then the same engine is still right)
+    assert not torch.equal(a0, a1) and eng0 is not None
+    m.max_seq_length = -1
+    m.setup_caches(1, 32)  # same size, new cache tensors
+    a2 = step()
+    assert torch.allclose(a1.float(), a2.float(), atol=1e-3)
