@@ -213,7 +213,7 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
     const int* __restrict__ pos_ptr, const float* __restrict__ qkv_slabs, uint16_t* __restrict__ k_cache,
     uint16_t* __restrict__ v_cache, const uint16_t* __restrict__ qkv, float* __restrict__ partials,
     const uint16_t* __restrict__ rope, const int n_head, const int n_kv, const int max_seq, const int nsplit,
-    const float scale, const int qkv_nslabs, unsigned long long* __restrict__ phase) {
+    const float scale, const int qkv_nslabs, unsigned long long* __restrict__ phase, const int exp) {
     constexpr int NW = NT / 64, hd = HD, SL = HD / 8, RW = 64 / SL;
     constexpr int PF = 4, STEP = NW * RW;
     const unsigned long long t_entry = wall_clock64();
@@ -340,8 +340,12 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
 #pragma unroll 4
     for (int i = PF; i < nsteps; ++i)
         score_row(i, *reinterpret_cast<const u32x4*>(kc + (size_t)min(row_of(i), max_seq - 1) * hd + ds * 8));
+    if (exp & 2) {  // A/B: the round-1 form (six ds_bpermute round trips)
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, d));
+        for (int d = 32; d >= 1; d >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, d));
+    } else {
+        lmax = wave_max_f(lmax);  // row_shr DPP: lanes without a predecessor keep their own value (old = src)
+    }
     if (lane == 0) red[wave] = lmax;
     __syncthreads();
     stamp_p(3);
@@ -388,9 +392,17 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
 #pragma unroll 4
     for (int i = PF; i < nsteps; ++i)
         pv_row(i, *reinterpret_cast<const u32x4*>(vc + (size_t)min(row_of(i), max_seq - 1) * hd + ds * 8));
-    for (int off = SL; off < 64; off <<= 1) {
+    if (exp & 4) {
+        for (int off = SL; off < 64; off <<= 1) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] += __shfl_xor(o[j], off);
+            for (int j = 0; j < 8; ++j) o[j] += __shfl_xor(o[j], off);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (SL <= 8) o[j] = xor_add<8>(o[j]);
+            o[j] = xor_add<32>(xor_add<16>(o[j]));
+        }
     }
     if (lane < SL) {
 #pragma unroll
@@ -849,7 +861,7 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
     const dim3 grid(n_head * nsplit), block(nt);
     // stride mode (teal_set_phase_stride): the attention launch takes the next region like a GEMV launch does
     unsigned long long* ph = (g_phase && g_phase_stride) ? g_phase + (size_t)g_phase_seq++ * g_phase_stride : nullptr;
-#define TEAL_ATTS(BF, HDV, NTV) hipLaunchKernelGGL((decode_attention_split_kernel<BF, HDV, NTV>), grid, block, lds, st, pos, qkv_slabs, kc, vc, q, pw, r, n_head, n_kv_head, max_seq, nsplit, scale, qkv_nslabs, ph)
+#define TEAL_ATTS(BF, HDV, NTV) hipLaunchKernelGGL((decode_attention_split_kernel<BF, HDV, NTV>), grid, block, lds, st, pos, qkv_slabs, kc, vc, q, pw, r, n_head, n_kv_head, max_seq, nsplit, scale, qkv_nslabs, ph, g_exp)
 #define TEAL_ATTS_NT(BF, HDV) do { if (nt == 1024) TEAL_ATTS(BF, HDV, 1024); else TEAL_ATTS(BF, HDV, 256); } while (0)
     if (dtype == TEAL_BF16) { if (head_dim == 128) TEAL_ATTS_NT(true, 128); else TEAL_ATTS_NT(true, 64); }
     else { if (head_dim == 128) TEAL_ATTS_NT(false, 128); else TEAL_ATTS_NT(false, 64); }

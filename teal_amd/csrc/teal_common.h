@@ -87,6 +87,7 @@ extern size_t g_phase_stride;
 extern int g_phase_seq;
 extern int g_swizzle;
 extern int g_wave_local;
+extern int g_exp;
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -146,6 +147,38 @@ __device__ __forceinline__ float wave_sum_f(float v) {
            __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 31)) +
            __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 47)) +
            __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 63));
+}
+
+// v[lane] + v[lane ^ OFF] for OFF = 8, 16, 32 — the butterfly steps of the row-group reductions — without the LDS
+// crossbar round trip of __shfl_xor (ds_bpermute) where the ISA offers something cheaper: a DPP row rotate inside the
+// 16-lane row (8), ds_swizzle's SWAP mode (16: no address VGPR, no LDS bank access); 32 stays a shuffle
+// (v_permlane32_swap through the builtin returned both halves unswapped on this toolchain: not used).
+// Same operands as the shuffle, a + b == b + a: bit-identical sums.
+template <int OFF>
+__device__ __forceinline__ float xor_add(const float v) {
+    const int iv = __builtin_bit_cast(int, v);
+    if constexpr (OFF == 8) {
+        return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0x128, 0xf, 0xf, false));  // row_ror:8
+    } else if constexpr (OFF == 16) {
+        return v + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(iv, 0x401F));  // swizzle(SWAP, 16)
+    } else {
+        return v + __shfl_xor(v, OFF);
+    }
+}
+
+// max of a float over the 64 lanes of a wave (result valid in every lane): DPP row shifts + four v_readlane, no LDS
+// crossbar traffic (six __shfl_xor = ds_bpermute round trips otherwise)
+__device__ __forceinline__ float wave_max_f(float v) {
+    auto shr = [](float a, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, a), __builtin_bit_cast(int, a), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    v = fmaxf(v, shr(v, std::integral_constant<int, 0x111>{}));
+    v = fmaxf(v, shr(v, std::integral_constant<int, 0x112>{}));
+    v = fmaxf(v, shr(v, std::integral_constant<int, 0x114>{}));
+    v = fmaxf(v, shr(v, std::integral_constant<int, 0x118>{}));
+    const int iv = __builtin_bit_cast(int, v);
+    return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 15)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 31))),
+                 fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 47)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 63))));
 }
 
 // sum over the SL (16 or 8) consecutive lanes that hold the 16-byte slices of one K/V row

@@ -335,13 +335,25 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
     if constexpr (PHASE) { if (a.phase && lane == 0) a.phase[(size_t)bid * kPhaseRow + 16 + wave] = wall_clock64(); }
 
     // ---- reduce: row groups of the wave (shuffles), then waves in fixed order through LDS -------------------
+    if (a.exp & 4) {  // A/B: shuffles (ds_bpermute) for every butterfly step, as in round 1
 #pragma unroll
-    for (int off = LPR; off < 64; off <<= 1) {
+        for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], off);
-        if constexpr (PAIR) {
+            for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], off);
+            if constexpr (PAIR) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc2[j] += __shfl_xor(acc2[j], off);
+                for (int j = 0; j < 8; ++j) acc2[j] += __shfl_xor(acc2[j], off);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (LPR <= 8) acc[j] = xor_add<8>(acc[j]);
+            acc[j] = xor_add<32>(xor_add<16>(acc[j]));
+            if constexpr (PAIR) {
+                if constexpr (LPR <= 8) acc2[j] = xor_add<8>(acc2[j]);
+                acc2[j] = xor_add<32>(xor_add<16>(acc2[j]));
+            }
         }
     }
     if (lane < LPR) {
