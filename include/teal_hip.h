@@ -256,7 +256,10 @@ int teal_set_wave_local(int on);
 const char* teal_last_launch_desc(void);
 
 /* Experiment switches of the lean kernel, for A/B timing inside one process (0 = production behaviour).
- * bit 0: do not issue the first weight batch before the compaction has finished. */
+ * bit 0: do not issue the first weight batch before the compaction has finished;
+ * bit 1: attention scores' running maximum by six shuffle round trips instead of DPP row shifts + readlanes;
+ * bit 2: butterfly reductions of the GEMV epilogue and of the attention P.V product by shuffles for every step instead
+ *        of a DPP row rotate (lane ^ 8) and a ds_swizzle swap (lane ^ 16).  Results are bit-identical either way. */
 int teal_set_experiment(int mask);
 
 /* Lean kernel for qualifying shapes (default on; 0 forces the general kernel everywhere: A/B and parity tests). */
