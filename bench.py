@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense comparator run")
     ap.add_argument("--swizzle", type=int, default=0, help="XCD-decorrelating tile swizzle (A/B switch)")
+    ap.add_argument("--experiment", type=int, default=0, help="teal_set_experiment mask (A/B switches, include/teal_hip.h; 0 = production)")
     ap.add_argument("--wave-local", type=int, default=1, help="wave-local compaction (A/B switch)")
     return ap.parse_args()
 
@@ -363,6 +364,7 @@ def main():
     from teal_amd import _lib
     _lib.load().teal_set_swizzle(a.swizzle)
     _lib.load().teal_set_wave_local(a.wave_local)
+    _lib.load().teal_set_experiment(a.experiment)
     if a.tuning:
         assert _lib.load().teal_set_tuning(*[int(v) for v in a.tuning.split(",")]) == 0
     if a.pair is not None:

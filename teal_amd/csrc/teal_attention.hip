@@ -420,6 +420,315 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
     stamp_p(7);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Grouped-query split-KV decode attention: one workgroup = one KV head x one share of its cached positions, for ALL
+// REP = n_head / n_kv query heads that read that KV head.  The per-query-head kernel above reads every K/V row REP
+// times (from L2 / the Infinity Cache when the workgroups of a group land on different XCDs): at 16 k positions the
+// Llama-2-70B cache (67 MB per layer) took 83 us = 0.8 TB/s of algorithmic bytes (scripts/attention_context_sweep.py).
+// Here each cache byte is loaded once and feeds REP heads.  That makes the launch instruction-bound on the vector ALU
+// (REP x head_dim multiply-adds per row for Q.K and again for P.V, 4 clocks per wave instruction), so the inner loops
+// are written for instruction count:
+//   * Q.K: the 16 bytes a lane holds of a K row stay packed; q (already rounded to the cache dtype) is held as packed
+//     pairs, one v_dot2c_f32_{f16,bf16} per pair and head (fp32 accumulate) — 4 per head instead of 8 FMAs + unpacking;
+//   * the row sum over the SL lanes of a cache row is a REDUCE-SCATTER over the REP heads (halve the value set at
+//     every butterfly level: 22 instead of 32 DPP adds for REP = 8) that leaves head (lane's bits) in each lane, so
+//     that scaling, rounding, the running max and the LDS store run once per row for all heads, not once per head;
+//   * P.V: probabilities of a row are read as one or two 16-byte LDS words ([row][REP] layout), V is unpacked once per
+//     row and the REP x 8 accumulators advance as packed fp32 pairs (v_pk_fma_f32).
+// Same lane layout, row dealing (round-robin row groups, independent of *pos), rounding points and partial format
+// {m, l, o[hd]} per (query head, split) as decode_attention_split_kernel; the loads run PF row groups ahead.
+// ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_lane(const float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+// One butterfly level over `a[0..NV)`: the partner lane is the DPP pattern CTRL (an involution that flips lane bit BIT).
+// NV > 1: the lane keeps the half of the values its bit selects and adds the partner's copy of that half; NV == 1: plain add.
+template <int NV, int CTRL, int BIT>
+__device__ __forceinline__ void fold_level(float* a, const int lane) {
+    if constexpr (NV > 1) {
+        const bool hi = (lane & BIT) != 0;
+#pragma unroll
+        for (int k = 0; k < NV / 2; ++k) {
+            const float keep = hi ? a[NV / 2 + k] : a[k];
+            const float send = hi ? a[k] : a[NV / 2 + k];
+            a[k] = keep + dpp_lane<CTRL>(send);
+        }
+    } else {
+        a[0] += dpp_lane<CTRL>(a[0]);
+    }
+}
+
+// Sum a[0..REP) over the SL lanes of a cache row; returns the total of head gqa_lane_head<REP, SL>(lane).
+template <int REP, int SL>
+__device__ __forceinline__ float gqa_reduce_scatter(float* a, const int lane) {
+    constexpr int N8 = REP, N4 = (SL == 16 && N8 > 1) ? N8 / 2 : N8, N2 = N4 > 1 ? N4 / 2 : N4, N1 = N2 > 1 ? N2 / 2 : N2;
+    static_assert((N1 > 1 ? N1 / 2 : N1) == 1, "more heads than lanes per row");
+    if constexpr (SL == 16) fold_level<N8, 0x128, 8>(a, lane);  // row_ror:8        lane ^ 8
+    fold_level<N4, 0x141, 4>(a, lane);                         // row_half_mirror  lane ^ 7 (flips bit 2)
+    fold_level<N2, 0x4E, 2>(a, lane);                          // quad_perm[2,3,0,1]  lane ^ 2
+    fold_level<N1, 0xB1, 1>(a, lane);                          // quad_perm[1,0,3,2]  lane ^ 1
+    return a[0];
+}
+
+template <int REP, int SL>
+__device__ __forceinline__ int gqa_lane_head(const int lane) {
+    constexpr int N8 = REP, N4 = (SL == 16 && N8 > 1) ? N8 / 2 : N8, N2 = N4 > 1 ? N4 / 2 : N4, N1 = N2 > 1 ? N2 / 2 : N2;
+    int h = 0;
+    if constexpr (SL == 16 && N8 > 1) h = (h << 1) | ((lane >> 3) & 1);
+    if constexpr (N4 > 1) h = (h << 1) | ((lane >> 2) & 1);
+    if constexpr (N2 > 1) h = (h << 1) | ((lane >> 1) & 1);
+    if constexpr (N1 > 1) h = (h << 1) | (lane & 1);
+    return h;
+}
+
+template <bool BF16>
+__device__ __forceinline__ float dot2_acc(const uint32_t a, const uint32_t b, const float c) {
+    typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+    if constexpr (BF16) return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b16x2, a), __builtin_bit_cast(b16x2, b), c, false);
+    else return __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, a), __builtin_bit_cast(h16x2, b), c, false);
+}
+
+template <bool BF16, int HD, int NT, int REP>
+__global__ __launch_bounds__(NT) void decode_attention_gqa_kernel(
+    const int* __restrict__ pos_ptr, const float* __restrict__ qkv_slabs, uint16_t* __restrict__ k_cache,
+    uint16_t* __restrict__ v_cache, const uint16_t* __restrict__ qkv, float* __restrict__ partials,
+    const uint16_t* __restrict__ rope, const int n_head, const int n_kv, const int max_seq, const int nsplit,
+    const float scale, const int qkv_nslabs, const int lrows) {
+    constexpr int NW = NT / 64, hd = HD, SL = HD / 8, RW = 64 / SL;
+    constexpr int PF = 4, STEP = NW * RW;
+    constexpr int NPAIR = (REP + 2) * (HD / 2), NITEM = (NPAIR + NT - 1) / NT;  // q pairs of REP heads, k pairs, v pairs
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    static_assert(NT % REP == 0 && (REP == 4 || REP == 8), "softmax pass assigns head tid % REP to a thread");
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* qsb = reinterpret_cast<uint32_t*>(smem);  // [REP][hd / 2] rotated, rounded q (packed pairs)
+    uint32_t* knb = qsb + REP * (hd / 2);               // [hd / 2] the token's own rotated k
+    uint32_t* vnb = knb + hd / 2;                       // [hd / 2] ... and v
+    float* red = reinterpret_cast<float*>(vnb + hd / 2);  // [2][REP][NW]: running max, sum
+    float* sc = red + 2 * REP * NW;                     // [lrows][REP] scores -> probabilities; later [NW][REP * hd] partial o
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kvh = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+    const int dim = n_head * hd, kvs = n_kv * hd;
+    uint16_t* kc = k_cache + (size_t)kvh * max_seq * hd;
+    uint16_t* vc = v_cache + (size_t)kvh * max_seq * hd;
+    const int ds = lane % SL, rw = lane / SL;
+    const int rbase = wave * RW + rw;
+    auto row_of = [&](const int i) { return (sp + i * nsplit) * STEP + rbase; };
+    auto k_at = [&](const int i) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kc + (size_t)min(row_of(i), max_seq - 1) * hd + ds * 8)); };
+    auto v_at = [&](const int i) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vc + (size_t)min(row_of(i), max_seq - 1) * hd + ds * 8)); };
+    u32x4 kb[PF], vb[PF];  // the first PF row groups of K and of V leave at the first instruction
+#pragma unroll
+    for (int i = 0; i < PF; ++i) kb[i] = k_at(i);
+#pragma unroll
+    for (int i = 0; i < PF; ++i) vb[i] = v_at(i);
+    // the projection's columns of this group: pairs (2c, 2c + 1); q of heads kvh * REP + r, then k, then v
+    const int sstride = (qkv_nslabs + 3) & ~3;
+    auto pair_col = [&](const int it) -> int {
+        if (it < REP * (hd / 2)) return (kvh * REP) * hd + 2 * it;
+        if (it < (REP + 1) * (hd / 2)) return dim + kvh * hd + 2 * (it - REP * (hd / 2));
+        return dim + kvs + kvh * hd + 2 * (it - (REP + 1) * (hd / 2));
+    };
+    f32x4 la[NITEM][2], lb[NITEM][2];
+    uint32_t lr[NITEM];
+#pragma unroll
+    for (int u = 0; u < NITEM; ++u) {
+        const int it = min(u * NT + tid, NPAIR - 1), col = pair_col(it);
+        if (qkv_slabs) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float* p = qkv_slabs + (size_t)(col + e) * sstride;
+                la[u][e] = *reinterpret_cast<const f32x4*>(p);
+                lb[u][e] = qkv_nslabs > 4 ? *reinterpret_cast<const f32x4*>(p + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+            lr[u] = *reinterpret_cast<const uint32_t*>(qkv + col);
+        }
+    }
+    auto fin = [&](const int u, const int e) -> float {
+        if (!qkv_slabs) return bits_to_float((lr[u] >> (16 * e)) & 0xFFFFu, BF16);
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += (j < qkv_nslabs) ? la[u][e][j] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += (4 + j < qkv_nslabs) ? lb[u][e][j] : 0.0f;
+        return bits_to_float(float_to_bits<BF16>(s), BF16);
+    };
+    const int pos = min(max(pos_ptr[0], 0), max_seq - 1), n = pos + 1;
+    auto out_of = [&](const int r) { return partials + ((size_t)(kvh * REP + r) * nsplit + sp) * (hd + 2); };
+    if (sp * STEP >= n) {  // no row group of this workgroup is in range yet
+        for (int c = tid; c < REP * hd; c += NT) out_of(c / hd)[2 + (c % hd)] = 0.0f;
+        if (tid < REP) { out_of(tid)[0] = -INFINITY; out_of(tid)[1] = 0.0f; }
+        return;
+    }
+    const int nsteps = ((n + STEP - 1) / STEP - sp + nsplit - 1) / nsplit;
+    const bool has_new = ((pos / STEP) % nsplit) == sp;
+#pragma unroll
+    for (int u = 0; u < NITEM; ++u) {
+        const int it = u * NT + tid;
+        if (it >= NPAIR) continue;
+        const float a0 = fin(u, 0), a1 = fin(u, 1);
+        if (it < (REP + 1) * (hd / 2)) {  // q or k pair: rotate by the position's angle, round
+            const int pr = it % (hd / 2);
+            const float c = bits_to_float(rope[((size_t)pos * (hd / 2) + pr) * 2], BF16);
+            const float sn = bits_to_float(rope[((size_t)pos * (hd / 2) + pr) * 2 + 1], BF16);
+            const uint32_t rr = (uint32_t)float_to_bits<BF16>(a0 * c - a1 * sn) | ((uint32_t)float_to_bits<BF16>(a1 * c + a0 * sn) << 16);
+            if (it < REP * (hd / 2)) {
+                qsb[it] = rr;
+            } else if (has_new) {
+                knb[pr] = rr;
+                *reinterpret_cast<uint32_t*>(kc + (size_t)pos * hd + 2 * pr) = rr;
+            }
+        } else if (has_new) {
+            const int pr = it - (REP + 1) * (hd / 2);
+            const uint32_t rr = (uint32_t)float_to_bits<BF16>(a0) | ((uint32_t)float_to_bits<BF16>(a1) << 16);
+            vnb[pr] = rr;
+            *reinterpret_cast<uint32_t*>(vc + (size_t)pos * hd + 2 * pr) = rr;
+        }
+    }
+    __syncthreads();
+    const int myhead = gqa_lane_head<REP, SL>(lane);
+    float lmax = -INFINITY;  // of head `myhead`, over this lane's rows
+    {
+        u32x4 qp[REP];
+#pragma unroll
+        for (int r = 0; r < REP; ++r) qp[r] = *reinterpret_cast<const u32x4*>(qsb + r * (hd / 2) + ds * 4);
+        const u32x4 knw = *reinterpret_cast<const u32x4*>(knb + ds * 4);
+        for (int i0 = 0; i0 < nsteps; i0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int i = i0 + u;
+                u32x4 w = kb[u];
+                kb[u] = k_at(i + PF);  // PF row groups ahead (clamped address past the end: harmless, unused)
+                if (i < nsteps) {  // workgroup-uniform
+                    const int t = row_of(i);
+                    if (t == pos) w = knw;
+                    float a[REP];
+#pragma unroll
+                    for (int r = 0; r < REP; ++r) {
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc = dot2_acc<BF16>(qp[r][j], w[j], acc);
+                        a[r] = acc;
+                    }
+                    const float tot = gqa_reduce_scatter<REP, SL>(a, lane);
+                    const float sv = bits_to_float(float_to_bits<BF16>(tot * scale), BF16);
+                    if (t < n) {
+                        sc[(i * STEP + rbase) * REP + myhead] = sv;  // the lanes that share a head write the same value
+                        lmax = fmaxf(lmax, sv);
+                    }
+                }
+            }
+        }
+    }
+    // max per head: lanes with the same `myhead` differ in the row group bits (lane / SL) and in the duplicated low bits
+#pragma unroll
+    for (int off = 32; off >= SL; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+    if (lane < SL) red[myhead * NW + wave] = lmax;  // duplicates write the same value
+    __syncthreads();
+    {
+        const int r = tid % REP;  // NT % REP == 0: a thread only ever sees entries of head r
+        float m = red[r * NW];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) m = fmaxf(m, red[r * NW + w]);
+        float lsum = 0.0f;
+        for (int e = tid; e < nsteps * STEP * REP; e += NT) {
+            const int le = e / REP;
+            const int t = (sp + (le / STEP) * nsplit) * STEP + (le % STEP);
+            if (t < n) {
+                const float ex = expf(sc[e] - m);
+                sc[e] = ex;
+                lsum += ex;
+            }
+        }
+#pragma unroll
+        for (int off = REP; off < 64; off <<= 1) lsum += __shfl_xor(lsum, off);
+        if (lane < REP) red[(REP + lane) * NW + wave] = lsum;
+    }
+    __syncthreads();
+    f32x2 o[REP][4];
+#pragma unroll
+    for (int r = 0; r < REP; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[r][j] = (f32x2){0.0f, 0.0f};
+    const u32x4 vnw = *reinterpret_cast<const u32x4*>(vnb + ds * 4);
+    for (int i0 = 0; i0 < nsteps; i0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int i = i0 + u;
+            u32x4 w = vb[u];
+            vb[u] = v_at(i + PF);
+            if (i < nsteps) {
+                const int t = row_of(i);
+                if (t < n) {
+                    if (t == pos) w = vnw;
+                    f32x2 vf[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) vf[j] = (f32x2){bits_to_float(w[j] & 0xFFFFu, BF16), bits_to_float(w[j] >> 16, BF16)};
+                    float pr[REP];
+                    const f32x4* pp = reinterpret_cast<const f32x4*>(sc + (size_t)(i * STEP + rbase) * REP);
+#pragma unroll
+                    for (int q4 = 0; q4 < REP / 4; ++q4) {
+                        const f32x4 pv = pp[q4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pr[q4 * 4 + e] = pv[e];
+                    }
+#pragma unroll
+                    for (int r = 0; r < REP; ++r) {
+                        const f32x2 p2 = (f32x2){pr[r], pr[r]};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[r][j] += p2 * vf[j];
+                    }
+                }
+            }
+        }
+    }
+    // sum over the row groups of the wave (lanes with the same 16-byte slice)
+#pragma unroll
+    for (int r = 0; r < REP; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float v = o[r][j][e];
+                if constexpr (SL <= 8) v = xor_add<8>(v);
+                v = xor_add<32>(xor_add<16>(v));
+                o[r][j][e] = v;
+            }
+    __syncthreads();  // every wave is done reading probabilities: the region becomes the per-wave partial o
+    float* part = sc;
+    if (lane < SL) {
+#pragma unroll
+        for (int r = 0; r < REP; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<f32x2*>(part + (wave * REP + r) * hd + lane * 8 + 2 * j) = o[r][j];
+    }
+    __syncthreads();
+    for (int c = tid; c < REP * hd; c += NT) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) acc += part[w * REP * hd + c];
+        out_of(c / hd)[2 + (c % hd)] = acc;
+    }
+    if (tid < REP) {
+        float tot = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += red[(REP + tid) * NW + w];
+        float m = red[tid * NW];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) m = fmaxf(m, red[tid * NW + w]);
+        out_of(tid)[0] = m;
+        out_of(tid)[1] = tot;
+    }
+}
+
+// Merge launch (split counts the wo launch's merge producer does not take): one workgroup per head.  Lane s of every
+// wave holds {m_s, l_s} of split s (nsplit <= 64), so the scale factors cost one load round trip; the o columns are then
+// summed in split order, 32 independent loads at a time (the dependent-load loop this replaces took 9-16 us at
+// 16-32 splits).  Same arithmetic, in the same order, as the merge producer of the GEMV launch.
 template <bool BF16>
 __global__ __launch_bounds__(128) void decode_attention_merge_kernel(const float* __restrict__ partials,
                                                                      uint16_t* __restrict__ y,
@@ -428,15 +737,30 @@ __global__ __launch_bounds__(128) void decode_attention_merge_kernel(const float
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const float* p = partials + (size_t)h * nsplit * (hd + 2);
     if (tid >= hd) return;  // hd = 64 or 128: whole waves
-    float M = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, p[(size_t)s * (hd + 2)]);
+    float m = -INFINITY, l = 0.0f;
+    if (lane < nsplit) {
+        m = p[(size_t)lane * (hd + 2)];
+        l = p[(size_t)lane * (hd + 2) + 1];
+    }
+    const float M = wave_max_f(m);
+    const float f = l > 0.0f ? expf(m - M) : 0.0f;  // empty splits (l == 0, m == -inf) contribute nothing
+    const float lf = l * f;
     float L = 0.0f, O = 0.0f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float* ps = p + (size_t)s * (hd + 2);
-        if (ps[1] > 0.0f) {
-            const float f = expf(ps[0] - M);
-            L += ps[1] * f;
-            O += ps[2 + tid] * f;
+    constexpr int MB = 32;  // loads per round trip
+    for (int s0 = 0; s0 < nsplit; s0 += MB) {
+        float v[MB];
+#pragma unroll
+        for (int u = 0; u < MB; ++u) v[u] = p[(size_t)min(s0 + u, nsplit - 1) * (hd + 2) + 2 + tid];
+#pragma unroll
+        for (int u = 0; u < MB; ++u) {
+            if (s0 + u < nsplit) {  // uniform
+                const float fs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f), s0 + u));
+                const float ls = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf), s0 + u));
+                if (ls > 0.0f) {
+                    L += ls;
+                    O += v[u] * fs;
+                }
+            }
         }
     }
     const uint16_t yb = float_to_bits<BF16>(O / L);
@@ -831,6 +1155,9 @@ int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_
     return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
 }
 
+constexpr int kGqaMinSeq = 4096;            // cache length from which grouped-query models take the grouped kernel
+constexpr size_t kGqaMaxLds = 128 * 1024;   // ... if its scores fit this much LDS (mirrored by engine.py's split choice)
+
 static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv_nslabs, const void* rope, const int32_t* pos,
                                 void* k_cache, void* v_cache, void* y, void* mask_out, float mask_tau, int n_head,
                                 int n_kv_head, int head_dim, int max_seq, int nsplit, void* partials, size_t partials_bytes,
@@ -850,7 +1177,6 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
     const int steps_total = (max_seq + step - 1) / step;
     const int local_steps = (steps_total + nsplit - 1) / nsplit;
     const size_t lds = (size_t)(3 * head_dim + 2 * (nt / 64) + (nt / 64) * head_dim + local_steps * step) * sizeof(float);
-    if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const float scale = 1.0f / sqrtf((float)head_dim);
     auto* q = reinterpret_cast<const uint16_t*>(qkv);
@@ -861,12 +1187,42 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
     const dim3 grid(n_head * nsplit), block(nt);
     // stride mode (teal_set_phase_stride): the attention launch takes the next region like a GEMV launch does
     unsigned long long* ph = (g_phase && g_phase_stride) ? g_phase + (size_t)g_phase_seq++ * g_phase_stride : nullptr;
+    // grouped-query models at long contexts: one workgroup per (KV head, split) serves all the query heads of the group
+    // (the per-query-head kernel is 2-3 us faster below ~2 k positions: scripts/attention_context_sweep.py)
+    const int rep = n_head / n_kv_head;
+    bool gqa = (rep == 4 || rep == 8) && max_seq >= kGqaMinSeq && !(g_exp & 8);
+    if (gqa) {
+        constexpr int GNT = 512, GNW = GNT / 64;
+        const int gstep = GNW * (64 / (head_dim / 8));
+        const int glocal = (((max_seq + gstep - 1) / gstep + nsplit - 1) / nsplit) * gstep;  // rows a workgroup may own
+        const size_t region = (size_t)rep * (glocal > GNW * head_dim ? glocal : GNW * head_dim);
+        const size_t glds = ((size_t)(rep + 2) * (head_dim / 2) + 2 * rep * GNW + region) * sizeof(float);
+        if (glds > kGqaMaxLds) gqa = false;
+        else {
+            const dim3 ggrid(n_kv_head * nsplit), gblock(GNT);
+            // one workgroup per CU: the kernel may take more than the default 64 KB of the CU's 160 KB LDS
+#define TEAL_ATTG(BF, HDV, REPV) do { \
+        auto kfn = decode_attention_gqa_kernel<BF, HDV, GNT, REPV>; \
+        static const hipError_t lds_opt_in = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGqaMaxLds); \
+        if (lds_opt_in != hipSuccess) return TEAL_ERR_LAUNCH; \
+        hipLaunchKernelGGL(kfn, ggrid, gblock, glds, st, pos, qkv_slabs, kc, vc, q, pw, r, n_head, n_kv_head, max_seq, nsplit, scale, qkv_nslabs, glocal); \
+    } while (0)
+#define TEAL_ATTG_R(BF, HDV) do { if (rep == 8) TEAL_ATTG(BF, HDV, 8); else TEAL_ATTG(BF, HDV, 4); } while (0)
+            if (dtype == TEAL_BF16) { if (head_dim == 128) TEAL_ATTG_R(true, 128); else TEAL_ATTG_R(true, 64); }
+            else { if (head_dim == 128) TEAL_ATTG_R(false, 128); else TEAL_ATTG_R(false, 64); }
+#undef TEAL_ATTG_R
+#undef TEAL_ATTG
+        }
+    }
+    if (!gqa) {
+        if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
 #define TEAL_ATTS(BF, HDV, NTV) hipLaunchKernelGGL((decode_attention_split_kernel<BF, HDV, NTV>), grid, block, lds, st, pos, qkv_slabs, kc, vc, q, pw, r, n_head, n_kv_head, max_seq, nsplit, scale, qkv_nslabs, ph, g_exp)
 #define TEAL_ATTS_NT(BF, HDV) do { if (nt == 1024) TEAL_ATTS(BF, HDV, 1024); else TEAL_ATTS(BF, HDV, 256); } while (0)
     if (dtype == TEAL_BF16) { if (head_dim == 128) TEAL_ATTS_NT(true, 128); else TEAL_ATTS_NT(true, 64); }
     else { if (head_dim == 128) TEAL_ATTS_NT(false, 128); else TEAL_ATTS_NT(false, 64); }
 #undef TEAL_ATTS_NT
 #undef TEAL_ATTS
+    }
     if (hipGetLastError() != hipSuccess) return TEAL_ERR_LAUNCH;
     if (!y) return TEAL_OK;  // partials only: the consumer merges (TEAL_IN_ATTN_MERGE)
     auto* yo = reinterpret_cast<uint16_t*>(y);

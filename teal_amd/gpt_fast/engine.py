@@ -119,8 +119,17 @@ class DecodeEngine:
         # attention (flash-decoding): 4 or 8 workgroups per head write split-KV partials that the wo launch
         # merges in its prologue (no extra launch); very long contexts / wide models: up to 16 splits + a
         # merge launch.  att_split > 0 overrides (benchmark A/B).
+        rep = cfg.n_head // cfg.n_local_heads
         if att_split:
             self.att_split = int(att_split)
+        elif rep in (4, 8) and self.max_seq >= 4096:
+            # grouped-query kernel (teal_attention.hip: decode_attention_gqa_kernel): one workgroup per (KV head, split)
+            # reads each K/V row once for the whole group; ~one workgroup per CU, more splits if the scores of a share
+            # would not fit the LDS budget (kGqaMaxLds); merged by the merge launch (or by wo at 4 / 8 splits)
+            ns = min(64, max(8, 256 // cfg.n_local_heads))
+            while ns < 64 and self._gqa_lds_bytes(rep, hd, self.max_seq, ns) > 128 * 1024:
+                ns *= 2
+            self.att_split = ns
         elif self.max_seq <= 1024:
             self.att_split = 4
         elif self.max_seq <= 4096 and dim <= 8192:
@@ -220,6 +229,14 @@ class DecodeEngine:
         if hook:
             hook("after", "head", -1)
         return self.logits
+
+    @staticmethod
+    def _gqa_lds_bytes(rep: int, hd: int, max_seq: int, nsplit: int) -> int:
+        """LDS of the grouped-query attention launch (mirrors attention_split_impl in teal_attention.hip)."""
+        nw = 8
+        step = nw * (64 // (hd // 8))
+        local = (((max_seq + step - 1) // step + nsplit - 1) // nsplit) * step
+        return ((rep + 2) * (hd // 2) + 2 * rep * nw + rep * max(local, nw * hd)) * 4
 
     def _layer(self, i: int, tok_ptr: int, pos_ptr: int, hook=None):
         """The five launches of layer i (module docstring)."""

@@ -43,6 +43,7 @@ transformer_configs = {
                         vocab_size=128256, rope_base=500000),
     "stories15M": dict(n_layer=6, n_head=6, dim=288),
     "tiny-test": dict(n_layer=2, n_head=4, n_local_heads=2, dim=256, intermediate_size=512, vocab_size=512, block_size=128),
+    "tiny-gqa-test": dict(n_layer=2, n_head=8, n_local_heads=2, dim=512, intermediate_size=1024, vocab_size=512, block_size=128),
 }
 
 
