@@ -23,7 +23,9 @@
  *   - extern "C", plain pointers and sizes, no C++/torch types, no exceptions across the boundary.
  *   - All pointers are DEVICE pointers owned by the caller (PyTorch); the library borrows them for
  *     the duration of the stream-ordered launch and never allocates.  Process-global state: the device
- *     properties cached by teal_init() (immutable), and the diagnostics / tuning switches of the last
+ *     properties cached by teal_init() (immutable), two scratch buffers teal_init() allocates once (arrival counters
+ *     of the single-launch split-K GEMV, 1 MB; candidate lists of the multi-workgroup sampler, 1 MB; launches take
+ *     slots of them round-robin, 64 / 16 in flight), and the diagnostics / tuning switches of the last
  *     section (teal_set_tuning, teal_set_fast, teal_set_wave_local, teal_set_swizzle, teal_set_phase_*):
  *     host-side variables read at launch time, NOT thread-safe, meant for benchmarks and tests.
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Every call is
@@ -236,7 +238,10 @@ int teal_decode_attention_split_slabs(const float* qkv_slabs, int qkv_nslabs, co
  * {seed, draw counter}; the kernel bumps the counter so hipGraph replays draw fresh numbers.
  * top_k <= 0 or >= vocab disables the filter.  token_out = device int32[1] (may be the buffer the next
  * decode step reads its token from).  Optional in-graph loop-carried state, so that one graph replay
- * IS one decode step with no host-side glue: pos_inout[0] += 1; history[draw counter] = token. */
+ * IS one decode step with no host-side glue: pos_inout[0] += 1; history[draw counter] = token.
+ * Vocabularies of 8193..131072 entries (multiple of 8) with an active filter run as one workgroup per 8192 logits:
+ * local top-k candidates -> library scratch (teal_init) -> the last workgroup to arrive picks the token; same tokens
+ * as the single-workgroup kernels, which remain for the other shapes (teal_set_experiment bit 4 forces them). */
 int teal_sample_topk(const void* logits, int vocab, int dtype, int top_k, float temperature, void* rng_state,
                      int32_t* token_out, int32_t* pos_inout, int32_t* history, int history_len, void* stream);
 
@@ -259,7 +264,9 @@ const char* teal_last_launch_desc(void);
  * bit 0: do not issue the first weight batch before the compaction has finished;
  * bit 1: attention scores' running maximum by six shuffle round trips instead of DPP row shifts + readlanes;
  * bit 2: butterfly reductions of the GEMV epilogue and of the attention P.V product by shuffles for every step instead
- *        of a DPP row rotate (lane ^ 8) and a ds_swizzle swap (lane ^ 16).  Results are bit-identical either way. */
+ *        of a DPP row rotate (lane ^ 8) and a ds_swizzle swap (lane ^ 16).  Results are bit-identical either way;
+ * bit 3: grouped-query models keep the per-query-head split attention kernel at every cache length;
+ * bit 4: the sampler runs as a single workgroup at every vocabulary size. */
 int teal_set_experiment(int mask);
 
 /* Lean kernel for qualifying shapes (default on; 0 forces the general kernel everywhere: A/B and parity tests). */

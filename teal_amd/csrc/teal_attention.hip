@@ -819,11 +819,10 @@ __device__ __forceinline__ void select_bin(const unsigned int* hist, unsigned in
 }
 
 template <bool BF16>
-__global__ __launch_bounds__(1024) void sample_topk_kernel(const uint16_t* __restrict__ logits, const int V,
-                                                            const int top_k, const float inv_temp,
-                                                            unsigned long long* __restrict__ rng_state,
-                                                            int* __restrict__ token_out, int* __restrict__ pos_inout,
-                                                            int* __restrict__ history, const int history_len) {
+__device__ __forceinline__ void sample_full(const uint16_t* __restrict__ logits, const int V, const int top_k,
+                                            const float inv_temp, unsigned long long* __restrict__ rng_state,
+                                            int* __restrict__ token_out, int* __restrict__ pos_inout,
+                                            int* __restrict__ history, const int history_len) {
     __shared__ unsigned int hist[256];
     __shared__ unsigned int whist[16][256];  // per-wave sub-histograms: logits cluster in a few bins, a single
                                              // shared histogram serialises on LDS atomics
@@ -944,6 +943,15 @@ __global__ __launch_bounds__(1024) void sample_topk_kernel(const uint16_t* __res
         rng_state[1] = c + 1ull;
         if (pos_inout) pos_inout[0] = pos_inout[0] + 1;
     }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(1024) void sample_topk_kernel(const uint16_t* __restrict__ logits, const int V,
+                                                            const int top_k, const float inv_temp,
+                                                            unsigned long long* __restrict__ rng_state,
+                                                            int* __restrict__ token_out, int* __restrict__ pos_inout,
+                                                            int* __restrict__ history, const int history_len) {
+    sample_full<BF16>(logits, V, top_k, inv_temp, rng_state, token_out, pos_inout, history, history_len);
 }
 
 
@@ -1120,6 +1128,236 @@ __global__ __launch_bounds__(1024) void sample_topk_window_kernel(const uint16_t
     stamp_s(4);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Multi-workgroup sampler (vocab % 8 == 0, vocab <= 16 x 8192, 0 < top_k < vocab): the single workgroup above spends
+// its time in NV sequential passes over its registers (14 us at 32 k, 37 us at 128 k logits).  Here workgroup g owns
+// 8192 logits (one 16-byte vector per thread) and
+//   stage A  bounds ITS k-th largest key from below with one pass of the same window select (the lower edge of the
+//            histogram bin that holds it) and appends every key >= that bound, with its index, to a candidate list
+//            in global memory (write-through stores), then takes an arrival ticket;
+//   stage B  (the last workgroup to arrive) reads the <= G x kSampCap candidates, finds the global pivot among them,
+//            and runs the exponential race over the candidates that survive it.
+// Exact: a key >= the global pivot P is >= its chunk's pivot (the k-th largest of a subset is <= the k-th largest of
+// the whole) and so >= the chunk's bound: the union of the candidate sets contains every key >= P, hence its k-th
+// largest is P; the race
+// uses the same counter-based random numbers by vocabulary index and the same tie-break as the single-workgroup
+// kernels, so the tokens are identical (tests/test_engine.py).  A chunk with more than kSampCap candidates (top_k
+// beyond the cap, or massive ties) raises an overflow flag and the last arriver runs the generic two-pass select over
+// the whole vocabulary instead.
+// ------------------------------------------------------------------------------------------------
+// k-th largest of the keys this workgroup's threads hold (NK per thread, absent entries flagged in `valid` bits): the
+// window select of sample_topk_window_kernel.  All 1024 threads call; returns the pivot key (keep keys >= pivot).
+// COARSE: return the lower edge of the histogram bin that holds the k-th largest key instead of resolving the bin — a
+// bound BELOW the exact pivot (a superset of the top-k, by up to one bin of 1 << sh keys), one pass cheaper.
+template <bool BF16, int NK, bool COARSE = false>
+__device__ __forceinline__ uint32_t window_pivot(const uint32_t (&keys)[NK], const uint32_t valid, const uint32_t kmax,
+                                                 const unsigned int top_k, unsigned int* hist, unsigned int (*whist)[256],
+                                                 float* fred, unsigned int* sel, const int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    auto merge_hist = [&]() {
+        __syncthreads();
+        if (tid < 256) {
+            unsigned int a = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) a += whist[w][tid];
+            hist[tid] = a;
+        }
+        __syncthreads();
+    };
+    uint32_t pivot_key = 0u;
+    for (int i = tid; i < 16 * 256; i += 1024) (&whist[0][0])[i] = 0;
+    __syncthreads();
+    for (int sh = BF16 ? 0 : 3;; sh += 3) {
+        if (sh > 8) sh = 8;  // 256 << 8 covers every key
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+            const uint32_t d = (kmax - keys[j]) >> sh;
+            if (((valid >> j) & 1u) && d < 256u) atomicAdd(&whist[wave][255u - d], 1u);
+        }
+        merge_hist();
+        unsigned int inwin = 0;
+        {
+            unsigned int a = (tid < 256) ? hist[tid] : 0u;
+            a = (unsigned int)wave_sum_f((float)a);  // <= 131072: exact in fp32
+            if (lane == 0) fred[wave] = (float)a;
+            __syncthreads();
+            inwin = (unsigned int)(fred[0] + fred[1] + fred[2] + fred[3]);
+        }
+        if (inwin >= top_k || sh == 8) {
+            select_bin(hist, nullptr, sel, top_k, tid);
+            const unsigned int d = 255u - sel[0], need2 = sel[1];
+            __syncthreads();
+            if (sh == 0) {
+                pivot_key = kmax - d;
+            } else if (COARSE) {
+                const uint32_t span = ((d + 1u) << sh) - 1u;  // kmax - key <= span for every key of bins 0..d
+                pivot_key = span >= kmax ? 0u : kmax - span;
+            } else {
+                for (int i = tid; i < 16 * 256; i += 1024) (&whist[0][0])[i] = 0;
+                __syncthreads();
+                const uint32_t lowmask = (1u << sh) - 1u;
+#pragma unroll
+                for (int j = 0; j < NK; ++j) {
+                    const uint32_t e = kmax - keys[j];
+                    if (((valid >> j) & 1u) && (e >> sh) == d) atomicAdd(&whist[wave][255u - (e & lowmask)], 1u);
+                }
+                merge_hist();
+                select_bin(hist, nullptr, sel, need2, tid);
+                pivot_key = kmax - ((d << sh) | (255u - sel[0]));
+                __syncthreads();
+            }
+            break;
+        }
+        for (int i = tid; i < 16 * 256; i += 1024) (&whist[0][0])[i] = 0;  // widen the window and count again
+        __syncthreads();
+    }
+    return pivot_key;
+}
+
+__device__ __forceinline__ uint32_t block_max_u32(uint32_t v, int* ired, const int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
+    __syncthreads();  // ired may still be read from a previous use
+    if (lane == 0) ired[wave] = (int)v;
+    __syncthreads();
+    v = (uint32_t)ired[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) v = max(v, (uint32_t)ired[w]);
+    return v;
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(1024) void sample_topk_multi_kernel(const uint16_t* __restrict__ logits, const int V,
+                                                                  const int top_k, const float inv_temp,
+                                                                  unsigned long long* __restrict__ rng_state,
+                                                                  int* __restrict__ token_out, int* __restrict__ pos_inout,
+                                                                  int* __restrict__ history, const int history_len,
+                                                                  unsigned char* __restrict__ slot) {
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned int whist[16][256];
+    __shared__ float fred[16];
+    __shared__ int ired[16];
+    __shared__ unsigned int sel[2];
+    __shared__ unsigned int lcnt;
+    __shared__ unsigned int lflag;
+    __shared__ unsigned int gcount[kSampMaxGroups];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x, G = gridDim.x;
+    const int V8 = V >> 3;
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(slot);
+    unsigned int* counts = reinterpret_cast<unsigned int*>(slot + (size_t)kSampMaxGroups * kSampCap * 8);
+    unsigned int* ticket = counts + kSampMaxGroups;
+    // ---- stage A: this workgroup's 8192 logits -------------------------------------------------------------
+    const int vi = g * 1024 + tid;
+    const bool ok = vi < V8;
+    const u32x4 raw = reinterpret_cast<const u32x4*>(logits)[min(vi, V8 - 1)];
+    // what the last arriver's epilogue needs from memory is requested now
+    const unsigned long long seed64 = rng_state[0], ctr64 = rng_state[1];
+    const int pos0 = pos_inout ? pos_inout[0] : 0;
+    if (tid == 0) lcnt = 0u;
+    uint32_t keys[8];
+    uint32_t kmax = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        keys[2 * j] = order_key16(raw[j] & 0xFFFFu, BF16);
+        keys[2 * j + 1] = order_key16(raw[j] >> 16, BF16);
+        if (ok) kmax = max(kmax, max(keys[2 * j], keys[2 * j + 1]));
+    }
+    kmax = block_max_u32(kmax, ired, tid);
+    const unsigned int chunk_keys = (unsigned int)(min(V8 - g * 1024, 1024) * 8);
+    // fewer keys in the chunk than requested: every key is a candidate (and overflows the cap: generic path)
+    const uint32_t lpivot = chunk_keys <= (unsigned int)top_k ? 0u
+                            : window_pivot<BF16, 8, true>(keys, ok ? 0xFFu : 0u, kmax, (unsigned int)top_k, hist, whist, fred, sel, tid);
+    __syncthreads();
+    if (ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (keys[j] >= lpivot) {
+                const unsigned int s = atomicAdd(&lcnt, 1u);
+                if (s < (unsigned int)kSampCap)
+                    __hip_atomic_store(&cand[(size_t)g * kSampCap + s], ((unsigned long long)keys[j] << 32) | (unsigned int)(vi * 8 + j),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&counts[g], lcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // arrival ticket (see gemv_fast_kernel): the stores above are write-through and complete before the increment
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lflag = (t == (unsigned)G - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (lflag == 0u) return;
+    // ---- stage B: the last arriver ---------------------------------------------------------------------------
+    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch / replay
+    constexpr int NC = kSampMaxGroups * kSampCap / 1024;  // candidate slots per thread
+    unsigned long long craw[NC];  // requested together with the counts (one round trip); slots past a count are stale
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int sidx = j * 1024 + tid;
+        craw[j] = sidx / kSampCap < G ? __hip_atomic_load(&cand[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    }
+    if (tid < kSampMaxGroups) gcount[tid] = tid < G ? __hip_atomic_load(&counts[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    __syncthreads();
+    bool overflow = false;
+#pragma unroll
+    for (int q = 0; q < kSampMaxGroups; ++q) overflow |= gcount[q] > (unsigned int)kSampCap;
+    if (overflow) {  // workgroup-uniform
+        sample_full<BF16>(logits, V, top_k, inv_temp, rng_state, token_out, pos_inout, history, history_len);
+        return;
+    }
+    uint32_t ck[NC], ci[NC], cvalid = 0u;
+    uint32_t gmax = 0u;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int sidx = j * 1024 + tid, gq = sidx / kSampCap, jj = sidx % kSampCap;
+        ck[j] = 0u; ci[j] = 0u;
+        if (gq < G && (unsigned int)jj < gcount[gq]) {
+            ck[j] = (uint32_t)(craw[j] >> 32); ci[j] = (uint32_t)craw[j];
+            cvalid |= 1u << j;
+            gmax = max(gmax, ck[j]);
+        }
+    }
+    gmax = block_max_u32(gmax, ired, tid);
+    const uint32_t pivot = window_pivot<BF16, NC>(ck, cvalid, gmax, (unsigned int)top_k, hist, whist, fred, sel, tid);
+    auto key_bits = [](const uint32_t k) -> uint32_t { return (k & 0x8000u) ? (k ^ 0x8000u) : (~k & 0xFFFFu); };  // order_key16^-1
+    const float mx = bits_to_float(key_bits(gmax), BF16);
+    const uint32_t seed = (uint32_t)seed64, ctr = (uint32_t)ctr64;
+    float best = -1.0f;
+    int besti = 0x7FFFFFFF;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        if (((cvalid >> j) & 1u) && ck[j] >= pivot) {
+            const int i = (int)ci[j];
+            const float pnum = expf((bits_to_float(key_bits(ck[j]), BF16) - mx) * inv_temp);
+            const float u = ((float)(hash3(seed, ctr, (uint32_t)i) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            const float scv = pnum / (-logf(u));
+            if (scv > best || (scv == best && i < besti)) { best = scv; besti = i; }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float ob = __shfl_xor(best, d);
+        const int oi = __shfl_xor(besti, d);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    __syncthreads();
+    if (lane == 0) { fred[wave] = best; ired[wave] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (fred[w] > best || (fred[w] == best && ired[w] < besti)) { best = fred[w]; besti = ired[w]; }
+        token_out[0] = besti;
+        if (history && (long long)ctr64 < (long long)history_len) history[ctr64] = besti;
+        rng_state[1] = ctr64 + 1ull;
+        if (pos_inout) pos_inout[0] = pos0 + 1;
+    }
+}
+
 }  // namespace teal
 
 using namespace teal;
@@ -1269,7 +1507,13 @@ int teal_sample_topk(const void* logits, int vocab, int dtype, int top_k, float 
 #define TEAL_SAMPLE(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len)
 #define TEAL_SAMPLE_W(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len, g_phase_stride ? nullptr : g_phase)
     const bool bf = dtype == TEAL_BF16;
-    if ((vocab & 7) == 0 && vocab <= 4 * 8192) {  // register-resident keys, window select: 4 vectors per thread
+    if ((vocab & 7) == 0 && vocab > 8192 && vocab <= kSampMaxGroups * 8192 && top_k > 0 && top_k < vocab && g_sampler_ws && !(g_exp & 16)) {
+        // one workgroup per 8192 logits + the last arriver (sample_topk_multi_kernel)
+        unsigned char* slot = g_sampler_ws + (size_t)(g_sampler_seq++ % kSampSlots) * kSampSlotBytes;
+        const dim3 grid((vocab / 8 + 1023) / 1024), block(1024);
+        if (bf) hipLaunchKernelGGL((sample_topk_multi_kernel<true>), grid, block, 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len, slot);
+        else hipLaunchKernelGGL((sample_topk_multi_kernel<false>), grid, block, 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len, slot);
+    } else if ((vocab & 7) == 0 && vocab <= 4 * 8192) {  // register-resident keys, window select: 4 vectors per thread
         if (bf) TEAL_SAMPLE_W((sample_topk_window_kernel<true, 4>)); else TEAL_SAMPLE_W((sample_topk_window_kernel<false, 4>));
     } else if ((vocab & 7) == 0 && vocab <= 16 * 8192) {  // 16 vectors per thread (Llama-3's 128256)
         if (bf) TEAL_SAMPLE_W((sample_topk_window_kernel<true, 16>)); else TEAL_SAMPLE_W((sample_topk_window_kernel<false, 16>));

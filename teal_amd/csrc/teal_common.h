@@ -88,6 +88,14 @@ extern int g_phase_seq;
 extern int g_swizzle;
 extern int g_wave_local;
 extern int g_exp;
+// scratch of the multi-workgroup sampler (teal_attention.hip): kSampSlots x kSampSlotBytes, allocated and zeroed by
+// teal_init(); a launch takes the next slot (candidates of up to 16 chunks x 512, their counts, the arrival ticket)
+constexpr int kSampCap = 512;      // candidates a chunk of 8192 logits may contribute
+constexpr int kSampMaxGroups = 16;
+constexpr int kSampSlots = 16;
+constexpr size_t kSampSlotBytes = (size_t)kSampMaxGroups * kSampCap * 8 + 256;
+extern unsigned char* g_sampler_ws;
+extern unsigned g_sampler_seq;
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -132,6 +132,8 @@ int g_fast = 1;  // lean kernel (teal_gemv_fast.h) where the shape qualifies
 int g_exp = 0;   // experiment switches handed to the lean kernel (teal_set_experiment)
 unsigned* g_tickets = nullptr;  // kTicketSlots x kTicketTiles arrival counters (zeroed once; every launch re-arms its own)
 unsigned g_ticket_seq = 0;
+unsigned char* g_sampler_ws = nullptr;
+unsigned g_sampler_seq = 0;
 constexpr int kTicketSlots = 64, kTicketTiles = 4096;
 char g_last_desc[160] = "";  // template instantiation + grid of the most recent GEMV launch (teal_last_launch_desc)
 
@@ -495,6 +497,13 @@ int teal_init(void) {
         if (hipMalloc(&g_tickets, (size_t)kTicketSlots * kTicketTiles * sizeof(unsigned)) != hipSuccess ||
             hipMemset(g_tickets, 0, (size_t)kTicketSlots * kTicketTiles * sizeof(unsigned)) != hipSuccess) {
             g_tickets = nullptr;
+            (void)hipGetLastError();
+        }
+    }
+    if (!g_sampler_ws) {  // multi-workgroup sampler scratch (1 MB); without it the single-workgroup sampler runs
+        if (hipMalloc(&g_sampler_ws, (size_t)kSampSlots * kSampSlotBytes) != hipSuccess ||
+            hipMemset(g_sampler_ws, 0, (size_t)kSampSlots * kSampSlotBytes) != hipSuccess) {
+            g_sampler_ws = nullptr;
             (void)hipGetLastError();
         }
     }

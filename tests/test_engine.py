@@ -510,7 +510,8 @@ def test_attention_from_qkv_slabs_equals_rounded_qkv(dtype, nslabs):
 
 @pytest.mark.parametrize("dtype,V,law", [(torch.float16, 32000, "normal"), (torch.bfloat16, 128256, "normal"), (torch.float16, 50304, "normal"),
                                          (torch.bfloat16, 4096, "normal"), (torch.float16, 32000, "flat"), (torch.bfloat16, 32000, "flat"),
-                                         (torch.float16, 32000, "spike")])
+                                         (torch.float16, 32000, "spike"), (torch.float16, 8200, "normal"), (torch.bfloat16, 131072, "flat"),
+                                         (torch.float16, 128256, "ties")])
 def test_sampler_window_and_radix_kernels_pick_the_same_tokens(dtype, V, law):
     """vocab % 8 == 0 runs the register-resident window-select kernel, V + 4 (logit -inf appended) the generic radix
     kernel: same pivot, same kept set, same counter-based random numbers -> identical tokens.  `flat` (uniform over
@@ -523,6 +524,8 @@ def test_sampler_window_and_radix_kernels_pick_the_same_tokens(dtype, V, law):
     if law == "normal":
         base = (torch.randn(V, device=DEV, generator=g) * 3).to(dtype)
         base[100:140] = base.float().max().to(dtype)          # a tie at the top: top_k = 20 must keep all of it
+    elif law == "ties":  # a few distinct values: thousands of ties at every pivot (candidate lists overflow -> generic path)
+        base = torch.randint(-3, 4, (V,), device=DEV, generator=g).to(dtype)
     elif law == "flat":
         base = ((torch.rand(V, device=DEV, generator=g) - 0.5) * 200).to(dtype)
     else:
@@ -532,7 +535,9 @@ def test_sampler_window_and_radix_kernels_pick_the_same_tokens(dtype, V, law):
     tok = torch.zeros(1, dtype=torch.int32, device=DEV)
     for top_k, temp in ((200, 0.8), (20, 1.0), (1, 1.0), (0, 1.0), (5000, 2.0), (V - 1, 1.5)):
         outs = []
-        for logits, n in ((base, V), (padded, V + 4)):
+        # multi-workgroup kernel (8192 < V <= 131072, filter on), single-workgroup window kernel, generic radix kernel
+        for logits, n, exp in ((base, V, 0), (padded, V + 4, 0), (base, V, 16)):
+            L.teal_set_experiment(exp)
             state = torch.tensor([1234, 0], dtype=torch.int64, device=DEV)
             pos = torch.tensor([11], dtype=torch.int32, device=DEV)
             hist = torch.full((64,), -1, dtype=torch.int32, device=DEV)
@@ -543,7 +548,9 @@ def test_sampler_window_and_radix_kernels_pick_the_same_tokens(dtype, V, law):
                 seq.append(int(tok.item()))
             assert int(state[1]) == 24 and int(pos[0]) == 11 + 24 and hist[:24].tolist() == seq
             outs.append(seq)
+        L.teal_set_experiment(0)
         assert outs[0] == outs[1], (top_k, outs[0][:8], outs[1][:8])
+        assert outs[0] == outs[2], (top_k, outs[0][:8], outs[2][:8])
         assert max(outs[0]) < V
         if top_k == 20 and law == "normal":
             tied = set(torch.nonzero(base == base.float().max().to(dtype)).view(-1).tolist())
