@@ -1358,6 +1358,23 @@ __global__ __launch_bounds__(1024) void sample_topk_multi_kernel(const uint16_t*
     }
 }
 
+constexpr int kGqaMinSeq = 4096;            // cache length from which grouped-query models take the grouped kernel
+constexpr size_t kGqaMaxLds = 128 * 1024;   // ... if its scores fit this much LDS (mirrored by engine.py's split choice)
+
+static bool g_gqa_lds_ok = false;
+
+// teal_init(): one workgroup per CU, so the grouped-query kernel may take more than the default 64 KB of the CU's
+// 160 KB LDS (scores of a long share); opted in once here, outside any stream capture.
+void attention_init() {
+    bool ok = true;
+#define TEAL_OPT(BF, HDV, REPV) ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_attention_gqa_kernel<BF, HDV, 512, REPV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGqaMaxLds) == hipSuccess
+    TEAL_OPT(false, 128, 8); TEAL_OPT(false, 128, 4); TEAL_OPT(false, 64, 8); TEAL_OPT(false, 64, 4);
+    TEAL_OPT(true, 128, 8); TEAL_OPT(true, 128, 4); TEAL_OPT(true, 64, 8); TEAL_OPT(true, 64, 4);
+#undef TEAL_OPT
+    if (!ok) (void)hipGetLastError();
+    g_gqa_lds_ok = ok;
+}
+
 }  // namespace teal
 
 using namespace teal;
@@ -1392,9 +1409,6 @@ int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_
 #undef TEAL_ATT
     return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
 }
-
-constexpr int kGqaMinSeq = 4096;            // cache length from which grouped-query models take the grouped kernel
-constexpr size_t kGqaMaxLds = 128 * 1024;   // ... if its scores fit this much LDS (mirrored by engine.py's split choice)
 
 static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv_nslabs, const void* rope, const int32_t* pos,
                                 void* k_cache, void* v_cache, void* y, void* mask_out, float mask_tau, int n_head,
@@ -1435,16 +1449,10 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
         const int glocal = (((max_seq + gstep - 1) / gstep + nsplit - 1) / nsplit) * gstep;  // rows a workgroup may own
         const size_t region = (size_t)rep * (glocal > GNW * head_dim ? glocal : GNW * head_dim);
         const size_t glds = ((size_t)(rep + 2) * (head_dim / 2) + 2 * rep * GNW + region) * sizeof(float);
-        if (glds > kGqaMaxLds) gqa = false;
+        if (glds > (g_gqa_lds_ok ? kGqaMaxLds : 64 * 1024)) gqa = false;
         else {
             const dim3 ggrid(n_kv_head * nsplit), gblock(GNT);
-            // one workgroup per CU: the kernel may take more than the default 64 KB of the CU's 160 KB LDS
-#define TEAL_ATTG(BF, HDV, REPV) do { \
-        auto kfn = decode_attention_gqa_kernel<BF, HDV, GNT, REPV>; \
-        static const hipError_t lds_opt_in = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGqaMaxLds); \
-        if (lds_opt_in != hipSuccess) return TEAL_ERR_LAUNCH; \
-        hipLaunchKernelGGL(kfn, ggrid, gblock, glds, st, pos, qkv_slabs, kc, vc, q, pw, r, n_head, n_kv_head, max_seq, nsplit, scale, qkv_nslabs, glocal); \
-    } while (0)
+#define TEAL_ATTG(BF, HDV, REPV) hipLaunchKernelGGL((decode_attention_gqa_kernel<BF, HDV, GNT, REPV>), ggrid, gblock, glds, st, pos, qkv_slabs, kc, vc, q, pw, r, n_head, n_kv_head, max_seq, nsplit, scale, qkv_nslabs, glocal)
 #define TEAL_ATTG_R(BF, HDV) do { if (rep == 8) TEAL_ATTG(BF, HDV, 8); else TEAL_ATTG(BF, HDV, 4); } while (0)
             if (dtype == TEAL_BF16) { if (head_dim == 128) TEAL_ATTG_R(true, 128); else TEAL_ATTG_R(true, 64); }
             else { if (head_dim == 128) TEAL_ATTG_R(false, 128); else TEAL_ATTG_R(false, 64); }

@@ -94,6 +94,7 @@ constexpr int kSampCap = 512;      // candidates a chunk of 8192 logits may cont
 constexpr int kSampMaxGroups = 16;
 constexpr int kSampSlots = 16;
 constexpr size_t kSampSlotBytes = (size_t)kSampMaxGroups * kSampCap * 8 + 256;
+void attention_init();  // teal_attention.hip: per-kernel attributes, from teal_init()
 extern unsigned char* g_sampler_ws;
 extern unsigned g_sampler_seq;
 

@@ -500,6 +500,7 @@ int teal_init(void) {
             (void)hipGetLastError();
         }
     }
+    attention_init();
     if (!g_sampler_ws) {  // multi-workgroup sampler scratch (1 MB); without it the single-workgroup sampler runs
         if (hipMalloc(&g_sampler_ws, (size_t)kSampSlots * kSampSlotBytes) != hipSuccess ||
             hipMemset(g_sampler_ws, 0, (size_t)kSampSlots * kSampSlotBytes) != hipSuccess) {
