@@ -278,3 +278,20 @@ def test_to_column_major_int8_pads_128_bytes():
     assert m.weight.shape == (40, 64) and m.weight.stride() == (1, 40 + 128) and torch.equal(m.weight, before)
     to_column_major(lin)
     assert lin.weight.stride() == (1, 40 + 64)
+
+
+def test_engine_grouped_query_split_choice_mirrors_the_launcher():
+    """engine.py picks the split count of the grouped-query attention launch from the same LDS formula and limits as
+    attention_split_impl (teal_attention.hip); a drift would silently fall back to the per-query-head kernel."""
+    import re
+    from teal_amd.gpt_fast.engine import DecodeEngine
+    src = open(os.path.join(ROOT, "teal_amd", "csrc", "teal_attention.hip")).read()
+    assert re.search(r"kGqaMinSeq\s*=\s*4096;", src) and re.search(r"kGqaMaxLds\s*=\s*128\s*\*\s*1024;", src)
+    eng_src = open(os.path.join(ROOT, "teal_amd", "gpt_fast", "engine.py")).read()
+    assert "self.max_seq >= 4096" in eng_src and "> 128 * 1024" in eng_src
+    f = DecodeEngine._gqa_lds_bytes
+    # Llama-2-70B shapes: 8 query heads per KV head, head_dim 128, 16 k positions, 32 splits -> 512 rows per share
+    assert f(8, 128, 16384, 32) == ((8 + 2) * 64 + 2 * 8 * 8 + 8 * max(512, 8 * 128)) * 4
+    # a share's scores grow with the cache length and shrink with the split count
+    assert f(8, 128, 131072, 32) > 128 * 1024 >= f(8, 128, 131072, 64)
+    assert f(4, 64, 4096, 8) == ((4 + 2) * 32 + 2 * 4 * 8 + 4 * max(512, 8 * 64)) * 4
