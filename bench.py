@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense comparator run")
     ap.add_argument("--swizzle", type=int, default=0, help="XCD-decorrelating tile swizzle (A/B switch)")
+    ap.add_argument("--block_size", type=int, default=0, help="override the architecture's context length (RoPE table / cache limit) "
+                    "for long-context experiments; 0 = the reference's value (2048 for 7B)")
     ap.add_argument("--experiment", type=int, default=0, help="teal_set_experiment mask (A/B switches, include/teal_hip.h; 0 = production)")
     ap.add_argument("--wave-local", type=int, default=1, help="wave-local compaction (A/B switch)")
     return ap.parse_args()
@@ -380,6 +382,11 @@ def main():
             mode = "dropin"
 
     model = G.build_synthetic_model(a.model, "cuda", dt, n_layer=a.n_layer)
+    if a.block_size:
+        model.config.block_size = a.block_size
+    if a.prompt_tokens + 8 > model.config.block_size:
+        raise SystemExit(f"--prompt_tokens {a.prompt_tokens} does not fit the model's context (block_size "
+                         f"{model.config.block_size}); pass --block_size for a long-context experiment")
     if a.weights == "int8":
         from teal_amd.quantize import quantize_model_int8
         quantize_model_int8(model)
