@@ -9,7 +9,8 @@ from collections import defaultdict
 
 
 def short(n):
-    for kn in ("gemv_fast_kernel", "sparse_gemv_kernel", "decode_attention_split_kernel", "sample_topk_window_kernel"):
+    for kn in ("gemv_fast_kernel", "sparse_gemv_kernel", "decode_attention_split_kernel", "decode_attention_gqa_kernel",
+               "decode_attention_merge_kernel", "sample_topk_window_kernel", "sample_topk_multi_kernel"):
         m = re.search(kn + r"<([^>]*)>", n)
         if m:
             return kn + "<" + m.group(1).replace(" ", "") + ">"
