@@ -269,7 +269,8 @@ const char* teal_last_launch_desc(void);
  * bit 2: butterfly reductions of the GEMV epilogue and of the attention P.V product by shuffles for every step instead
  *        of a DPP row rotate (lane ^ 8) and a ds_swizzle swap (lane ^ 16).  Results are bit-identical either way;
  * bit 3: grouped-query models keep the per-query-head split attention kernel at every cache length;
- * bit 4: the sampler runs as a single workgroup at every vocabulary size. */
+ * bit 4: the sampler runs as a single workgroup at every vocabulary size;
+ * bit 5: no issue-priority ramp over the waves of a workgroup on short row lists. */
 int teal_set_experiment(int mask);
 
 /* Lean kernel for qualifying shapes (default on; 0 forces the general kernel everywhere: A/B and parity tests). */

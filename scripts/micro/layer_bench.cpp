@@ -119,6 +119,7 @@ int main(int argc, char** argv) {
     if (ncu <= 0) { fprintf(stderr, "no device\n"); return 1; }
     hipStream_t st; CK(hipStreamCreate(&st));
     g_st = st; g_trace = getenv("LB_TRACE") != nullptr;
+    if (getenv("LB_EXP")) TK(teal_set_experiment(atoi(getenv("LB_EXP"))));  // whole run under an experiment mask (phase stamps of a variant)
     hipStream_t st2; CK(hipStreamCreate(&st2));
     hipStream_t ls = st;  // the stream the k_* launch helpers use
     auto alloc16 = [&](size_t n, uint32_t seed, float amp) {
