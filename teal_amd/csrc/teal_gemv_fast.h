@@ -301,7 +301,7 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
         // while long lists lose 0.3-0.7 % (every row kept, or 8192-wide models) and keep the default.  Timing only.
         prio_set = nloc < 6 * STEP && !(a.exp & 32);  // exp bit 5: off (A/B)
         if (prio_set) {
-            switch (wave >> 2) {
+            switch (wave >> 2) {  // (oldest first made explicit: -1.2 %; interleaved, wave & 3: -0.8 % against this ramp)
                 case 1: __builtin_amdgcn_s_setprio(1); break;
                 case 2: __builtin_amdgcn_s_setprio(2); break;
                 case 3: __builtin_amdgcn_s_setprio(3); break;
