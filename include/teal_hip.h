@@ -218,7 +218,7 @@ int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_
  * that write un-normalised partials {max, sum, o[head_dim]} (fp32, n_head*nsplit*(head_dim+2) floats), then
  * a merge launch rescales, sums, rounds once and emits the masks.  Use when max_seq is in the thousands:
  * one workgroup per head would leave most CUs idle while n_head of them stream the whole KV cache.
- * nsplit <= 64.  Grouped-query shapes (n_head / n_kv_head of 4 or 8) with max_seq >= 4096 run as ONE workgroup per
+ * nsplit <= 64.  Grouped-query shapes (n_head / n_kv_head = 8 with max_seq >= 2048, = 4 with max_seq >= 4096) run as ONE workgroup per
  * (KV head, split) that serves all query heads of the group, so every K/V row is read once instead of once per query
  * head; choose nsplit so that n_kv_head * nsplit is about the CU count (32 for 8 KV heads).  Same partial format. */
 int teal_decode_attention_split(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,

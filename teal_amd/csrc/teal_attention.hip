@@ -1358,7 +1358,8 @@ __global__ __launch_bounds__(1024) void sample_topk_multi_kernel(const uint16_t*
     }
 }
 
-constexpr int kGqaMinSeq = 4096;            // cache length from which grouped-query models take the grouped kernel
+constexpr int kGqaMinSeq8 = 2048;           // cache length from which 8-heads-per-KV-head models take the grouped kernel
+constexpr int kGqaMinSeq = 4096;            // ... and 4-heads-per-KV-head models
 constexpr size_t kGqaMaxLds = 128 * 1024;   // ... if its scores fit this much LDS (mirrored by engine.py's split choice)
 
 static bool g_gqa_lds_ok = false;
@@ -1442,7 +1443,7 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
     // grouped-query models at long contexts: one workgroup per (KV head, split) serves all the query heads of the group
     // (the per-query-head kernel is 2-3 us faster below ~2 k positions: scripts/attention_context_sweep.py)
     const int rep = n_head / n_kv_head;
-    bool gqa = (rep == 4 || rep == 8) && max_seq >= kGqaMinSeq && !(g_exp & 8);
+    bool gqa = ((rep == 8 && max_seq >= kGqaMinSeq8) || (rep == 4 && max_seq >= kGqaMinSeq)) && !(g_exp & 8);
     if (gqa) {
         constexpr int GNT = 512, GNW = GNT / 64;
         const int gstep = GNW * (64 / (head_dim / 8));

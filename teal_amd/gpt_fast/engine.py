@@ -122,7 +122,7 @@ class DecodeEngine:
         rep = cfg.n_head // cfg.n_local_heads
         if att_split:
             self.att_split = int(att_split)
-        elif rep in (4, 8) and self.max_seq >= 4096:
+        elif (rep == 8 and self.max_seq >= 2048) or (rep == 4 and self.max_seq >= 4096):
             # grouped-query kernel (teal_attention.hip: decode_attention_gqa_kernel): one workgroup per (KV head, split)
             # reads each K/V row once for the whole group; ~one workgroup per CU, more splits if the scores of a share
             # would not fit the LDS budget (kGqaMaxLds); merged by the merge launch (or by wo at 4 / 8 splits)

@@ -391,7 +391,7 @@ def test_decode_attention_split_long_context(dtype):
                                                    ("tiny-gqa-test", 4096, 3000, False), ("tiny-gqa-test", 2048, 1500, True)])
 def test_engine_long_context_uses_split_attention(name, block, plen, fused):
     """8 split-KV partials merged by the wo launch up to 4096 positions; 16 + the merge launch beyond.  Grouped-query
-    models (4 or 8 query heads per KV head) take the grouped kernel from 4096 cache positions: ~one workgroup per CU
+    models (4 or 8 query heads per KV head) take the grouped kernel from 4096 cache positions (2048 with 8 heads per KV head): ~one workgroup per CU
     (n_kv x splits), merged by the merge launch."""
     from teal_amd.gpt_fast import generate as G
     from teal_amd.gpt_fast.engine import DecodeEngine

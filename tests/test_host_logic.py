@@ -286,9 +286,10 @@ def test_engine_grouped_query_split_choice_mirrors_the_launcher():
     import re
     from teal_amd.gpt_fast.engine import DecodeEngine
     src = open(os.path.join(ROOT, "teal_amd", "csrc", "teal_attention.hip")).read()
-    assert re.search(r"kGqaMinSeq\s*=\s*4096;", src) and re.search(r"kGqaMaxLds\s*=\s*128\s*\*\s*1024;", src)
+    assert re.search(r"kGqaMinSeq\s*=\s*4096;", src) and re.search(r"kGqaMinSeq8\s*=\s*2048;", src)
+    assert re.search(r"kGqaMaxLds\s*=\s*128\s*\*\s*1024;", src)
     eng_src = open(os.path.join(ROOT, "teal_amd", "gpt_fast", "engine.py")).read()
-    assert "self.max_seq >= 4096" in eng_src and "> 128 * 1024" in eng_src
+    assert "(rep == 8 and self.max_seq >= 2048) or (rep == 4 and self.max_seq >= 4096)" in eng_src and "> 128 * 1024" in eng_src
     f = DecodeEngine._gqa_lds_bytes
     # Llama-2-70B shapes: 8 query heads per KV head, head_dim 128, 16 k positions, 32 splits -> 512 rows per share
     assert f(8, 128, 16384, 32) == ((8 + 2) * 64 + 2 * 8 * 8 + 8 * max(512, 8 * 128)) * 4
