@@ -350,7 +350,7 @@ def test_decode_attention_split_long_context(dtype):
                                              (64, 8, 128, 16000, 16384, 32), (16, 2, 64, 37, 1024, 4), (32, 8, 128, 226, 464, 4),
                                              (8, 1, 128, 0, 512, 8), (16, 4, 64, 1023, 1024, 3), (6, 2, 128, 700, 2048, 4),
                                              (16, 2, 64, 4000, 4096, 16), (16, 4, 64, 37, 4096, 8), (8, 1, 128, 0, 8192, 32),
-                                             (32, 8, 128, 8191, 8192, 64)):
+                                             (32, 8, 128, 8191, 8192, 64), (16, 2, 64, 2500, 3072, 16), (64, 8, 128, 2047, 2048, 32)):
         g = torch.Generator(device=DEV).manual_seed(pos + hd)
         qkv = (torch.randn((n_head + 2 * n_kv) * hd, device=DEV, generator=g) * 0.5).to(dtype)
         kc = (torch.randn(n_kv, S, hd, device=DEV, generator=g) * 0.5).to(dtype)
