@@ -296,3 +296,13 @@ def test_engine_grouped_query_split_choice_mirrors_the_launcher():
     # a share's scores grow with the cache length and shrink with the split count
     assert f(8, 128, 131072, 32) > 128 * 1024 >= f(8, 128, 131072, 64)
     assert f(4, 64, 4096, 8) == ((4 + 2) * 32 + 2 * 4 * 8 + 4 * max(512, 8 * 64)) * 4
+
+
+def test_measurement_scripts_compile():
+    """scripts/ only run on the GPU box; a syntax error there would surface in the middle of a measurement session."""
+    import glob
+    import py_compile
+    files = sorted(glob.glob(os.path.join(ROOT, "scripts", "*.py")) + glob.glob(os.path.join(ROOT, "scripts", "micro", "*.py")))
+    assert len(files) >= 10
+    for f in files + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]:
+        py_compile.compile(f, doraise=True)
