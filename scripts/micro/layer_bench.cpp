@@ -136,7 +136,10 @@ int main(int argc, char** argv) {
         l.wqkv = alloc16((size_t)dim * ldq, seed++, a_in * 1.5f);
         l.wo = alloc16((size_t)dim * ldo, seed++, a_in * 1.5f);
         l.w1 = alloc16((size_t)dim * ldi, seed++, a_in * 1.5f);
-        l.w3 = alloc16((size_t)dim * ldi, seed++, a_in * 1.5f);
+        {   // LB_W3OFF=<bytes, multiple of 16>: shift the up matrix against the gate matrix (DRAM channel alignment of the pair)
+            const size_t off = getenv("LB_W3OFF") ? (size_t)atoi(getenv("LB_W3OFF")) / 2 : 0;
+            l.w3 = alloc16((size_t)dim * ldi + off, seed++, a_in * 1.5f) + off;
+        }
         l.w2 = alloc16((size_t)inter * ldd, seed++, a_dn * 1.5f);
         l.norm1 = alloc16(dim, seed++, 0.0f); l.norm2 = alloc16(dim, seed++, 0.0f);
         l.kc = alloc16((size_t)S.n_kv * max_seq * hd, seed++, 1.0f);

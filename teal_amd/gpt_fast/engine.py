@@ -25,7 +25,7 @@ from typing import Dict, List, Optional
 import torch
 
 from .. import _lib, runtime
-from ..monkeypatch import to_column_major
+from ..monkeypatch import UP_SHIFT_BYTES, to_column_major
 from .model import Transformer
 
 TEAL_IN_PLAIN, TEAL_IN_RESID_NORM, TEAL_IN_SILU_MUL, TEAL_IN_MASKED, TEAL_IN_ATTN_MERGE = 0, 1, 2, 3, 4
@@ -96,7 +96,7 @@ class DecodeEngine:
         for layer in model.layers:
             for lin in (layer.attention.wqkv, layer.attention.wo, layer.feed_forward.w1, layer.feed_forward.w3,
                         layer.feed_forward.w2):
-                to_column_major(lin)
+                to_column_major(lin, shift_bytes=UP_SHIFT_BYTES if lin is layer.feed_forward.w3 else 0)
         to_column_major(model.output)
         e = lambda *shape, dtype=dt: torch.zeros(*shape, device=dev, dtype=dtype)  # noqa: E731
         self.resid = [e(dim), e(dim)]

@@ -426,10 +426,10 @@ def main(args) -> Dict:
         decoder = EngineDecoder(model, thresholds, args.compile, args.temperature, args.top_k)
         # the engine re-lays every projection (and lm_head) out column-major when it is built, lazily, after the first
         # prefill: do it NOW so that a --compile_prefill graph never captures pointers to storage that is freed later
-        from teal_amd.monkeypatch import to_column_major
+        from teal_amd.monkeypatch import UP_SHIFT_BYTES, to_column_major
         for layer in model.layers:
             for lin in (layer.attention.wqkv, layer.attention.wo, layer.feed_forward.w1, layer.feed_forward.w3, layer.feed_forward.w2):
-                to_column_major(lin)
+                to_column_major(lin, shift_bytes=UP_SHIFT_BYTES if lin is layer.feed_forward.w3 else 0)
         to_column_major(model.output)
     prefill = GraphedPrefill(model) if getattr(args, "compile_prefill", False) else None
     tps, seqs = [], []

@@ -42,7 +42,13 @@ def layer_thresholds(layer_idx: int, hist_path: str, sparsities: Dict[str, Seque
 ROW_PAD = 64  # elements (128 B): see to_column_major
 
 
-def to_column_major(linear: torch.nn.Module, pad: Optional[int] = None) -> None:
+# The up matrix starts this many bytes into its allocation: large allocations are 2 MB-aligned, so gate row m and up row m
+# (requested together by the fused gate|up launch) would otherwise sit in the same DRAM channel phase; shifted, a
+# Llama-2-7B layer runs 0.3 us faster (53.6 -> 53.3 us, scripts/micro/layer_bench LB_W3OFF, alternating runs on one box).
+UP_SHIFT_BYTES = int(os.environ.get("TEAL_UP_SHIFT_BYTES", "1024"))  # the variable exists for the A/B measurement only
+
+
+def to_column_major(linear: torch.nn.Module, pad: Optional[int] = None, shift_bytes: int = 0) -> None:
     """weight.data = weight.data.T.contiguous().T : shape stays [N, Z], memory becomes W^T [Z][ld]
     (gpt-fast/generate.py:296-317), here with a row stride ld = N + pad.
 
@@ -60,7 +66,10 @@ def to_column_major(linear: torch.nn.Module, pad: Optional[int] = None) -> None:
     ld = N + pad
     if w.stride(0) == 1 and w.stride(1) == ld:
         return
-    buf = torch.zeros(Z, ld, dtype=w.dtype, device=w.device)
+    shift = shift_bytes // w.element_size()  # keeps the 16-byte (and 128-byte tile) alignment of every row
+    assert shift_bytes % 128 == 0
+    flat = torch.zeros(Z * ld + shift, dtype=w.dtype, device=w.device)
+    buf = flat[shift:].view(Z, ld)
     buf[:, :N] = w.T
     linear.weight.data = buf[:, :N].T
 
@@ -95,7 +104,7 @@ def monkeypatch_layer(layer_idx: int, layer, sparsity, hist_path: Optional[str],
     ff.thresh_gate = thresholds["gate"]
     ff.sparsity_bin = 0
     to_column_major(ff.w1)
-    to_column_major(ff.w3)
+    to_column_major(ff.w3, shift_bytes=UP_SHIFT_BYTES)
     ff.gemv2_kernel = SparseGEMV.initialize("sparse_gemv", device)
     ff.gemv2 = ff.gemv2_kernel.operator(True)
     ff.thresh_down = thresholds["down"]
@@ -136,7 +145,7 @@ def _monkeypatch_layer_int8(layer, thresholds: Dict[str, float], device: str) ->
     attn.thresh_q, attn.thresh_k, attn.thresh_v, attn.thresh_o = (thresholds[k] for k in ("q", "k", "v", "o"))
     attn.sparsity_bin = 0
     for lin in (ff.w1, ff.w3, ff.w2, attn.wqkv, attn.wo):
-        to_column_major(lin)
+        to_column_major(lin, shift_bytes=UP_SHIFT_BYTES if lin is ff.w3 else 0)
     ff.int8 = attn.int8 = True
     ff.apply_monkeypatch()
     attn.apply_monkeypatch()
