@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--exp", type=int, default=0, help="teal_set_experiment mask")
     ap.add_argument("--splits", type=int, nargs="*", default=[4, 8, 16, 32])
+    ap.add_argument("--voff", type=int, default=0, help="shift every V cache this many bytes into its allocation (DRAM channel phase of K vs V)")
     ap.add_argument("--models", nargs="*", default=["7B", "8B", "70B"])
     ap.add_argument("--ctx", type=int, nargs="*", default=[1024, 4096, 16384])
     a = ap.parse_args()
@@ -31,7 +32,12 @@ def main():
             pos = S - 2
             nrot = max(2, min(16, int(600e6 // (n_kv * S * hd * 4)) + 1))
             kcs = [torch.randn(n_kv, S, hd, device="cuda").to(dt) for _ in range(nrot)]
-            vcs = [torch.randn(n_kv, S, hd, device="cuda").to(dt) for _ in range(nrot)]
+            vcs = []
+            for _ in range(nrot):
+                flat = torch.empty(n_kv * S * hd + a.voff // 2, device="cuda", dtype=dt)
+                v = flat[a.voff // 2:].view(n_kv, S, hd)
+                v.copy_(torch.randn(n_kv, S, hd, device="cuda").to(dt))
+                vcs.append(v)
             qkv = torch.randn((n_head + 2 * n_kv) * hd, device="cuda").to(dt)
             rope = precompute_freqs_cis(S, hd, 10000, dt).cuda().contiguous()
             y = torch.empty(n_head * hd, device="cuda", dtype=dt)
