@@ -22,12 +22,14 @@
  * Conventions
  *   - extern "C", plain pointers and sizes, no C++/torch types, no exceptions across the boundary.
  *   - All pointers are DEVICE pointers owned by the caller (PyTorch); the library borrows them for
- *     the duration of the stream-ordered launch and never allocates.  Process-global state: the device
- *     properties cached by teal_init() (immutable), two scratch buffers teal_init() allocates once (arrival counters
- *     of the single-launch split-K GEMV, 1 MB; candidate lists of the multi-workgroup sampler, 1 MB; launches take
- *     slots of them round-robin, 64 / 16 in flight), and the diagnostics / tuning switches of the last
- *     section (teal_set_tuning, teal_set_fast, teal_set_wave_local, teal_set_swizzle, teal_set_phase_*):
- *     host-side variables read at launch time, NOT thread-safe, meant for benchmarks and tests.
+ *     the duration of the stream-ordered launch and never allocates.  Library state: the properties of each device,
+ *     cached the first time it is used (teal_init(); immutable), a host-side registry of the workspaces prepared by
+ *     teal_workspace_init() (which device memory holds a valid header), and the diagnostics / tuning switches of the
+ *     last section (teal_set_tuning, teal_set_fast, teal_set_wave_local, teal_set_swizzle, teal_set_phase_*):
+ *     host-side variables read at launch time, NOT thread-safe, meant for benchmarks and tests.  No device memory
+ *     belongs to the library: the arrival counters of the single-launch split-K GEMVs and the scratch of the
+ *     multi-workgroup sampler live in the header of the CALLER's workspace, so two streams, two captured graphs or two
+ *     devices can only collide if the caller hands them the same workspace.
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Every call is
  *     asynchronous, allocation-free and hipGraph-capture safe.
  *   - dtype: 0 = fp16, 1 = bf16 (x, weights and y share it; int8 weights carry scales in that dtype).
@@ -68,15 +70,27 @@ extern "C" {
 int teal_version(void);
 const char* teal_strerror(int code);
 
-/* Cache immutable device properties (CU count).  Call once per process before any launch that
- * may happen during stream capture.  Returns the CU count (> 0) or a negative error. */
+/* Cache the immutable properties of the CURRENT device (CU count, per-kernel attributes).  Call once per device
+ * before any launch that may happen during stream capture (every entry point does it lazily otherwise).  Returns the
+ * CU count (> 0) or a negative error. */
 int teal_init(void);
 
-/* Bytes of fp32 split-K workspace a GEMV with N output columns may need: an upper bound over all launch
- * geometries (the deepest split x two N-column segments), which does not depend on Z — Z is accepted for
- * symmetry with the GEMV entry points.  The caller allocates once and reuses; distinct streams need distinct
- * workspaces. */
+/* Bytes of workspace a GEMV with N output columns may need: the library's header (arrival counters, sampler scratch)
+ * plus an upper bound of the fp32 split-K slabs over all launch geometries (the deepest split x two N-column
+ * segments).  Does not depend on Z — accepted for symmetry with the GEMV entry points.  The caller allocates once and
+ * reuses; distinct streams need distinct workspaces. */
 size_t teal_workspace_bytes(int Z, int N);
+
+/* Prepare a workspace: zero its header (asynchronously on `stream`) and remember the pointer.  Once per allocation,
+ * before the first launch that uses it and not under stream capture.  A prepared workspace lets a split-K GEMV with a
+ * rounded output run as ONE launch (per-tile arrival tickets; the last slice to arrive sums the partials in slice
+ * order) and a large-vocabulary sampler as several workgroups; every launch re-arms what it used, so a graph that was
+ * captured with the workspace can be replayed indefinitely.  An unprepared workspace (plain memory of
+ * teal_workspace_bytes) is still valid everywhere: the same results from GEMV + ordered reduce launch / a
+ * single-workgroup sampler.  If a launch is aborted (device reset), prepare again.  teal_workspace_release() forgets the
+ * pointer; call it before freeing the memory. */
+int teal_workspace_init(void* ws, size_t ws_bytes, void* stream);
+int teal_workspace_release(void* ws);
 
 /* idx_out[0..count) = ascending m with float32(|x[m]|) > float32(tau); *count_out = count.
  * idx_out must hold Z int32.  (kernels/sparse_gemv.py:75) */
@@ -181,7 +195,7 @@ typedef struct teal_gemv_out {
     float tau[3];        /* keep threshold of the segment */
     void* y[3];          /* ROUNDED: output of the segment [ncols] */
     int mode;            /* TEAL_OUT_* */
-    float* slabs;        /* SLABS: destination, fp32 [nslabs][sum ncols] */
+    float* slabs;        /* SLABS: destination, fp32 [nslabs][sum ncols]; plain memory, NOT a prepared workspace */
     size_t slabs_bytes;
     void* mask_out;      /* PAIR_SILU, optional: uint64 [ceil(ncols/64)] keep masks of h */
     float mask_tau;      /* PAIR_SILU: threshold of the consumer (the down projection) */
@@ -242,11 +256,15 @@ int teal_decode_attention_split_slabs(const float* qkv_slabs, int qkv_nslabs, co
  * top_k <= 0 or >= vocab disables the filter.  token_out = device int32[1] (may be the buffer the next
  * decode step reads its token from).  Optional in-graph loop-carried state, so that one graph replay
  * IS one decode step with no host-side glue: pos_inout[0] += 1; history[draw counter] = token.
- * Vocabularies of 8193..131072 entries (multiple of 8) with an active filter run as one workgroup per 8192 logits:
- * local top-k candidates -> library scratch (teal_init) -> the last workgroup to arrive picks the token; same tokens
- * as the single-workgroup kernels, which remain for the other shapes (teal_set_experiment bit 4 forces them). */
+ * teal_sample_topk_ws with a prepared workspace (teal_workspace_init): vocabularies of 8193..131072 entries (multiple
+ * of 8) with an active filter run as one workgroup per 8192 logits: local top-k candidates -> workspace header -> the
+ * last workgroup to arrive picks the token; same tokens as the single-workgroup kernels, which serve every other case
+ * (no / unprepared workspace, other shapes, teal_set_experiment bit 4). */
 int teal_sample_topk(const void* logits, int vocab, int dtype, int top_k, float temperature, void* rng_state,
                      int32_t* token_out, int32_t* pos_inout, int32_t* history, int history_len, void* stream);
+int teal_sample_topk_ws(const void* logits, int vocab, int dtype, int top_k, float temperature, void* rng_state,
+                        int32_t* token_out, int32_t* pos_inout, int32_t* history, int history_len, void* ws,
+                        size_t ws_bytes, void* stream);
 
 /* ---- tuning / introspection ------------------------------------------------------------------ */
 
@@ -280,13 +298,18 @@ int teal_set_fast(int on);
  * once the row stride is padded; a launch with the swizzle on uses the general kernel. */
 int teal_set_swizzle(int on);
 
-/* Diagnostics: when set (device pointer to >= 24 * workgroups uint64; the last 16 per workgroup receive each
- * wave's end-of-stream stamp), thread 0 of every GEMV
- * workgroup stores 100 MHz wall-clock stamps of its phases (0 start, 1 ballots, 2 scatter,
- * 3 list ready, 4 rows streamed, 5 done).  NULL (default) disables.  Process-global. */
+/* Diagnostics: when set (device pointer to >= 32 * workgroups uint64 — 32 stamps per workgroup of the launch), every
+ * GEMV workgroup stores 100 MHz wall-clock stamps of its phases, row w of the buffer = workgroup w:
+ *   [0] kernel entry, [1] kernel arguments in registers, [2] activation ready, [3] row list ready, [4] first weight
+ *   batch consumed (wave 0), [5] wave 0 done streaming, [6] past the reduce barrier, [7] done,
+ *   [12] hardware id << 32 | XCC id, [13] waves << 32 | workgroups, [16 + w] end of stream of wave w (w < 16).
+ * The attention and sampler launches stamp rows of the same width with their own phase meanings (scripts/attn_phase.py,
+ * scripts/sampler_phase.py).  NULL (default) disables.  Process-global. */
 int teal_set_phase_buffer(void* dev_u64);
-/* > 0: consecutive GEMV launches stamp consecutive regions of `u64_per_launch` uint64 of the phase buffer (so that a
- * chain of launches can be timed against each other); 0 (default): every launch stamps the start of the buffer. */
+/* > 0: consecutive GEMV / attention launches stamp consecutive regions of `u64_per_launch` uint64 of the phase buffer
+ * (so that a chain of launches can be timed against each other): u64_per_launch >= 32 * the largest launch's
+ * workgroups, and the buffer must hold u64_per_launch * (launches between two teal_set_phase_stride calls) uint64;
+ * 0 (default): every launch stamps the start of the buffer. */
 int teal_set_phase_stride(size_t u64_per_launch);
 
 /* The geometry a GEMV of this shape would use: out[0..5) = {lanes_per_row, waves, split, unroll,

@@ -180,6 +180,7 @@ int main(int argc, char** argv) {
     uint16_t* logits = (uint16_t*)allocz((size_t)S.vocab * 2);
     const size_t ws_bytes = teal_workspace_bytes(std::max(dim, inter), std::max(std::max(nqkv, inter), S.vocab));
     void* ws = allocz(ws_bytes);
+    TK(teal_workspace_init(ws, ws_bytes, st));  // header: arrival counters, sampler scratch (one workspace per stream)
     int32_t* tok = (int32_t*)allocz(4); int32_t* pos = (int32_t*)allocz(4); int32_t* hist = (int32_t*)allocz(4 * 65536);
     unsigned long long* rng = (unsigned long long*)allocz(16);
     { int32_t p = pos0, t = 3; CK(hipMemcpy(pos, &p, 4, hipMemcpyHostToDevice)); CK(hipMemcpy(tok, &t, 4, hipMemcpyHostToDevice));
@@ -359,7 +360,7 @@ int main(int argc, char** argv) {
             k_qkv(i, l.tq); k_attn(i, !fused_merge, l.to); k_wo(i, l.to); k_gu(i, l.tg, l.td); k_down(i, l.td);
         }
         k_head();
-        TK(teal_sample_topk(logits, S.vocab, dt, 200, 0.8f, rng, tok, pos, hist, 65536, st));
+        TK(teal_sample_topk_ws(logits, S.vocab, dt, 200, 0.8f, rng, tok, pos, hist, 65536, ws, ws_bytes, st));
     };
     auto capture = [&](auto&& fn) {
         hipGraph_t g; hipGraphExec_t ge;
@@ -430,8 +431,8 @@ int main(int argc, char** argv) {
         auto layers = [&]() { for (int i = 0; i < n_layer; ++i) { Layer& l = Ls[i]; k_qkv(i, l.tq); k_attn(i, !fused_merge, l.to); k_wo(i, l.to); k_gu(i, l.tg, l.td); k_down(i, l.td); } };
         hipGraphExec_t ga = capture([&]() { layers(); });
         hipGraphExec_t gb = capture([&]() { layers(); k_head(); });
-        hipGraphExec_t gc = capture([&]() { layers(); k_head(); TK(teal_sample_topk(logits, S.vocab, dt, 200, 0.8f, rng, tok, pos, hist, 65536, st)); });
-        hipGraphExec_t gd = capture([&]() { layers(); TK(teal_sample_topk(logits, S.vocab, dt, 200, 0.8f, rng, tok, pos, hist, 65536, st)); });
+        hipGraphExec_t gc = capture([&]() { layers(); k_head(); TK(teal_sample_topk_ws(logits, S.vocab, dt, 200, 0.8f, rng, tok, pos, hist, 65536, ws, ws_bytes, st)); });
+        hipGraphExec_t gd = capture([&]() { layers(); TK(teal_sample_topk_ws(logits, S.vocab, dt, 200, 0.8f, rng, tok, pos, hist, 65536, ws, ws_bytes, st)); });
         for (int r = 0; r < 3; ++r) {
             const double a = time_graph(ga, steps, true), b = time_graph(gb, steps, true), c = time_graph(gc, steps, true), d = time_graph(gd, steps, true);
             printf("  layers %.1f | + lm_head %.1f (+%.1f) | + lm_head + sampler %.1f (+%.1f) | layers + sampler only %.1f (+%.1f)\n", a, b, b - a, c, c - b, d, d - a);

@@ -13,6 +13,7 @@ from teal_amd import _lib, runtime  # noqa: E402
 
 L = _lib.load()
 runtime.init()
+WS = runtime.new_workspace(64, 64)  # prepared workspace: scratch of the multi-workgroup sampler
 names = ["load + keys + max", "window select", "race over kept", "final reduce"]
 for V, dt, code in ((32000, torch.float16, 0), (128256, torch.bfloat16, 1)):
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -26,7 +27,7 @@ for V, dt, code in ((32000, torch.float16, 0), (128256, torch.bfloat16, 1)):
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr, stream=st):
                 for lg in lgs:
-                    assert L.teal_sample_topk(lg.data_ptr(), V, code, 200, 0.8, state.data_ptr(), tok.data_ptr(), None, None, 0, st.cuda_stream) == 0
+                    assert L.teal_sample_topk_ws(lg.data_ptr(), V, code, 200, 0.8, state.data_ptr(), tok.data_ptr(), None, None, 0, WS.data_ptr(), WS.numel() * 4, st.cuda_stream) == 0
             gr.replay(); st.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)

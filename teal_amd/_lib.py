@@ -31,6 +31,7 @@ EXPORTS = (
     "teal_version", "teal_strerror", "teal_init", "teal_workspace_bytes", "teal_compact",
     "teal_sparse_gemv", "teal_sparse_qkv_gemv", "teal_dense_gemv", "teal_sparse_gateup_silu",
     "teal_set_tuning", "teal_get_config", "teal_set_phase_buffer", "teal_fused_gemv", "teal_decode_attention", "teal_sample_topk", "teal_set_swizzle", "teal_set_wave_local", "teal_sparse_qkv_gemv_ld", "teal_decode_attention_masked", "teal_decode_attention_split", "teal_sparse_qkv_gemv_i8", "teal_decode_attention_split_slabs", "teal_set_phase_stride", "teal_set_fast", "teal_last_launch_desc", "teal_sparse_qkv_gemv_i4", "teal_set_experiment",
+    "teal_workspace_init", "teal_workspace_release", "teal_sample_topk_ws",
 )
 
 _lib = None
@@ -113,6 +114,9 @@ def load() -> ctypes.CDLL:
     L.teal_set_phase_stride.argtypes = [sz]
     L.teal_fused_gemv.argtypes = [vp, vp, ci, ci, vp, sz, ctypes.POINTER(ci), vp]
     L.teal_sample_topk.argtypes = [vp, ci, ci, ci, cf, vp, vp, vp, vp, ci, vp]
+    L.teal_sample_topk_ws.argtypes = [vp, ci, ci, ci, cf, vp, vp, vp, vp, ci, vp, sz, vp]
+    L.teal_workspace_init.argtypes = [vp, sz, vp]
+    L.teal_workspace_release.argtypes = [vp]
     L.teal_set_swizzle.argtypes = [ci]
     L.teal_set_wave_local.argtypes = [ci]
     L.teal_set_fast.argtypes = [ci]

@@ -1362,18 +1362,17 @@ constexpr int kGqaMinSeq8 = 2048;           // cache length from which 8-heads-p
 constexpr int kGqaMinSeq = 4096;            // ... and 4-heads-per-KV-head models
 constexpr size_t kGqaMaxLds = 128 * 1024;   // ... if its scores fit this much LDS (mirrored by engine.py's split choice)
 
-static bool g_gqa_lds_ok = false;
-
-// teal_init(): one workgroup per CU, so the grouped-query kernel may take more than the default 64 KB of the CU's
-// 160 KB LDS (scores of a long share); opted in once here, outside any stream capture.
-void attention_init() {
+// First use of a device (device_ctx(), teal_kernels.hip): one workgroup per CU, so the grouped-query kernel may take more
+// than the default 64 KB of the CU's 160 KB LDS (scores of a long share); opted in once per device, outside any stream
+// capture.  Returns whether the opt-in succeeded.
+bool attention_device_init() {
     bool ok = true;
 #define TEAL_OPT(BF, HDV, REPV) ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_attention_gqa_kernel<BF, HDV, 512, REPV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGqaMaxLds) == hipSuccess
     TEAL_OPT(false, 128, 8); TEAL_OPT(false, 128, 4); TEAL_OPT(false, 64, 8); TEAL_OPT(false, 64, 4);
     TEAL_OPT(true, 128, 8); TEAL_OPT(true, 128, 4); TEAL_OPT(true, 64, 8); TEAL_OPT(true, 64, 4);
 #undef TEAL_OPT
     if (!ok) (void)hipGetLastError();
-    g_gqa_lds_ok = ok;
+    return ok;
 }
 
 }  // namespace teal
@@ -1422,6 +1421,8 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
         nsplit < 1 || nsplit > 64)
         return TEAL_ERR_SHAPE;
     if (partials_bytes < (size_t)n_head * nsplit * (head_dim + 2) * sizeof(float)) return TEAL_ERR_WORKSPACE;
+    DeviceCtx* dctx = device_ctx();  // per-device kernel attributes (not under capture the first time: teal_init())
+    if (!dctx) return TEAL_ERR_NO_DEVICE;
     const int chunk_max = (max_seq + nsplit - 1) / nsplit;
     // bandwidth of one workgroup = bytes in flight / latency: long shares get 16 waves, short ones 4 waves (cheaper
     // barriers).  Rows are dealt to the workgroups of a head in groups of STEP = waves x rows-per-wave, round-robin.
@@ -1450,7 +1451,7 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
         const int glocal = (((max_seq + gstep - 1) / gstep + nsplit - 1) / nsplit) * gstep;  // rows a workgroup may own
         const size_t region = (size_t)rep * (glocal > GNW * head_dim ? glocal : GNW * head_dim);
         const size_t glds = ((size_t)(rep + 2) * (head_dim / 2) + 2 * rep * GNW + region) * sizeof(float);
-        if (glds > (g_gqa_lds_ok ? kGqaMaxLds : 64 * 1024)) gqa = false;
+        if (glds > (dctx->gqa_lds_ok ? kGqaMaxLds : 64 * 1024)) gqa = false;
         else {
             const dim3 ggrid(n_kv_head * nsplit), gblock(GNT);
 #define TEAL_ATTG(BF, HDV, REPV) hipLaunchKernelGGL((decode_attention_gqa_kernel<BF, HDV, GNT, REPV>), ggrid, gblock, glds, st, pos, qkv_slabs, kc, vc, q, pw, r, n_head, n_kv_head, max_seq, nsplit, scale, qkv_nslabs, glocal)
@@ -1506,6 +1507,13 @@ int teal_decode_attention(const void* qkv, const void* rope, const int32_t* pos,
 
 int teal_sample_topk(const void* logits, int vocab, int dtype, int top_k, float temperature, void* rng_state,
                      int32_t* token_out, int32_t* pos_inout, int32_t* history, int history_len, void* stream) {
+    return teal_sample_topk_ws(logits, vocab, dtype, top_k, temperature, rng_state, token_out, pos_inout, history, history_len,
+                               nullptr, 0, stream);
+}
+
+int teal_sample_topk_ws(const void* logits, int vocab, int dtype, int top_k, float temperature, void* rng_state,
+                        int32_t* token_out, int32_t* pos_inout, int32_t* history, int history_len, void* ws, size_t ws_bytes,
+                        void* stream) {
     if (!logits || !rng_state || !token_out || vocab <= 0) return TEAL_ERR_ARG;
     if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
     if (!aligned16(logits)) return TEAL_ERR_ALIGN;
@@ -1516,9 +1524,9 @@ int teal_sample_topk(const void* logits, int vocab, int dtype, int top_k, float 
 #define TEAL_SAMPLE(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len)
 #define TEAL_SAMPLE_W(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len, g_phase_stride ? nullptr : g_phase)
     const bool bf = dtype == TEAL_BF16;
-    if ((vocab & 7) == 0 && vocab > 8192 && vocab <= kSampMaxGroups * 8192 && top_k > 0 && top_k < vocab && g_sampler_ws && !(g_exp & 16)) {
+    if ((vocab & 7) == 0 && vocab > 8192 && vocab <= kSampMaxGroups * 8192 && top_k > 0 && top_k < vocab && ws_prepared(ws, ws_bytes) && !(g_exp & 16)) {
         // one workgroup per 8192 logits + the last arriver (sample_topk_multi_kernel)
-        unsigned char* slot = g_sampler_ws + (size_t)(g_sampler_seq++ % kSampSlots) * kSampSlotBytes;
+        unsigned char* slot = ws_sampler(ws);  // scratch of the caller's prepared workspace (one per stream)
         const dim3 grid((vocab / 8 + 1023) / 1024), block(1024);
         if (bf) hipLaunchKernelGGL((sample_topk_multi_kernel<true>), grid, block, 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len, slot);
         else hipLaunchKernelGGL((sample_topk_multi_kernel<false>), grid, block, 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len, slot);

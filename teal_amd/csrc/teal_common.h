@@ -71,6 +71,7 @@ struct Params {
     unsigned long long* mask_out;  // pair: keep masks of the output vs mask_tau for the next launch (or null)
     float mask_tau;
     unsigned long long* phase;  // optional: per-workgroup phase timestamps (teal_set_phase_buffer)
+    unsigned* tickets;          // host side: arrival counters of the caller's prepared workspace (or null)
     Seg seg[kMaxSeg];
 };
 
@@ -79,8 +80,20 @@ struct Config {
     int lpr, waves, split, unroll;
 };
 
-// process-global tuning state (teal_kernels.hip)
-extern int g_num_cu;
+// Per-device immutable properties, cached the first time a device is used (teal_init() on that device; every entry
+// point does it lazily, which must not first happen under stream capture).  Indexed by the HIP device ordinal.
+struct DeviceCtx {
+    int num_cu;       // 0: not initialised yet
+    bool gqa_lds_ok;  // the grouped-query attention kernel may take kGqaMaxLds of LDS on this device
+};
+DeviceCtx* device_ctx();                   // context of the CURRENT device (nullptr: no device)
+inline int num_cu_or(int dflt) {           // CU count of the current device, or dflt without a device (host-only queries)
+    DeviceCtx* c = device_ctx();
+    return c && c->num_cu > 0 ? c->num_cu : dflt;
+}
+bool attention_device_init();              // teal_attention.hip: per-kernel attributes of the current device
+
+// process-global diagnostics / tuning switches (teal_kernels.hip): host-side variables read at launch time
 extern Config g_override;
 extern unsigned long long* g_phase;
 extern size_t g_phase_stride;
@@ -88,15 +101,24 @@ extern int g_phase_seq;
 extern int g_swizzle;
 extern int g_wave_local;
 extern int g_exp;
-// scratch of the multi-workgroup sampler (teal_attention.hip): kSampSlots x kSampSlotBytes, allocated and zeroed by
-// teal_init(); a launch takes the next slot (candidates of up to 16 chunks x 512, their counts, the arrival ticket)
+
+// ---- caller-owned workspace --------------------------------------------------------------------------------------
+// A workspace prepared by teal_workspace_init() starts with a header the library owns (zeroed once by that call, re-armed
+// by every launch that uses it): the per-tile arrival counters of the single-launch split-K GEMVs and the scratch of the
+// multi-workgroup sampler.  The fp32 split-K slabs follow.  One workspace per stream, so two streams / graphs / devices
+// can never share a counter; an unprepared workspace (plain memory) still works — split-K GEMVs then run as GEMV +
+// ordered reduce launch and the sampler as a single workgroup.
 constexpr int kSampCap = 512;      // candidates a chunk of 8192 logits may contribute
 constexpr int kSampMaxGroups = 16;
-constexpr int kSampSlots = 16;
-constexpr size_t kSampSlotBytes = (size_t)kSampMaxGroups * kSampCap * 8 + 256;
-void attention_init();  // teal_attention.hip: per-kernel attributes, from teal_init()
-extern unsigned char* g_sampler_ws;
-extern unsigned g_sampler_seq;
+constexpr size_t kSampSlotBytes = (size_t)kSampMaxGroups * kSampCap * 8 + 256;  // candidates, counts, ticket
+constexpr int kTicketTiles = 4096;                                              // column tiles a ticketed launch may have
+constexpr size_t kWsTicketBytes = (size_t)kTicketTiles * sizeof(unsigned);
+constexpr size_t kWsSamplerOff = kWsTicketBytes;
+constexpr size_t kWsHeaderBytes = (kWsTicketBytes + kSampSlotBytes + 255) & ~(size_t)255;
+bool ws_prepared(const void* ws, size_t ws_bytes);  // registered by teal_workspace_init with at least the header
+inline unsigned* ws_tickets(void* ws) { return reinterpret_cast<unsigned*>(ws); }
+inline unsigned char* ws_sampler(void* ws) { return reinterpret_cast<unsigned char*>(ws) + kWsSamplerOff; }
+inline float* ws_slabs(void* ws) { return reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ws) + kWsHeaderBytes); }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -22,8 +22,6 @@
 
 namespace teal {
 
-extern unsigned* g_tickets;
-extern unsigned g_ticket_seq;
 
 struct Int4Args {
     const uint16_t* x;
@@ -157,9 +155,10 @@ extern "C" int teal_sparse_qkv_gemv_i4(const void* x, const void* wq, const void
     if ((N % 128) || (Z % groupsize) || Z > 65536 || ldb < N / 2 || (ldb & 3)) return TEAL_ERR_SHAPE;
     if (N_q <= 0 || N_kv < 0 || N_q + 2 * N_kv != N || (N_q % 128) || (N_kv % 128)) return TEAL_ERR_SHAPE;
     if (!aligned16(scales_and_zeros) || (reinterpret_cast<uintptr_t>(wq) & 3u)) return TEAL_ERR_ALIGN;
-    if (g_num_cu <= 0 && teal_init() <= 0) return TEAL_ERR_NO_DEVICE;
+    DeviceCtx* dc = device_ctx();
+    if (!dc) return TEAL_ERR_NO_DEVICE;
     const int ntiles = N / 128, ngroups = Z / groupsize;
-    int split = g_num_cu / ntiles;
+    int split = dc->num_cu / ntiles;
     if (split > 8) split = 8;
     if (split * 16 > ngroups) split = ngroups / 16;  // every wave of every slice owns at least one group
     if (split < 1) split = 1;
@@ -173,13 +172,15 @@ extern "C" int teal_sparse_qkv_gemv_i4(const void* x, const void* wq, const void
     a.seg_tile1 = N_kv > 0 ? N_q / 128 : INT_MAX;
     a.seg_tile2 = N_kv > 0 ? (N_q + N_kv) / 128 : INT_MAX;
     if (split > 1) {
-        if (!g_tickets || ntiles > 4096) split = 1;
+        // split-K over the groups needs the arrival counters of a prepared workspace (teal_workspace_init); without one
+        // the launch keeps every group of a tile in one workgroup
+        if (!ws_prepared(ws, ws_bytes) || ntiles > kTicketTiles) split = 1;
         else {
             a.ws_stride = (split + 3) & ~3;
-            if (!ws || ws_bytes < (size_t)a.ws_stride * N * sizeof(float)) return TEAL_ERR_WORKSPACE;
+            if (ws_bytes - kWsHeaderBytes < (size_t)a.ws_stride * N * sizeof(float)) return TEAL_ERR_WORKSPACE;
             if (!aligned16(ws)) return TEAL_ERR_ALIGN;
-            a.ws = reinterpret_cast<float*>(ws);
-            a.ticket = g_tickets + (size_t)(g_ticket_seq++ % 64) * 4096;
+            a.ws = ws_slabs(ws);
+            a.ticket = ws_tickets(ws);
         }
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -16,6 +16,9 @@
 #include <limits.h>
 #include <stdio.h>
 
+#include <mutex>
+#include <vector>
+
 namespace teal {
 
 // ------------------------------------------------------------------------------------------------
@@ -121,7 +124,6 @@ __global__ __launch_bounds__(1024) void compact_kernel(const uint16_t* __restric
 // ------------------------------------------------------------------------------------------------
 
 
-int g_num_cu = 0;
 Config g_override = {0, 0, 0, 0};
 unsigned long long* g_phase = nullptr;
 size_t g_phase_stride = 0;  // > 0: consecutive GEMV launches stamp consecutive regions of this many uint64
@@ -130,11 +132,43 @@ int g_swizzle = 0;
 int g_wave_local = 1;
 int g_fast = 1;  // lean kernel (teal_gemv_fast.h) where the shape qualifies
 int g_exp = 0;   // experiment switches handed to the lean kernel (teal_set_experiment)
-unsigned* g_tickets = nullptr;  // kTicketSlots x kTicketTiles arrival counters (zeroed once; every launch re-arms its own)
-unsigned g_ticket_seq = 0;
-unsigned char* g_sampler_ws = nullptr;
-unsigned g_sampler_seq = 0;
-constexpr int kTicketSlots = 64, kTicketTiles = 4096;
+
+// ---- per-device properties (immutable once cached) ---------------------------------------------------------------
+constexpr int kMaxDevices = 64;
+static DeviceCtx g_dev[kMaxDevices] = {};
+static std::mutex g_dev_mu;
+
+DeviceCtx* device_ctx() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (dev < 0 || dev >= kMaxDevices) return nullptr;
+    DeviceCtx* c = &g_dev[dev];
+    if (c->num_cu > 0) return c;
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if (c->num_cu > 0) return c;
+    int cu = 0;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    c->gqa_lds_ok = attention_device_init();
+    c->num_cu = cu;
+    return c;
+}
+
+// ---- prepared workspaces (teal_workspace_init): host-side registry, keyed by the device pointer -------------------
+struct WsEntry { const void* ws; size_t bytes; };
+static std::vector<WsEntry> g_ws_reg;
+static std::mutex g_ws_mu;
+
+bool ws_prepared(const void* ws, size_t ws_bytes) {
+    if (!ws || ws_bytes < kWsHeaderBytes) return false;
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    for (const WsEntry& e : g_ws_reg)
+        if (e.ws == ws) return true;
+    return false;
+}
+
 char g_last_desc[160] = "";  // template instantiation + grid of the most recent GEMV launch (teal_last_launch_desc)
 
 
@@ -155,7 +189,7 @@ int count_tiles(const Params& p, int bn) {
 // a single launch (split == 1) whenever the column tiles alone can occupy >= ~60 % of the CUs.
 Config pick_config(int Z, int ncols_total, int nseg_tiles_hint) {
     (void)nseg_tiles_hint;
-    const int ncu = g_num_cu > 0 ? g_num_cu : 256;
+    const int ncu = num_cu_or(256);
     Config c;
     c.waves = g_override.waves ? g_override.waves : 16;
     c.unroll = 4;
@@ -219,7 +253,7 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
     // launch by arrival tickets (the last slice of a tile sums the partials in slice order)
     const bool ticketed = !to_ws && c.split > 1;
     if (to_ws ? (!p.ws_il || c.split > 8) : (c.split > 8)) return false;
-    if (ticketed && (!g_tickets || p.ntiles > kTicketTiles || !p.ws ||
+    if (ticketed && (!p.tickets || p.ntiles > kTicketTiles || !p.ws ||
                      ws_bytes < (size_t)((c.split + 3) & ~3) * (size_t)p.ws_ld * sizeof(float)))
         return false;
     const int nseg = p.pair ? 2 : p.nseg;
@@ -275,7 +309,7 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
     f.a.seg_tile2 = (!p.pair && p.nseg > 2) ? p.seg[2].tile0 : INT_MAX;
     f.a.exp = g_exp;
     f.a.ws_stride = (to_ws || ticketed) ? ((c.split + 3) & ~3) : 0;
-    f.a.ticket = ticketed ? g_tickets + (size_t)(g_ticket_seq++ % kTicketSlots) * kTicketTiles : nullptr;
+    f.a.ticket = ticketed ? p.tickets : nullptr;
     return true;
 }
 
@@ -288,7 +322,15 @@ inline hipError_t launch_gemv(const Params& p, int dtype, size_t lds, const Conf
 // Common driver: fills geometry fields of `p` (segments' w/y/tau/ld/col0/ncols are set by the
 // caller), launches the GEMV and, if needed, the ordered slab reduce.
 int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStream_t st,
-             Config* used, bool few_slabs = false, bool interleave = false) {
+             Config* used, bool few_slabs = false, bool interleave = false, bool caller_ws = true) {
+    // caller_ws: `ws` is the caller's workspace (as opposed to an explicit slab destination, TEAL_OUT_SLABS).  A workspace
+    // prepared by teal_workspace_init() starts with the header that holds the arrival counters: slabs go behind it.
+    p.tickets = nullptr;
+    if (caller_ws && ws_prepared(ws, ws_bytes)) {
+        p.tickets = ws_tickets(ws);
+        ws = ws_slabs(ws);
+        ws_bytes -= kWsHeaderBytes;
+    }
     int total_cols = 0;
     for (int i = 0; i < p.nseg; ++i) total_cols += p.seg[i].ncols;
     Config c = pick_config(p.Z, total_cols, p.nseg);
@@ -299,7 +341,7 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
         // rows sliced so that tiles x slices ~ the CU count — fewer, longer row requests per CU.  Measured +2-8 % on
         // those launches; on 7B / 8B matrices the extra slices cost more in the consumers' prologues than they save
         // (7B: 529 -> 518 tok/s), hence the size gate.
-        const int ncu = g_num_cu > 0 ? g_num_cu : 256;
+        const int ncu = num_cu_or(256);
         const int tiles = (total_cols + 127) / 128;
         const int rounds = (((p.Z + 63) >> 6) + c.waves - 1) / c.waves;
         int split = ncu / tiles;
@@ -315,7 +357,7 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
     if (!wide_sliced && few_slabs && c.split > 1 && !g_override.split && !g_override.lpr) {
         // the consumer re-reads every slab in each of its workgroups: prefer narrow tiles and a
         // shallow split (64-column tiles, <= 8 slabs) over 512-byte row segments
-        const int ncu = g_num_cu > 0 ? g_num_cu : 256;
+        const int ncu = num_cu_or(256);
         c.lpr = 8;
         const int tiles = (total_cols + 63) / 64;
         int split = ncu / tiles;
@@ -333,7 +375,7 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
         // line = 16 lanes = 128 columns, as long as tiles x slices still cover most of the CUs
         if (c.lpr > 32) c.lpr = 32;
         if (!g_override.lpr && !g_override.split && !p.pair && c.lpr < 16) {
-            const int ncu = g_num_cu > 0 ? g_num_cu : 256;
+            const int ncu = num_cu_or(256);
             const int tiles = (total_cols + 127) / 128;
             const int rounds = (((p.Z + 63) >> 6) + 15) / 16;
             int split = 1;
@@ -360,7 +402,7 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
         c.split = 1;
         if ((size_t)(p.Z + 1) * 4 > 44 * 1024) return TEAL_ERR_SHAPE;
         if (!g_override.lpr) {
-            const int ncu = g_num_cu > 0 ? g_num_cu : 256;
+            const int ncu = num_cu_or(256);
             const int n1 = p.seg[0].ncols;
             c.lpr = 8;
             for (int lpr = 64; lpr > 8; lpr >>= 1)  // widest tile that still gives >= 2/3 of the CUs a tile
@@ -454,7 +496,7 @@ int check_common(const void* x, const void* w, const void* y, int Z, int N, int 
     if ((N & 7) != 0 || Z > 65536) return TEAL_ERR_SHAPE;
     if (!aligned16(w) || (reinterpret_cast<uintptr_t>(x) & 1u) || (reinterpret_cast<uintptr_t>(y) & 1u))
         return TEAL_ERR_ALIGN;
-    if (g_num_cu <= 0 && teal_init() <= 0) return TEAL_ERR_NO_DEVICE;
+    if (!device_ctx()) return TEAL_ERR_NO_DEVICE;
     return TEAL_OK;
 }
 
@@ -484,38 +526,38 @@ const char* teal_strerror(int code) {
 }
 
 int teal_init(void) {
-    if (g_num_cu > 0) return g_num_cu;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return TEAL_ERR_NO_DEVICE;
-    int cu = 0;
-    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
-        return TEAL_ERR_NO_DEVICE;
-    g_num_cu = cu;
-    // arrival counters of the single-launch split-K GEMV: the one allocation this library makes, once, here (so not
-    // under stream capture — see the header); without it split-K GEMVs fall back to the two-launch form
-    if (!g_tickets) {
-        if (hipMalloc(&g_tickets, (size_t)kTicketSlots * kTicketTiles * sizeof(unsigned)) != hipSuccess ||
-            hipMemset(g_tickets, 0, (size_t)kTicketSlots * kTicketTiles * sizeof(unsigned)) != hipSuccess) {
-            g_tickets = nullptr;
-            (void)hipGetLastError();
-        }
-    }
-    attention_init();
-    if (!g_sampler_ws) {  // multi-workgroup sampler scratch (1 MB); without it the single-workgroup sampler runs
-        if (hipMalloc(&g_sampler_ws, (size_t)kSampSlots * kSampSlotBytes) != hipSuccess ||
-            hipMemset(g_sampler_ws, 0, (size_t)kSampSlots * kSampSlotBytes) != hipSuccess) {
-            g_sampler_ws = nullptr;
-            (void)hipGetLastError();
-        }
-    }
-    return cu;
+    DeviceCtx* c = device_ctx();
+    return c ? c->num_cu : TEAL_ERR_NO_DEVICE;
 }
 
 size_t teal_workspace_bytes(int Z, int N) {
     (void)Z;
     if (N <= 0) return 0;
-    // kMaxSplit slabs of N columns; the fused gate|up GEMV uses two segments of N columns
-    return (size_t)kMaxSplit * (size_t)N * 2 * sizeof(float);
+    // the library's header (arrival counters, sampler scratch) + kMaxSplit slabs of N columns; the fused gate|up GEMV
+    // uses two segments of N columns
+    return kWsHeaderBytes + (size_t)kMaxSplit * (size_t)N * 2 * sizeof(float);
+}
+
+int teal_workspace_init(void* ws, size_t ws_bytes, void* stream) {
+    if (!ws || ws_bytes < kWsHeaderBytes) return TEAL_ERR_WORKSPACE;
+    if (!aligned16(ws)) return TEAL_ERR_ALIGN;
+    if (!device_ctx()) return TEAL_ERR_NO_DEVICE;
+    if (hipMemsetAsync(ws, 0, kWsHeaderBytes, reinterpret_cast<hipStream_t>(stream)) != hipSuccess) {
+        (void)hipGetLastError();
+        return TEAL_ERR_LAUNCH;
+    }
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    for (WsEntry& e : g_ws_reg)
+        if (e.ws == ws) { e.bytes = ws_bytes; return TEAL_OK; }
+    g_ws_reg.push_back({ws, ws_bytes});
+    return TEAL_OK;
+}
+
+int teal_workspace_release(void* ws) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    for (size_t i = 0; i < g_ws_reg.size(); ++i)
+        if (g_ws_reg[i].ws == ws) { g_ws_reg.erase(g_ws_reg.begin() + i); return TEAL_OK; }
+    return TEAL_ERR_ARG;
 }
 
 int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll) {
@@ -694,7 +736,7 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
     if (!in || !out || Z <= 0 || out->nseg < 1 || out->nseg > kMaxSeg) return TEAL_ERR_ARG;
     if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
     if (Z > 65536) return TEAL_ERR_SHAPE;
-    if (g_num_cu <= 0 && teal_init() <= 0) return TEAL_ERR_NO_DEVICE;
+    if (!device_ctx()) return TEAL_ERR_NO_DEVICE;
     Params p = {};
     p.Z = Z;
     p.in.mode = in->mode;
@@ -762,7 +804,8 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
         rc = run_gemv(p, dtype, ws, ws_bytes, false, st, &used, false);
     } else if (out->mode == TEAL_OUT_SLABS) {
         if (!out->slabs) return TEAL_ERR_ARG;
-        rc = run_gemv(p, dtype, out->slabs, out->slabs_bytes, true, st, &used, true, out->slabs_interleaved != 0);
+        if (ws_prepared(out->slabs, out->slabs_bytes)) return TEAL_ERR_ARG;  // a prepared workspace starts with the library's header
+        rc = run_gemv(p, dtype, out->slabs, out->slabs_bytes, true, st, &used, true, out->slabs_interleaved != 0, false);
         if (rc == TEAL_OK && out->slabs_interleaved && !p.ws_il) return TEAL_ERR_CONFIG;  // > 8 slices cannot interleave
     } else if (out->mode == TEAL_OUT_ROUNDED) {
         rc = run_gemv(p, dtype, ws, ws_bytes, false, st, &used, false);

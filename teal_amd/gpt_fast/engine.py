@@ -76,8 +76,45 @@ class DecodeEngine:
     (`setup_caches`) are shared: prefill runs through the module path, decode through the engine.
     """
 
+    @staticmethod
+    def supports(model: Transformer) -> Optional[str]:
+        """None if the fused step can run `model` as it stands, else the reason it cannot (the caller then keeps the
+        op-by-op module path, which handles every shape torch does).  Mirrors the shape contracts of the launches:
+        teal_decode_attention* (head_dim 64 / 128, [1][n_kv][max_seq][hd] caches), the register-resident RMSNorm
+        producer (dim <= 16384), 16-byte rows (multiples of 8 columns), Z <= 65536, one weight format for all linears."""
+        cfg = model.config
+        lins = [lin for layer in model.layers for lin in (layer.attention.wqkv, layer.attention.wo, layer.feed_forward.w1,
+                                                         layer.feed_forward.w3, layer.feed_forward.w2)] + [model.output]
+        if any(hasattr(lin, "scales_and_zeros") for lin in lins):
+            return "int4 group-quantised linears run op by op"
+        i8 = [lin.weight.dtype == torch.int8 for lin in lins]
+        if any(i8) and not all(i8):
+            return "mixed int8 / 16-bit linears"
+        dt = model.output.scales.dtype if all(i8) else model.output.weight.dtype
+        if dt not in (torch.float16, torch.bfloat16) or any((not b) and lin.weight.dtype != dt for b, lin in zip(i8, lins)):
+            return f"weights are not uniformly fp16 / bf16 (or int8 with such scales): {dt}"
+        if cfg.head_dim not in (64, 128):
+            return f"head_dim {cfg.head_dim} (the attention launches are built for 64 and 128)"
+        kv = cfg.n_local_heads * cfg.head_dim
+        if cfg.dim % 64 or cfg.dim > 16384 or cfg.dim != cfg.n_head * cfg.head_dim:
+            return f"dim {cfg.dim} (need a multiple of 64, <= 16384, = n_head * head_dim)"
+        if cfg.intermediate_size % 8 or cfg.intermediate_size > 65536 or kv % 8 or cfg.vocab_size % 8:
+            return "intermediate_size / kv width / vocab_size must be multiples of 8 (intermediate_size <= 65536)"
+        if model.freqs_cis is None or model.freqs_cis.dtype != dt:
+            return "caches are not set up (model.setup_caches) in the model dtype"
+        for layer in model.layers:
+            kc = getattr(layer.attention, "kv_cache", None)
+            if kc is None or kc.k_cache.shape[0] != 1 or not kc.k_cache.is_contiguous() or not kc.v_cache.is_contiguous():
+                return "KV caches must be contiguous with max_batch_size == 1"
+        if not model.output.weight.is_cuda:
+            return "model is not on a HIP device"
+        return None
+
     def __init__(self, model: Transformer, thresholds: List[Dict[str, float]], pair: Optional[bool] = None,
                  att_split: int = 0):
+        why = DecodeEngine.supports(model)
+        if why is not None:
+            raise ValueError(f"DecodeEngine cannot run this model: {why}")
         self.L = _lib.load()
         runtime.init()
         cfg = model.config
@@ -112,7 +149,7 @@ class DecodeEngine:
         self.s_wo, self.s_down = e(MAX_SLABS, dim, dtype=torch.float32), e(MAX_SLABS, dim, dtype=torch.float32)
         self.s_qkv = e(8, self.nqkv, dtype=torch.float32)  # wqkv split-K slabs, summed by the attention launch
         self.logits = e(1, 1, cfg.vocab_size)
-        self.ws = runtime.reserve_workspace(max(dim, inter), max(self.nqkv, inter, cfg.vocab_size))
+        self.ws = runtime.new_workspace(max(dim, inter), max(self.nqkv, inter, cfg.vocab_size))  # own header: own tickets
         self.rope = model.freqs_cis.contiguous()
         assert self.rope.dtype == dt and self.rope.shape[1:] == (hd // 2, 2)
         self.max_seq = model.max_seq_length
@@ -407,10 +444,11 @@ class DecodeEngine:
         feed=True also carries the loop state on the device: the token goes into the buffer the next
         step reads, the position is advanced and the token is appended to `history`."""
         tok_out = self.tok_buf if feed else self.token
-        rc = self.L.teal_sample_topk(logits.data_ptr(), self.cfg.vocab_size, self.code, int(top_k or 0), float(temperature),
-                                     self.rng_state.data_ptr(), tok_out.data_ptr(),
-                                     self.pos_buf.data_ptr() if feed else None,
-                                     self.history.data_ptr() if feed else None, self.history.numel(), runtime.stream_ptr())
+        rc = self.L.teal_sample_topk_ws(logits.data_ptr(), self.cfg.vocab_size, self.code, int(top_k or 0), float(temperature),
+                                        self.rng_state.data_ptr(), tok_out.data_ptr(),
+                                        self.pos_buf.data_ptr() if feed else None,
+                                        self.history.data_ptr() if feed else None, self.history.numel(),
+                                        self.ws.data_ptr(), self.ws.numel() * 4, runtime.stream_ptr())
         if rc != 0:
             _lib.check(rc, "teal_sample_topk")
         return tok_out

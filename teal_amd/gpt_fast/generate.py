@@ -163,6 +163,9 @@ def refine_thresholds_on_decode(model: Transformer, sparsities: Dict[str, List[f
         return ths
     model.max_seq_length, model.max_batch_size = -1, -1
     model.setup_caches(max_batch_size=1, max_seq_length=n_prompt + span + 8)
+    if DecodeEngine.supports(model) is not None:  # e.g. head_dim 48: the module path decodes it, with the prefill thresholds
+        model.max_seq_length, model.max_batch_size = -1, -1
+        return ths
     toks = torch.randint(0, model.config.vocab_size, (n_prompt,), device=dev, dtype=torch.int,
                          generator=torch.Generator(device=dev).manual_seed(97))
     model(toks.view(1, -1), torch.arange(n_prompt, device=dev))

@@ -285,12 +285,19 @@ class Transformer(nn.Module):
                                                  layer.ffn_norm.weight.data_ptr()))
 
     def _fused_engine(self):
+        """The fused engine for this model's current weights / caches / thresholds, or None when the model is not fully
+        patched or DecodeEngine.supports() names a reason (head_dim 48, batched caches, mixed int8 / 16-bit, ...): the
+        caller then runs the op-by-op module path, as before the engine existed.  The verdict is cached per key."""
         ths = self._patched_thresholds()
         if ths is None:
             return None
-        if getattr(self, "_eng_key", None) != self._engine_key(ths):
+        key = self._engine_key(ths)
+        if getattr(self, "_eng_key", None) != key:
             from .engine import DecodeEngine
-            object.__setattr__(self, "_eng", DecodeEngine(self, ths))  # not a submodule: it only borrows this model
+            why = DecodeEngine.supports(self)
+            object.__setattr__(self, "_eng_why", why)
+            # not a submodule: the engine only borrows this model
+            object.__setattr__(self, "_eng", None if why is not None else DecodeEngine(self, ths))
             self._eng_key = self._engine_key(ths)  # after the build: the engine re-lays lm_head out column-major
         return self._eng
 
@@ -300,7 +307,8 @@ class Transformer(nn.Module):
                 and not torch.is_grad_enabled() and self.output.weight.dtype in (torch.float16, torch.bfloat16, torch.int8)):
             eng = self._fused_engine()
             if eng is not None:
-                return eng(idx.view(1, 1).to(torch.int32), input_pos.view(1).to(torch.int32))
+                # a fresh tensor like the op-by-op path returns (the engine's logits buffer is overwritten by the next step)
+                return eng(idx.view(1, 1).to(torch.int32), input_pos.view(1).to(torch.int32)).clone()
         mask = self.causal_mask[None, None, input_pos]
         freqs_cis = self.freqs_cis[input_pos]
         x = self.tok_embeddings(idx)

@@ -1,9 +1,10 @@
 """Device-side plumbing shared by the ops: dtype codes, current stream, split-K workspace.
 
 PyTorch owns every buffer; the C ABI only borrows raw pointers for a stream-ordered launch
-(SURVEY §8(b) "Ownership").  The fp32 split-K workspace is one persistent tensor per device,
-allocated outside graph capture (the warm-up call every capture needs), so captured graphs
-see a static address.
+(SURVEY §8(b) "Ownership").  The workspace (fp32 split-K slabs behind the library's header of arrival
+counters and sampler scratch, teal_workspace_init) is one persistent tensor per (device, stream),
+allocated and prepared outside graph capture (the warm-up call every capture needs), so captured
+graphs see a static address and two streams never share a counter.
 """
 from __future__ import annotations
 
@@ -13,8 +14,8 @@ from . import _lib
 
 F16, BF16 = 0, 1
 _DTYPE_CODE = {torch.float16: F16, torch.bfloat16: BF16}
-_workspaces: dict[int, torch.Tensor] = {}
-_inited = False
+_workspaces: dict[tuple[int, int], torch.Tensor] = {}
+_inited: set[int] = set()
 
 
 def dtype_code(dt: torch.dtype) -> int:
@@ -25,15 +26,14 @@ def dtype_code(dt: torch.dtype) -> int:
 
 
 def init() -> int:
-    """Cache device properties inside the library (must not first happen during capture)."""
-    global _inited
+    """Cache the current device's properties inside the library (must not first happen during capture)."""
     L = _lib.load()
     if not torch.cuda.is_available():
         raise RuntimeError("teal_amd: no HIP device visible to PyTorch; the sparse GEMV path has no CPU fallback")
     cu = L.teal_init()
     if cu <= 0:
         _lib.check(cu, "teal_init")
-    _inited = True
+    _inited.add(torch.cuda.current_device())
     return cu
 
 
@@ -41,21 +41,52 @@ def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _prepared(idx: int, nbytes: int) -> torch.Tensor:
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=torch.device("cuda", idx))
+    _lib.check(_lib.load().teal_workspace_init(ws.data_ptr(), ws.numel() * 4, stream_ptr()), "teal_workspace_init")
+    return ws
+
+
 def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    """Persistent fp32 split-K scratch for `device`, grown on demand (never during capture)."""
-    if not _inited:
-        init()
+    """Persistent prepared workspace for ops launched on the current stream of `device`, grown on demand.
+
+    Eager launches key on (device, stream), so two streams never share slabs or arrival counters.  A stream capture
+    cannot allocate, and torch.cuda.graph captures on a stream of its own, so captures use the device's capture
+    workspace, which is created (same size) whenever an eager one is: run one warm-up call before capturing, and
+    replay graphs captured through the ops one at a time (a DecodeEngine owns its workspace instead)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    ws = _workspaces.get(idx)
+    if idx not in _inited:
+        with torch.cuda.device(idx):
+            init()
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (idx, -1 if capturing else stream_ptr())
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("teal_amd: split-K workspace must be allocated before graph capture "
+        if capturing:
+            raise RuntimeError("teal_amd: the workspace must be allocated before graph capture "
                                "(run one warm-up call, or teal_amd.runtime.reserve_workspace(Z, N))")
-        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=torch.device("cuda", idx))
-        _workspaces[idx] = ws
+        L = _lib.load()
+        for k in (key, (idx, -1)):
+            old = _workspaces.get(k)
+            if old is None or old.numel() * 4 < nbytes:
+                if old is not None:
+                    L.teal_workspace_release(old.data_ptr())
+                _workspaces[k] = _prepared(idx, nbytes)
+        ws = _workspaces[key]
     return ws
 
 
 def reserve_workspace(Z: int, N: int, device=None) -> torch.Tensor:
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     return workspace(device, int(_lib.load().teal_workspace_bytes(int(Z), int(N))))
+
+
+def new_workspace(Z: int, N: int, device=None) -> torch.Tensor:
+    """A prepared workspace of its own (not the per-stream one): for an object that launches / replays on whatever
+    stream is current, one launch at a time, e.g. the decode engine."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _inited:
+        with torch.cuda.device(idx):
+            init()
+    return _prepared(idx, int(_lib.load().teal_workspace_bytes(int(Z), int(N))))

@@ -537,6 +537,7 @@ def test_sampler_window_and_radix_kernels_pick_the_same_tokens(dtype, V, law):
         base[777] = 60.0
     padded = torch.cat([base, torch.full((4,), float("-inf"), device=DEV, dtype=dtype)])
     tok = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ws = runtime.reserve_workspace(64, 64)  # prepared (teal_workspace_init): its header holds the multi-workgroup scratch
     for top_k, temp in ((200, 0.8), (20, 1.0), (1, 1.0), (0, 1.0), (5000, 2.0), (V - 1, 1.5)):
         outs = []
         # multi-workgroup kernel (8192 < V <= 131072, filter on), single-workgroup window kernel, generic radix kernel
@@ -547,8 +548,8 @@ def test_sampler_window_and_radix_kernels_pick_the_same_tokens(dtype, V, law):
             hist = torch.full((64,), -1, dtype=torch.int32, device=DEV)
             seq = []
             for _ in range(24):
-                assert L.teal_sample_topk(logits.data_ptr(), n, code, top_k, temp, state.data_ptr(), tok.data_ptr(), pos.data_ptr(),
-                                          hist.data_ptr(), 64, runtime.stream_ptr()) == 0
+                assert L.teal_sample_topk_ws(logits.data_ptr(), n, code, top_k, temp, state.data_ptr(), tok.data_ptr(), pos.data_ptr(),
+                                             hist.data_ptr(), 64, ws.data_ptr(), ws.numel() * 4, runtime.stream_ptr()) == 0
                 seq.append(int(tok.item()))
             assert int(state[1]) == 24 and int(pos[0]) == 11 + 24 and hist[:24].tolist() == seq
             outs.append(seq)

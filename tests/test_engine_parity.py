@@ -93,28 +93,37 @@ def _mask_words(O, bits, tau, dtype):
     return (kb.astype(np.uint64) << np.arange(64, dtype=np.uint64)).sum(axis=1, dtype=np.uint64)
 
 
-CASES = [("7B", torch.float16, 0.5), ("llama-3-8b", torch.bfloat16, 0.4), ("70B", torch.float16, 0.5)]
+# (architecture, dtype, sparsity, layers built, layer checked).  Layer 0 takes its residual from the embedding table through
+# the row_index producer (no slabs); the 32-layer case checks the LAST layer of a full-depth Llama-2-7B step (where round
+# 2's one-off `wo slabs DIFF` was seen) and, like every case, the lm_head launch behind it.
+CASES = [("7B", torch.float16, 0.5, 2, 1), ("7B", torch.float16, 0.5, 2, 0), ("llama-3-8b", torch.bfloat16, 0.4, 2, 1),
+         ("llama-3-8b", torch.bfloat16, 0.4, 2, 0), ("70B", torch.float16, 0.5, 2, 1), ("7B", torch.float16, 0.5, 32, 31)]
 
 
 @pytest.mark.parametrize("fast", [1, 0])
-@pytest.mark.parametrize("name,tdt,sparsity", CASES)
-def test_engine_launches_vs_oracle_under_sparsity(oracle, name, tdt, sparsity, fast):
+@pytest.mark.parametrize("name,tdt,sparsity,n_layer,target", CASES)
+def test_engine_launches_vs_oracle_under_sparsity(oracle, name, tdt, sparsity, n_layer, target, fast):
     from teal_amd import _lib
     from teal_amd.gpt_fast import generate as G
     from teal_amd.gpt_fast.engine import DecodeEngine
     O = oracle
     dtype = 0 if tdt == torch.float16 else 1
     L = _lib.load()
-    model = G.build_synthetic_model(name, DEV, tdt, seed=11, n_layer=2)
+    if n_layer > 2 and fast == 0:
+        pytest.skip("full depth runs with the production (lean) kernel; the general kernel is covered at 2 layers")
+    model = G.build_synthetic_model(name, DEV, tdt, seed=11, n_layer=n_layer)
     cfg = model.config
     dim, inter, hd = cfg.dim, cfg.intermediate_size, cfg.head_dim
     kv = cfg.n_local_heads * hd
     nqkv = dim + 2 * kv
-    lay = model.layers[1]
+    lay = model.layers[target]
     W = {"qkv": _wT_bits(lay.attention.wqkv), "o": _wT_bits(lay.attention.wo), "gate": _wT_bits(lay.feed_forward.w1),
          "up": _wT_bits(lay.feed_forward.w3), "down": _wT_bits(lay.feed_forward.w2)}
     nw1 = O.from_bits(bits_from_torch(lay.attention_norm.weight), dtype).astype(np.float32)
     nw2 = O.from_bits(bits_from_torch(lay.ffn_norm.weight), dtype).astype(np.float32)
+    nwf = O.from_bits(bits_from_torch(model.norm.weight), dtype).astype(np.float32)
+    W_head = _wT_bits(model.output) if target == n_layer - 1 else None
+    emb = bits_from_torch(model.tok_embeddings.weight[17]) if target == 0 else None
     ths = G.apply_sparsity(model, sparsity=sparsity, hist_path=None, greedy_lookup=None, synthetic=True)
     V = cfg.vocab_size
     prompt = torch.randint(0, V, (6,), device=DEV, dtype=torch.int, generator=torch.Generator(device=DEV).manual_seed(2))
@@ -126,7 +135,7 @@ def test_engine_launches_vs_oracle_under_sparsity(oracle, name, tdt, sparsity, f
             model(prompt.view(1, -1), torch.arange(6, device=DEV))
             eng = DecodeEngine(model, ths)
         assert eng.pair and eng.att_fused_merge
-        k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out, _ = eng.stages[1]
+        k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out, _ = eng.stages[target]
         A, B = eng.resid
         seen = {}
 
@@ -135,10 +144,31 @@ def test_engine_launches_vs_oracle_under_sparsity(oracle, name, tdt, sparsity, f
             return t.detach().float().cpu().numpy().astype(np.float32)
 
         def hook(when, stage, i):
-            if i != 1:
+            if stage == "head" and W_head is not None:
+                torch.cuda.synchronize()
+                if when == "before":  # lm_head: RMSNorm producer over the final residual + down slabs, every row kept
+                    _, y16 = _slab_sum(O, np32(eng.s_down.view(-1)), eng.n_down.value, dim, dtype)
+                    h = _round(O, np32(A) + O.from_bits(y16, dtype).astype(np.float32), dtype)
+                    seen["xh"] = _rmsnorm_variants(O, h, nwf, eng.eps, dtype)[0]
+                else:
+                    truth = O.truth64(seen["xh"], W_head, dim, V, float("-inf"), dtype=dtype)
+                    err = np.abs(O.from_bits(bits_from_torch(eng.logits.view(-1)), dtype) - truth)
+                    assert (err <= tolerance(O, truth, dtype)).all(), ("lm_head", float(err.max()))
+                    seen["head"] = True
+                return
+            if i != target:
                 return
             torch.cuda.synchronize()
-            if when == "before" and stage == "qkv":
+            if when == "before" and stage == "qkv" and target == 0:
+                # layer 0: the residual is the embedding row of the token (row_index producer), nothing to add
+                assert k1_in.nslabs == 0 and k1_in.row_index
+                h = O.from_bits(emb, dtype).astype(np.float32)
+                seen["h1"] = emb
+                xv = _rmsnorm_variants(O, h, nw1, eng.eps, dtype)
+                seen["x1"] = xv[0]
+                seen["tq"], seen["tk"], seen["tv"] = (_safe_tau(O, xv, s, dtype) for s in (sparsity, sparsity + 0.05, sparsity - 0.05))
+                k1_out.tau[0], k1_out.tau[1], k1_out.tau[2] = seen["tq"], seen["tk"], seen["tv"]
+            elif when == "before" and stage == "qkv":
                 n = eng.n_down.value
                 _, y16 = _slab_sum(O, np32(eng.s_down.view(-1)), n, dim, dtype)
                 h = _round(O, np32(A) + O.from_bits(y16, dtype).astype(np.float32), dtype)
@@ -209,7 +239,8 @@ def test_engine_launches_vs_oracle_under_sparsity(oracle, name, tdt, sparsity, f
         with torch.no_grad():
             eng(tok, pos, hook=hook)
         torch.cuda.synchronize()
-        assert seen.get("done"), "the hook never reached layer 1's down projection"
+        assert seen.get("done"), "the hook never reached the checked layer's down projection"
+        assert W_head is None or seen.get("head"), "the lm_head launch was not checked"
         assert abs(seen["qkv_kept"] - (1 - sparsity)) < 0.03 and 0.2 < seen["down_kept"] < 0.8
     finally:
         L.teal_set_fast(1)

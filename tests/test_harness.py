@@ -83,7 +83,70 @@ def test_cli_flags_match_reference_surface():
     assert d.max_new_tokens == 200 and d.num_samples == 5 and d.top_k == 200 and d.temperature == 0.8 and d.sparsity == 0.0
 
 
+def test_decode_engine_supports_names_ineligible_models():
+    """DecodeEngine.supports(): the predicate Transformer.forward and the synthetic calibration consult before building
+    the fused step; an ineligible model keeps the op-by-op module path instead of raising inside forward."""
+    from teal_amd.gpt_fast.engine import DecodeEngine
+    m = G.build_synthetic_model("stories15M", "cpu", torch.float16, seed=1)  # dim 288, 6 heads: head_dim 48
+    m.setup_caches(1, 16)
+    assert "head_dim 48" in DecodeEngine.supports(m)
+    t = tiny("cpu", torch.float16)  # head_dim 64, dim 256
+    assert "setup_caches" in DecodeEngine.supports(t)
+    t.setup_caches(2, 16)
+    assert "max_batch_size == 1" in DecodeEngine.supports(t)
+    t.max_seq_length = -1
+    t.max_batch_size = -1
+    t.setup_caches(1, 16)
+    assert DecodeEngine.supports(t) == "model is not on a HIP device"  # everything else is fine
+    w2 = t.layers[1].feed_forward.w2
+    w2.weight = torch.nn.Parameter(w2.weight.data.to(torch.int8), requires_grad=False)
+    assert "mixed int8" in DecodeEngine.supports(t)
+    with pytest.raises(ValueError, match="cannot run this model"):
+        DecodeEngine(t, [])
+
+
 # --------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_ineligible_model_keeps_the_module_path():
+    """stories15M (head_dim 48): patching and single-token calls must work through the op-by-op path, as they did before
+    the fused engine existed (round-2 advice: the engine was built unconditionally and raised TEAL_ERR_SHAPE)."""
+    dev = "cuda"
+    m = G.build_synthetic_model("stories15M", dev, torch.float16, seed=5, std=0.05)
+    ths = G.apply_sparsity(m, sparsity=0.5, hist_path=None, greedy_lookup=None, synthetic=True)  # no engine: no decode refinement
+    assert len(ths) == len(m.layers) and ths[0]["q"] > 0
+    m.setup_caches(1, 32)
+    V = m.config.vocab_size
+    toks = torch.randint(0, V, (6,), device=dev, dtype=torch.int)
+    with torch.no_grad():
+        m(toks.view(1, -1), torch.arange(6, device=dev))
+        t = torch.tensor([[7]], device=dev, dtype=torch.int)
+        a = m(t, torch.tensor([6], device=dev))          # fused_decode is on, the engine declines: module path
+        assert getattr(m, "_eng", None) is None and "head_dim 48" in m._eng_why
+        m.fused_decode = False
+        b = m(t, torch.tensor([6], device=dev))
+    assert torch.equal(a, b)
+    # batched caches on an otherwise eligible model: same fallback
+    m2 = tiny(dev, torch.float16)
+    G.apply_sparsity(m2, sparsity=0.0, hist_path=None, greedy_lookup=None, synthetic=True)
+    m2.setup_caches(2, 32)
+    with torch.no_grad():
+        out = m2(torch.tensor([[3]], device=dev, dtype=torch.int), torch.tensor([0], device=dev))
+    assert out.shape == (1, 1, 512) and m2._eng is None and "max_batch_size" in m2._eng_why
+
+
+@pytest.mark.gpu
+def test_fused_forward_returns_a_fresh_tensor():
+    dev = "cuda"
+    m = tiny(dev, torch.float16)
+    G.apply_sparsity(m, sparsity=0.0, hist_path=None, greedy_lookup=None, synthetic=True)
+    m.setup_caches(1, 32)
+    with torch.no_grad():
+        a = m(torch.tensor([[3]], device=dev, dtype=torch.int), torch.tensor([0], device=dev))
+        keep = a.clone()
+        b = m(torch.tensor([[9]], device=dev, dtype=torch.int), torch.tensor([1], device=dev))
+    assert m._eng is not None and a.data_ptr() != b.data_ptr() and torch.equal(a, keep)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("fused", [True, False])
 def test_monkeypatched_model_matches_dense_when_everything_is_kept(fused):
