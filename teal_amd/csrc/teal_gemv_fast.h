@@ -131,7 +131,7 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
             }
             if (!EXACT) r = (cidx[k] < nch) ? r : 0.0f;
             rv[k] = r;
-            sumsq_part += r * r;
+            sumsq_part = fmaf(r, r, sumsq_part);  // explicit: see the contract(off) note at the top of teal_gemv_kernel.h
         }
         stamp(8);
         float* sumsq = reinterpret_cast<float*>(smem);
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
             for (int k = 0; k < KR; ++k) {
                 float Os = 0.0f;
 #pragma unroll
-                for (int q = 0; q < NS; ++q) Os += ov[k][q] * __int_as_float(__builtin_amdgcn_readlane(cw, NS * k + q));
+                for (int q = 0; q < NS; ++q) Os = fmaf(ov[k][q], __int_as_float(__builtin_amdgcn_readlane(cw, NS * k + q)), Os);
                 xr[k] = float_to_bits<BF16>(Os);
             }
         };

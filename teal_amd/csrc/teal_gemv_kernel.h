@@ -23,6 +23,14 @@
 #pragma once
 #include "teal_common.h"
 
+// Floating-point contraction is OFF in the GEMV translation units: every fused multiply-add below is written as fmaf().
+// hipcc's default (-ffp-contract=fast) lets the compiler fuse `a * b + c` wherever it sees fit, and it saw fit differently
+// in this kernel and in the lean kernel (teal_gemv_fast.h) for the same source line of the attention-merge producer: the
+// activation handed to the wo projection then differed in the last place for some inputs, i.e. the two kernels — which
+// are specified to be bit-identical — were not (round 2's "wo slabs DIFF"; found by tests/test_soak.py).  With the
+// contraction explicit, what is written is what runs, in both.
+#pragma clang fp contract(off)
+
 namespace teal {
 
 template <bool BF16>
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
             }
             r = (m < Z) ? r : 0.0f;
             rv[k] = r;
-            ss += r * r;
+            ss = fmaf(r, r, ss);  // explicit: see the contract(off) note at the top of this file
         }
         stamp(p, 8);   // loads back, row sums formed
         ss = wave_sum_f(ss);
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
             for (int k = 0; k < KM; ++k) {
                 float Os = 0.0f;
 #pragma unroll
-                for (int q = 0; q < NS; ++q) Os += ov[k][q] * __int_as_float(__builtin_amdgcn_readlane(cw, NS * k + q));
+                for (int q = 0; q < NS; ++q) Os = fmaf(ov[k][q], __int_as_float(__builtin_amdgcn_readlane(cw, NS * k + q)), Os);
                 xr[k] = float_to_bits<BF16>(Os);
             }
 #pragma unroll

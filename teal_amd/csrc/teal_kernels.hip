@@ -547,8 +547,15 @@ int teal_workspace_init(void* ws, size_t ws_bytes, void* stream) {
         return TEAL_ERR_LAUNCH;
     }
     std::lock_guard<std::mutex> lk(g_ws_mu);
-    for (WsEntry& e : g_ws_reg)
-        if (e.ws == ws) { e.bytes = ws_bytes; return TEAL_OK; }
+    // entries that overlap the new range are stale by construction (their memory was freed and handed out again
+    // without teal_workspace_release): drop them
+    const char* lo = reinterpret_cast<const char*>(ws);
+    const char* hi = lo + ws_bytes;
+    for (size_t i = 0; i < g_ws_reg.size();) {
+        const char* elo = reinterpret_cast<const char*>(g_ws_reg[i].ws);
+        if (elo < hi && lo < elo + g_ws_reg[i].bytes) g_ws_reg.erase(g_ws_reg.begin() + i);
+        else ++i;
+    }
     g_ws_reg.push_back({ws, ws_bytes});
     return TEAL_OK;
 }

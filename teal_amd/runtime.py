@@ -8,6 +8,8 @@ graphs see a static address and two streams never share a counter.
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -42,8 +44,14 @@ def stream_ptr() -> int:
 
 
 def _prepared(idx: int, nbytes: int) -> torch.Tensor:
+    """A workspace tensor whose header the library has zeroed and registered (teal_workspace_init).  The registration
+    is keyed by the device pointer, so it must end with the tensor: when the tensor is collected — and the caching
+    allocator may hand the address to anything else — a finalizer releases it (teal_workspace_release).  Keep the
+    tensor itself alive for as long as launches (or captured graphs) use its pointer; do not keep views instead."""
+    L = _lib.load()
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=torch.device("cuda", idx))
-    _lib.check(_lib.load().teal_workspace_init(ws.data_ptr(), ws.numel() * 4, stream_ptr()), "teal_workspace_init")
+    _lib.check(L.teal_workspace_init(ws.data_ptr(), ws.numel() * 4, stream_ptr()), "teal_workspace_init")
+    weakref.finalize(ws, L.teal_workspace_release, ws.data_ptr())
     return ws
 
 
@@ -65,13 +73,10 @@ def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
         if capturing:
             raise RuntimeError("teal_amd: the workspace must be allocated before graph capture "
                                "(run one warm-up call, or teal_amd.runtime.reserve_workspace(Z, N))")
-        L = _lib.load()
         for k in (key, (idx, -1)):
             old = _workspaces.get(k)
             if old is None or old.numel() * 4 < nbytes:
-                if old is not None:
-                    L.teal_workspace_release(old.data_ptr())
-                _workspaces[k] = _prepared(idx, nbytes)
+                _workspaces[k] = _prepared(idx, nbytes)  # (a replaced tensor's finalizer releases its registration)
         ws = _workspaces[key]
     return ws
 

@@ -125,13 +125,6 @@ def test_ineligible_model_keeps_the_module_path():
         m.fused_decode = False
         b = m(t, torch.tensor([6], device=dev))
     assert torch.equal(a, b)
-    # batched caches on an otherwise eligible model: same fallback
-    m2 = tiny(dev, torch.float16)
-    G.apply_sparsity(m2, sparsity=0.0, hist_path=None, greedy_lookup=None, synthetic=True)
-    m2.setup_caches(2, 32)
-    with torch.no_grad():
-        out = m2(torch.tensor([[3]], device=dev, dtype=torch.int), torch.tensor([0], device=dev))
-    assert out.shape == (1, 1, 512) and m2._eng is None and "max_batch_size" in m2._eng_why
 
 
 @pytest.mark.gpu
