@@ -464,6 +464,23 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
+    if (getenv("LB_PAIRAB")) {
+        // A/B inside one process: gate|up as ONE paired launch (silu * up + masks in its epilogue, MODE 3 down) against two
+        // unpaired threshold segments of 128-column tiles (256-byte row segments) + a silu * up producer in down (MODE 2)
+        const int p0 = pair;
+        pair = 1; hipGraphExec_t ga = capture(token_step);
+        pair = 0; token_step(); CK(hipStreamSynchronize(st)); hipGraphExec_t gb = capture(token_step);
+        pair = p0;
+        double sa = 0, sb = 0; const int rounds = 6;
+        for (int r = 0; r < rounds; ++r) {
+            const double ta = time_graph(ga, steps, true), tb = time_graph(gb, steps, true);
+            printf("  pair A/B round %d: paired %.1f us  unpaired %.1f us\n", r, ta, tb);
+            if (r) { sa += ta; sb += tb; }
+        }
+        printf("pair A/B mean (rounds 1..): paired %.1f us/token, unpaired %.1f us/token  -> %+.2f %%\n", sa / (rounds - 1), sb / (rounds - 1),
+               (sb / sa - 1.0) * 100.0);
+        return 0;
+    }
     if (getenv("LB_AB")) {
         // A/B inside one process: the same token step captured with teal_set_experiment(0) and (mask), timed alternately
         const int mask = atoi(getenv("LB_AB"));

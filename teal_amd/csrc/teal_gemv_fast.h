@@ -30,19 +30,21 @@ namespace teal {
     asm volatile("" ::"s"((a).w0), "s"((a).w1), "s"((a).y), "s"((a).ws), "s"((a).mask_out), "s"((a).resid_out),          \
                  "s"((a).phase), "s"((a).ticket), "s"((a).ld0), "s"((a).ld1), "s"((a).seg_tile1), "s"((a).seg_tile2), "s"((a).tau0),       \
                  "s"((a).tau1), "s"((a).tau2), "s"((a).mask_tau), "s"((a).ws_stride), "s"((a).att_hd), "s"((a).att_ns),  \
-                 "s"((a).cap), "s"((a).exp))
+                 "s"((a).cap), "s"((a).exp), "s"((a).w1_tile))
 
 
-// LPR lanes x 16 B = BN columns per tile; KR = register-cached 64-element chunks per wave.
-//   MODE 0 plain x; 1 residual + slabs -> RMSNorm (in0 residual, in1 slabs, in2 norm weight); 3 x + producer masks
-//   (in0 x, in1 masks); 4 split-KV attention partials (in0).  Element-wise modes (0, 3, 4) cache the rounds of the
-//   workgroup's own slice only: register k <-> round slice + k * split.
+// LPR lanes x 16 B = BN columns per tile; KR = register-cached 64-element chunks per wave; U = 16-byte loads a lane has
+// in flight per batch (two batches in the software pipeline).
+//   MODE 0 plain x; 1 residual + slabs -> RMSNorm (in0 residual, in1 slabs, in2 norm weight); 2 x = silu(gate) * up with
+//   gate|up contiguous [2Z] at in0 (gpt-fast/model.py:258-259, the roundings of the unfused sequence); 3 x + producer
+//   masks (in0 x, in1 masks); 4 split-KV attention partials (in0).  Element-wise modes (0, 2, 3, 4) cache the rounds of
+//   the workgroup's own slice only: register k <-> round slice + k * split.
 //   EXACT (MODE 1): Z == 1024 * KR, every cached chunk exists — no clamps, no guards.
-template <bool BF16, int MODE, bool PAIR, int LPR, int KR, bool EXACT, bool PHASE>
+template <bool BF16, int MODE, bool PAIR, int LPR, int KR, bool EXACT, bool PHASE, int U = 4>
 __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const void* in1, const void* in2,
                                                          const int* row_index, const int Z, const int nslabs,
                                                          const float eps, const FastArgs a) {
-    constexpr int WAVES = 16, U = 4;
+    constexpr int WAVES = 16;
     constexpr int RPW = 64 / LPR;
     constexpr int BN = LPR * 8;
     unsigned long long t_entry = 0;
@@ -197,6 +199,22 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
         } else {
             merge(std::integral_constant<int, 4>{});
         }
+    } else if constexpr (MODE == 2) {
+        uint32_t gb[KR], ub[KR];
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {  // all gate / up loads first, then the activation maths
+            const uint32_t m = (uint32_t)min(cidx[k], nch - 1) * 64u + lane;
+            gb[k] = x16[m];
+            ub[k] = x16[(uint32_t)Z + m];
+        }
+        TEAL_FAST_ARGS_BATCH(a);
+        stamp(1);
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const float gt = bits_to_float(gb[k], BF16);
+            const float sl = bits_to_float(float_to_bits<BF16>(gt / (1.0f + expf(-gt))), BF16);
+            xr[k] = float_to_bits<BF16>(sl * bits_to_float(ub[k], BF16));
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
@@ -223,9 +241,12 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
     //      the remaining chunks are still being balloted (the launch is bound by HBM from the first request on, so every
     //      100 ns the pipeline starts earlier is 100 ns off the launch) -------------------------------------------------
     const int g = lane / LPR, cl = lane % LPR;
-    const uint32_t col = (uint32_t)tile * BN + cl * 8;
-    const char* wp = reinterpret_cast<const char*>(a.w0) + (size_t)col * 2;
-    const uint32_t ldb = (uint32_t)a.ld0 * 2u;
+    // two weight images without pairing (gate | up as two threshold segments, each tile streams ONE matrix): tiles from
+    // w1_tile on belong to the second image
+    const bool second = !PAIR && tile >= a.w1_tile;
+    const uint32_t col = (uint32_t)(second ? tile - a.w1_tile : tile) * BN + cl * 8;
+    const char* wp = reinterpret_cast<const char*>(second ? a.w1 : a.w0) + (size_t)col * 2;
+    const uint32_t ldb = (uint32_t)(second ? a.ld1 : a.ld0) * 2u;
     const char* wp2 = PAIR ? reinterpret_cast<const char*>(a.w1) + (size_t)col * 2 : nullptr;
     const uint32_t ldb2 = PAIR ? (uint32_t)a.ld1 * 2u : 0u;
     const float tau_g = a.tau0, tau_u = a.tau1;
@@ -299,7 +320,7 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
         // with the wave index.  Measured, not derived: the arbiter serves the oldest wave first, and with only a few
         // batches per wave letting the youngest go first is worth 1.0 % of a Llama-2-7B token (0.7 % on Llama-3-8B),
         // while long lists lose 0.3-0.7 % (every row kept, or 8192-wide models) and keep the default.  Timing only.
-        prio_set = nloc < 6 * STEP && !(a.exp & 32);  // exp bit 5: off (A/B)
+        prio_set = nloc < 6 * 4 * RPW && !(a.exp & 32);  // exp bit 5: off (A/B)
         if (prio_set) {
             switch (wave >> 2) {  // (oldest first made explicit: -1.2 %; interleaved, wave & 3: -0.8 % against this ramp)
                 case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -459,6 +480,13 @@ hipError_t launch_fast_e(const FastLaunch& f, hipStream_t st) {
             return hipGetLastError();
         }
     }
+    if constexpr (!PAIR && KR <= 8) {  // single-matrix launches: 8 loads in flight per lane and batch (f.u, fast_eligible)
+        if (f.u == 8) {
+            hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, false, 8>), grid, block, f.lds, st, f.in0, f.in1,
+                               f.in2, f.row_index, f.Z, f.nslabs, f.eps, f.a);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, false>), grid, block, f.lds, st, f.in0, f.in1, f.in2,
                        f.row_index, f.Z, f.nslabs, f.eps, f.a);
     return hipGetLastError();
@@ -497,6 +525,7 @@ hipError_t launch_fast_m(const FastLaunch& f, hipStream_t st) {
     switch (f.mode) {
         case 0: return launch_fast_r<BF16, 0, false, LPR>(f, st);
         case 1: return launch_fast_r<BF16, 1, false, LPR>(f, st);
+        case 2: return launch_fast_r<BF16, 2, false, LPR>(f, st);
         case 3: return launch_fast_r<BF16, 3, false, LPR>(f, st);
         case 4: return launch_fast_r<BF16, 4, false, LPR>(f, st);
         default: return hipErrorInvalidValue;

@@ -21,6 +21,7 @@ struct FastArgs {
     int ws_stride;                  // (split + 3) & ~3, or 0: round and store y (split == 1)
     int att_hd, att_ns;             // MODE 4
     int cap;                        // list entries one wave can own
+    int w1_tile;                    // not PAIR: first tile that streams the second image w1 / ld1 (INT_MAX: one image)
     int exp;                        // experiment switches (teal_set_experiment; 0 in production): A/B inside one process
 };
 
@@ -30,6 +31,7 @@ struct FastLaunch {
     int Z, nslabs; float eps;
     FastArgs a;
     int mode, pair, lpr, kr, ntiles, split;
+    int u;  // 16-byte loads in flight per lane and batch: 4, or 8 (single-matrix launches, teal_set_experiment bit 6)
     size_t lds;
 };
 

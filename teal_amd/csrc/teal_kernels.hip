@@ -247,7 +247,7 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
     if (!g_fast || p.w8 || c.waves != 16 || c.unroll != 4 || (c.lpr != 8 && c.lpr != 16) || p.swizzle) return false;
     if ((p.Z & 63) || p.Z > 65536 || !p.wl) return false;
     const int mode = p.in.mode;
-    if (mode != 0 && mode != 1 && mode != 3 && mode != 4) return false;
+    if (mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 4) return false;
     const int bn = c.lpr * 8, nch = p.Z >> 6, owned_all = (nch + 15) / 16;
     // outputs: interleaved slabs for the next launch; one rounded vector (split == 1); or split > 1 folded into ONE
     // launch by arrival tickets (the last slice of a tile sums the partials in slice order)
@@ -262,7 +262,9 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
         const Seg& sg = p.seg[i];
         if (sg.ncols % bn) return false;
         if (p.pair) continue;
-        if (sg.w != p.seg[0].w || sg.ld != p.seg[0].ld || sg.col0 != p.seg[0].col0 + off) return false;
+        // one weight image cut into threshold segments (q|k|v) — or exactly two images, one per segment (gate | up unpaired)
+        const bool same_image = sg.w == p.seg[0].w && sg.ld == p.seg[0].ld && sg.col0 == p.seg[0].col0 + off;
+        if (!same_image && !(nseg == 2 && i == 1)) return false;
         if (!to_ws && reinterpret_cast<const uint16_t*>(sg.y) != reinterpret_cast<const uint16_t*>(p.seg[0].y) + off) return false;
         off += sg.ncols;
     }
@@ -290,14 +292,18 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
                 if (p.in.nslabs > 0 && !p.in.slabs_il) return false;
                 if (p.in.nslabs > 8) return false;
                 break;
+        case 2: f.in0 = p.x; break;  // gate | up contiguous [2Z]
         case 3: f.in0 = p.x; f.in1 = p.in.masks; break;
         case 4: f.in0 = p.in.att; f.a.att_hd = p.in.att_hd; f.a.att_ns = p.in.att_ns; break;
         default: f.in0 = p.x; break;
     }
     f.a.w0 = reinterpret_cast<const uint16_t*>(p.seg[0].w) + p.seg[0].col0;
     f.a.ld0 = p.seg[0].ld;
-    f.a.w1 = p.pair ? reinterpret_cast<const uint16_t*>(p.seg[1].w) + p.seg[1].col0 : nullptr;
-    f.a.ld1 = p.pair ? p.seg[1].ld : 0;
+    const bool two_images = !p.pair && p.nseg == 2 && !(p.seg[1].w == p.seg[0].w && p.seg[1].ld == p.seg[0].ld &&
+                                                        p.seg[1].col0 == p.seg[0].col0 + p.seg[0].ncols);
+    f.a.w1 = (p.pair || two_images) ? reinterpret_cast<const uint16_t*>(p.seg[1].w) + p.seg[1].col0 : nullptr;
+    f.a.ld1 = (p.pair || two_images) ? p.seg[1].ld : 0;
+    f.a.w1_tile = two_images ? p.seg[1].tile0 : INT_MAX;
     f.a.y = p.seg[0].y;
     f.a.ws = p.ws;
     f.a.mask_out = p.mask_out;
@@ -308,6 +314,7 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
     f.a.seg_tile1 = (!p.pair && p.nseg > 1) ? p.seg[1].tile0 : INT_MAX;
     f.a.seg_tile2 = (!p.pair && p.nseg > 2) ? p.seg[2].tile0 : INT_MAX;
     f.a.exp = g_exp;
+    f.u = (g_exp & 64) ? 8 : 4;
     f.a.ws_stride = (to_ws || ticketed) ? ((c.split + 3) & ~3) : 0;
     f.a.ticket = ticketed ? p.tickets : nullptr;
     return true;

@@ -145,7 +145,15 @@ class DecodeEngine:
         can_pair = inter % 64 == 0 and dim % 64 == 0 and (dim + 1) * 4 <= 44 * 1024
         if pair is None and self.int8:
             pair = False  # int8 rows are half as long: the PAIR launch's 172 workgroups are request-bound
-        self.pair = can_pair if pair is None else (bool(pair) and can_pair)
+        if pair is None:
+            # Pair (one launch streams the same column tile of gate AND up, silu * up + keep masks in its epilogue) only where
+            # the paired tiles are 128 columns wide, i.e. where inter / 128 tiles still cover 2/3 of the CUs (Llama-2-70B).
+            # Narrower models pair 64-column tiles = two 128-byte row segments per kept row, and the stream is bound by
+            # row-segment REQUESTS: unpaired — two threshold segments of 128-column tiles (one 256-byte segment per row) and
+            # a silu * up producer in the down launch — measured -1.4 % per token on Llama-2-7B, -0.3 % on Llama-3-8B, +0.8 %
+            # on Llama-2-70B (layer_bench LB_PAIRAB, profiles/r03_layer_experiments.txt)
+            pair = inter * 3 >= 128 * int(self.L.teal_init()) * 2
+        self.pair = bool(pair) and can_pair
         self.s_wo, self.s_down = e(MAX_SLABS, dim, dtype=torch.float32), e(MAX_SLABS, dim, dtype=torch.float32)
         self.s_qkv = e(8, self.nqkv, dtype=torch.float32)  # wqkv split-K slabs, summed by the attention launch
         self.logits = e(1, 1, cfg.vocab_size)

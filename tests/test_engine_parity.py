@@ -96,13 +96,30 @@ def _mask_words(O, bits, tau, dtype):
 # (architecture, dtype, sparsity, layers built, layer checked).  Layer 0 takes its residual from the embedding table through
 # the row_index producer (no slabs); the 32-layer case checks the LAST layer of a full-depth Llama-2-7B step (where round
 # 2's one-off `wo slabs DIFF` was seen) and, like every case, the lm_head launch behind it.
-CASES = [("7B", torch.float16, 0.5, 2, 1), ("7B", torch.float16, 0.5, 2, 0), ("llama-3-8b", torch.bfloat16, 0.4, 2, 1),
-         ("llama-3-8b", torch.bfloat16, 0.4, 2, 0), ("70B", torch.float16, 0.5, 2, 1), ("7B", torch.float16, 0.5, 32, 31)]
+# `pair`: gate|up as ONE paired launch (silu * up + keep masks in its epilogue, masks handed to down) or as two unpaired
+# threshold segments (rounded gate|up, silu * up producer inside the down launch); None = the engine's own choice
+# (unpaired at 7B / 8B widths, paired at 70B width).
+CASES = [("7B", torch.float16, 0.5, 2, 1, True), ("7B", torch.float16, 0.5, 2, 1, False), ("7B", torch.float16, 0.5, 2, 0, None),
+         ("llama-3-8b", torch.bfloat16, 0.4, 2, 1, True), ("llama-3-8b", torch.bfloat16, 0.4, 2, 1, False),
+         ("llama-3-8b", torch.bfloat16, 0.4, 2, 0, None), ("70B", torch.float16, 0.5, 2, 1, True), ("70B", torch.float16, 0.5, 2, 1, False),
+         ("7B", torch.float16, 0.5, 32, 31, None)]
+
+
+def _silu_mul_variants(O, gu_bits, inter, dtype):
+    """h = round(round(silu(gate)) * up) from the engine's own rounded gate|up bits (gpt-fast/model.py:258-259), plus two
+    variants with silu nudged by a few fp32 ulps (the GPU's expf / division differ from numpy's in the last place)"""
+    g = O.from_bits(gu_bits[:inter], dtype).astype(np.float32)
+    u = O.from_bits(gu_bits[inter:], dtype).astype(np.float32)
+    out = []
+    for k in (0.0, -4e-7, 4e-7):
+        sl = (g / (np.float32(1.0) + np.exp(-g, dtype=np.float32))).astype(np.float32) * np.float32(1.0 + k)
+        out.append(O.to_bits((_round(O, sl, dtype) * u).astype(np.float32), dtype))
+    return out
 
 
 @pytest.mark.parametrize("fast", [1, 0])
-@pytest.mark.parametrize("name,tdt,sparsity,n_layer,target", CASES)
-def test_engine_launches_vs_oracle_under_sparsity(oracle, name, tdt, sparsity, n_layer, target, fast):
+@pytest.mark.parametrize("name,tdt,sparsity,n_layer,target,pair", CASES)
+def test_engine_launches_vs_oracle_under_sparsity(oracle, name, tdt, sparsity, n_layer, target, pair, fast):
     from teal_amd import _lib
     from teal_amd.gpt_fast import generate as G
     from teal_amd.gpt_fast.engine import DecodeEngine
@@ -133,8 +150,10 @@ def test_engine_launches_vs_oracle_under_sparsity(oracle, name, tdt, sparsity, n
             model.max_seq_length = -1
             model.setup_caches(1, 32)
             model(prompt.view(1, -1), torch.arange(6, device=DEV))
-            eng = DecodeEngine(model, ths)
-        assert eng.pair and eng.att_fused_merge
+            eng = DecodeEngine(model, ths, pair=pair)
+        assert eng.att_fused_merge and (pair is None or eng.pair == pair)
+        if pair is None:
+            assert eng.pair == (name == "70B")
         k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out, _ = eng.stages[target]
         A, B = eng.resid
         seen = {}
@@ -212,6 +231,19 @@ def test_engine_launches_vs_oracle_under_sparsity(oracle, name, tdt, sparsity, n
                 assert seen["tg"] != seen["tu"]
                 k4_out.tau[0], k4_out.tau[1] = seen["tg"], seen["tu"]
                 seen["td"] = float(k4_out.mask_tau)
+            elif when == "after" and stage == "gate_up" and not eng.pair:
+                # unpaired: gate and up are two threshold segments with rounded outputs; h is formed by down's producer
+                assert np.array_equal(bits_from_torch(A), seen["h2"]), "residual written by the gate|up launch"
+                gub = bits_from_torch(eng.gu)
+                for nm, wk, t, sl in (("gate", "gate", seen["tg"], slice(0, inter)), ("up", "up", seen["tu"], slice(inter, 2 * inter))):
+                    truth = O.truth64(seen["x2"], W[wk], dim, inter, t, dtype=dtype)
+                    err = np.abs(O.from_bits(gub[sl], dtype) - truth)
+                    assert (err <= tolerance(O, truth, dtype)).all(), (nm, float(err.max()))
+                hv = _silu_mul_variants(O, gub, inter, dtype)
+                seen["hb"] = hv[0]
+                seen["td"] = _safe_tau(O, hv, sparsity, dtype)
+                k5_out.tau[0] = seen["td"]
+                seen["down_kept"] = float((np.abs(O.from_bits(hv[0], dtype)) > seen["td"]).mean())
             elif when == "after" and stage == "gate_up":
                 assert np.array_equal(bits_from_torch(A), seen["h2"]), "residual written by the gate|up launch"
                 hb = bits_from_torch(eng.h_mlp)

@@ -25,7 +25,7 @@ DEV = "cuda"
 # replays per graph; 2 graphs (lean, general) x (PLAIN + SNAP) replays x ~1.8 ms: the defaults take ~12 s of GPU time
 PLAIN = int(os.environ.get("TEAL_SOAK_REPLAYS", "2500"))
 SNAP = int(os.environ.get("TEAL_SOAK_SNAP_REPLAYS", "400"))
-NAMES = ("s_qkv", "att_ws", "s_wo", "h_mlp", "h_mask", "s_down", "resid_A", "resid_B")
+NAMES = ("s_qkv", "att_ws", "s_wo", "h_mlp", "h_mask", "s_down", "resid_A", "resid_B", "gate|up")
 
 
 def _live(eng):
@@ -33,7 +33,8 @@ def _live(eng):
     dim, inter, nq = eng.dim, eng.inter, eng.nqkv
     st = lambda n: (n + 3) & ~3  # noqa: E731
     return [eng.s_qkv.view(-1)[: nq * st(eng.n_qkv.value)], eng.att_ws.view(-1), eng.s_wo.view(-1)[: dim * st(eng.n_wo.value)],
-            eng.h_mlp, eng.h_mask, eng.s_down.view(-1)[: dim * st(eng.n_down.value)], eng.resid[0], eng.resid[1]]
+            eng.h_mlp, eng.h_mask, eng.s_down.view(-1)[: dim * st(eng.n_down.value)], eng.resid[0], eng.resid[1], eng.gu]
+    # (paired gate|up writes h_mlp / h_mask, unpaired writes the rounded gate|up vector; the other one stays constant)
 
 
 def _bytes(t):
@@ -73,7 +74,7 @@ def test_full_depth_graph_replay_soak():
                 if when != "after" or i < 0:
                     return
                 live = _live(eng)
-                for j in {"qkv": (0,), "attn": (1,), "wo": (2,), "gate_up": (3, 4, 6), "down": (5,)}[stage]:
+                for j in {"qkv": (0,), "attn": (1,), "wo": (2,), "gate_up": (3, 4, 6, 8), "down": (5,)}[stage]:
                     snap[j][i].copy_(_bytes(live[j]))
                 if stage == "qkv":
                     snap[7][i].copy_(_bytes(live[7]))
