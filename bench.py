@@ -20,6 +20,7 @@ import argparse
 import ctypes
 import json
 import os
+import re
 import sys
 import time
 
@@ -279,9 +280,16 @@ def pmc_traffic(kernel_desc):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_fetch_by_kernel.csv")))
     if not files:
         return None, None
+    # "gemv_fast_kernel<...> grid (172,1) x 1024": the same instantiation serves launches with different grids (gate|up and
+    # lm_head), so the profile is keyed by (instantiation, workgroups)
     short = kernel_desc.split(" grid")[0].replace(" ", "")
+    m = re.search(r"grid \((\d+),(\d+)\)", kernel_desc) or re.search(r"grid (\d+) x", kernel_desc)
+    wgs = None
+    if m:
+        wgs = int(m.group(1)) * (int(m.group(2)) if m.lastindex and m.lastindex > 1 else 1)
     for r in csv.DictReader(open(files[-1])):
-        if short and short in r["kernel"].replace(" ", "") and r["counter"] == "FETCH_SIZE":
+        if short and short == r["kernel"].replace(" ", "") and r["counter"] == "FETCH_SIZE" and (
+                "workgroups" not in r or wgs is None or int(r["workgroups"]) == wgs):
             return float(r["avg_value"]) * 1024 * 2, os.path.relpath(files[-1], ROOT) + " (FETCH_SIZE KiB x 2, per dispatch)"
     return None, None
 

@@ -7,14 +7,14 @@
 set -u
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-OUT=gpurun_out/prof_${ROUND:-r02}
+OUT=gpurun_out/prof_${ROUND:-r03}${TAG:-}
 rm -rf "$OUT"; mkdir -p "$OUT"
-ARGS="--steps 40 --warmup 5 --no-dense --no-cpu-baseline"
+ARGS="--steps 40 --warmup 5 --no-dense --no-cpu-baseline ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python bench.py $ARGS > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- python bench.py --steps 10 --warmup 2 --no-dense --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- python bench.py --steps 10 --warmup 2 --no-dense --no-cpu-baseline ${BENCH_ARGS:-} > "$OUT/pmc_fetch.log" 2>&1
 echo "pmc fetch rc=$?"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- python bench.py --steps 10 --warmup 2 --no-dense --no-cpu-baseline > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- python bench.py --steps 10 --warmup 2 --no-dense --no-cpu-baseline ${BENCH_ARGS:-} > "$OUT/pmc_write.log" 2>&1
 echo "pmc write rc=$?"
 find "$OUT" -name "*.db" -delete
 ls -la "$OUT"/*

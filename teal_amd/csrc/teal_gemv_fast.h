@@ -30,7 +30,7 @@ namespace teal {
     asm volatile("" ::"s"((a).w0), "s"((a).w1), "s"((a).y), "s"((a).ws), "s"((a).mask_out), "s"((a).resid_out),          \
                  "s"((a).phase), "s"((a).ticket), "s"((a).ld0), "s"((a).ld1), "s"((a).seg_tile1), "s"((a).seg_tile2), "s"((a).tau0),       \
                  "s"((a).tau1), "s"((a).tau2), "s"((a).mask_tau), "s"((a).ws_stride), "s"((a).att_hd), "s"((a).att_ns),  \
-                 "s"((a).cap), "s"((a).exp), "s"((a).w1_tile))
+                 "s"((a).cap), "s"((a).exp), "s"((a).w1_tile), "s"((a).scale0), "s"((a).scale1))
 
 
 // LPR lanes x 16 B = BN columns per tile; KR = register-cached 64-element chunks per wave; U = 16-byte loads a lane has
@@ -40,13 +40,20 @@ namespace teal {
 //   masks (in0 x, in1 masks); 4 split-KV attention partials (in0).  Element-wise modes (0, 2, 3, 4) cache the rounds of
 //   the workgroup's own slice only: register k <-> round slice + k * split.
 //   EXACT (MODE 1): Z == 1024 * KR, every cached chunk exists — no clamps, no guards.
-template <bool BF16, int MODE, bool PAIR, int LPR, int KR, bool EXACT, bool PHASE, int U = 4>
+template <bool BF16, int MODE, bool PAIR, int LPR, int KR, bool EXACT, bool PHASE, int U = 4, bool W8 = false>
 __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const void* in1, const void* in2,
                                                          const int* row_index, const int Z, const int nslabs,
                                                          const float eps, const FastArgs a) {
+    static_assert(!(W8 && PAIR), "int8 gate|up runs unpaired (two images of 128-byte row segments)");
     constexpr int WAVES = 16;
     constexpr int RPW = 64 / LPR;
-    constexpr int BN = LPR * 8;
+    // a lane owns 8 columns: 16 bytes of 16-bit weights, 8 bytes of int8 weights (the same lane <-> row mapping, hence the
+    // same summation order, as sparse_gemv_kernel's int8 form: bit-identical results).  16 int8 columns per lane (16-byte
+    // loads, 8 lanes per 128-byte row segment) measured SLOWER: 669 against 706 tok/s on Llama-2-7B int8 @ 50 %.
+    constexpr int CPL = 8;
+    constexpr int BN = LPR * CPL;
+    constexpr int WB = W8 ? 1 : 2;  // bytes per weight
+    using wvec = std::conditional_t<W8, u32x2, u32x4>;
     unsigned long long t_entry = 0;
     if constexpr (PHASE) t_entry = wall_clock64();
     extern __shared__ __align__(16) unsigned char smem[];
@@ -226,6 +233,14 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
         stamp(1);
     }
     stamp(2);
+    // int8: the per-column scale of the epilogue, requested now (a dependent epilogue load would cost a cold round trip)
+    uint32_t scb = 0u;
+    if constexpr (W8) {
+        if (tid < BN) {
+            const bool sec = tile >= a.w1_tile;
+            scb = (sec ? a.scale1 : a.scale0)[(uint32_t)(sec ? tile - a.w1_tile : tile) * BN + tid];
+        }
+    }
 
     // ---- mask + wave-local compaction: (row:16 | x:16) pairs of the wave's own chunks, ascending ---------------
     int s = 0;
@@ -244,48 +259,50 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
     // two weight images without pairing (gate | up as two threshold segments, each tile streams ONE matrix): tiles from
     // w1_tile on belong to the second image
     const bool second = !PAIR && tile >= a.w1_tile;
-    const uint32_t col = (uint32_t)(second ? tile - a.w1_tile : tile) * BN + cl * 8;
-    const char* wp = reinterpret_cast<const char*>(second ? a.w1 : a.w0) + (size_t)col * 2;
-    const uint32_t ldb = (uint32_t)(second ? a.ld1 : a.ld0) * 2u;
-    const char* wp2 = PAIR ? reinterpret_cast<const char*>(a.w1) + (size_t)col * 2 : nullptr;
-    const uint32_t ldb2 = PAIR ? (uint32_t)a.ld1 * 2u : 0u;
+    const uint32_t col = (uint32_t)(second ? tile - a.w1_tile : tile) * BN + cl * CPL;
+    const char* wp = reinterpret_cast<const char*>(second ? a.w1 : a.w0) + (size_t)col * WB;
+    const uint32_t ldb = (uint32_t)(second ? a.ld1 : a.ld0) * (uint32_t)WB;
+    const char* wp2 = PAIR ? reinterpret_cast<const char*>(a.w1) + (size_t)col * WB : nullptr;
+    const uint32_t ldb2 = PAIR ? (uint32_t)a.ld1 * (uint32_t)WB : 0u;
+    float xs = 0.0f;  // int8: sum of the activations multiplied into acc (bias correction of the epilogue, see fma8)
     const float tau_g = a.tau0, tau_u = a.tau1;
     const bool two_tau = PAIR && (tau_g != tau_u);
-    float acc[8], acc2[PAIR ? 8 : 1];
+    float acc[CPL], acc2[PAIR ? 8 : 1];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+    for (int j = 0; j < CPL; ++j) acc[j] = 0.0f;
 #pragma unroll
     for (int j = 0; j < (PAIR ? 8 : 1); ++j) acc2[j] = 0.0f;
     {
         constexpr int STEP = U * RPW;
         auto full = [&](const int e) { return e + STEP <= nloc; };
-        auto issue = [&](u32x4 (&w)[U], u32x4 (&w2)[PAIR ? U : 1], float (&xv)[U], const int e0) {
+        auto issue = [&](wvec (&w)[U], wvec (&w2)[PAIR ? U : 1], float (&xv)[U], const int e0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t ent = list[e0 + u * RPW + g];
                 xv[u] = bits_to_float(ent & 0xFFFFu, BF16);
-                w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)(ent >> 16) * ldb));
+                w[u] = __builtin_nontemporal_load(reinterpret_cast<const wvec*>(wp + (size_t)(ent >> 16) * ldb));
                 if constexpr (PAIR)
-                    w2[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp2 + (size_t)(ent >> 16) * ldb2));
+                    w2[u] = __builtin_nontemporal_load(reinterpret_cast<const wvec*>(wp2 + (size_t)(ent >> 16) * ldb2));
             }
         };
-        auto consume = [&](u32x4 (&w)[U], u32x4 (&w2)[PAIR ? U : 1], float (&xv)[U]) {
+        auto consume = [&](wvec (&w)[U], wvec (&w2)[PAIR ? U : 1], float (&xv)[U]) {
             if (two_tau) {  // a row outside one of the two keep sets: zero weights, exactly a masked load
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const float ax = fabsf(xv[u]);
                     const bool nanx = xv[u] != xv[u];
-                    if (!(ax > tau_g || nanx)) w[u] = u32x4(0u);
-                    if constexpr (PAIR) if (!(ax > tau_u || nanx)) w2[u] = u32x4(0u);
+                    if (!(ax > tau_g || nanx)) w[u] = wvec(0u);
+                    if constexpr (PAIR) if (!(ax > tau_u || nanx)) w2[u] = wvec(0u);
                 }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 fma8<BF16>(acc, w[u], xv[u]);
+                if constexpr (W8) xs += xv[u];
                 if constexpr (PAIR) fma8<BF16>(acc2, w2[u], xv[u]);
             }
         };
-        u32x4 wa[U], wbb[U], w2a[PAIR ? U : 1], w2b[PAIR ? U : 1];
+        wvec wa[U], wbb[U], w2a[PAIR ? U : 1], w2b[PAIR ? U : 1];
         float xa[U], xb[U];
         bool early = false;
         // ---- mask + wave-local compaction ----------------------------------------------------------------------
@@ -354,12 +371,12 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
                 const bool ok = e < nloc;
                 const uint32_t ent = list[ok ? e : nloc - 1];
                 xa[u] = ok ? bits_to_float(ent & 0xFFFFu, BF16) : 0.0f;
-                u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)(ent >> 16) * ldb));
-                if (!ok) t = u32x4(0u);
+                wvec t = __builtin_nontemporal_load(reinterpret_cast<const wvec*>(wp + (size_t)(ent >> 16) * ldb));
+                if (!ok) t = wvec(0u);  // (int8: the zero activation alone drops the row and keeps it out of the bias sum)
                 wa[u] = t;
                 if constexpr (PAIR) {
-                    u32x4 t2 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp2 + (size_t)(ent >> 16) * ldb2));
-                    if (!ok) t2 = u32x4(0u);
+                    wvec t2 = __builtin_nontemporal_load(reinterpret_cast<const wvec*>(wp2 + (size_t)(ent >> 16) * ldb2));
+                    if (!ok) t2 = wvec(0u);
                     w2a[u] = t2;
                 }
             }
@@ -375,7 +392,7 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
 #pragma unroll
         for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], off);
+            for (int j = 0; j < CPL; ++j) acc[j] += __shfl_xor(acc[j], off);
             if constexpr (PAIR) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc2[j] += __shfl_xor(acc2[j], off);
@@ -383,24 +400,33 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < CPL; ++j) {
             if constexpr (LPR <= 8) acc[j] = xor_add<8>(acc[j]);
             acc[j] = xor_add<32>(xor_add<16>(acc[j]));
-            if constexpr (PAIR) {
+        }
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
                 if constexpr (LPR <= 8) acc2[j] = xor_add<8>(acc2[j]);
                 acc2[j] = xor_add<32>(xor_add<16>(acc2[j]));
             }
         }
     }
     if (lane < LPR) {
-        float* r = red + wave * BN + lane * 8;
+        float* r = red + wave * BN + lane * CPL;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = acc[j];
+        for (int j = 0; j < CPL; ++j) r[j] = acc[j];
         if constexpr (PAIR) {
             float* r2 = red + (WAVES + wave) * BN + lane * 8;
 #pragma unroll
             for (int j = 0; j < 8; ++j) r2[j] = acc2[j];
         }
+    }
+    float* xsw = red + (PAIR ? 2 : 1) * WAVES * BN;  // int8: [WAVES] per-wave activation sums
+    if constexpr (W8) {
+        if constexpr (LPR <= 8) xs = xor_add<8>(xs);
+        xs = xor_add<32>(xor_add<16>(xs));
+        if (lane == 0) xsw[wave] = xs;
     }
     __syncthreads();
     stamp(6);
@@ -411,6 +437,15 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
         for (int wv = 0; wv < WAVES; ++wv) {
             gs += red[wv * BN + tid];
             if constexpr (PAIR) us += red[(WAVES + wv) * BN + tid];
+        }
+        if constexpr (W8) {
+            // sum q * x = sum (q + 1152) * x - 1152 * sum x (fma8 on bytes), then the per-column scale in fp32 before the one
+            // rounding (gpt-fast/quantize.py:354 scales the reduced product)
+            float bias = 0.0f;
+#pragma unroll
+            for (int wv = 0; wv < WAVES; ++wv) bias += xsw[wv];
+            bias *= kInt8Bias;
+            gs = (gs - bias) * bits_to_float(scb, BF16);
         }
         if constexpr (PAIR) {
             // h = silu(gate) * up with the roundings of the unfused sequence (gpt-fast/model.py:258-259), and the keep
@@ -470,50 +505,45 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
 }
 
 
-template <bool BF16, int MODE, bool PAIR, int LPR, int KR, bool EXACT>
+template <bool BF16, int MODE, bool PAIR, int LPR, int KR, bool EXACT, bool W8 = false>
 hipError_t launch_fast_e(const FastLaunch& f, hipStream_t st) {
     const dim3 grid(f.ntiles, f.split), block(1024);
-    if (f.a.phase) {
-        if constexpr (!BF16) {  // stamped instantiations exist for fp16 only (diagnostics)
-            hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, true>), grid, block, f.lds, st, f.in0, f.in1,
-                               f.in2, f.row_index, f.Z, f.nslabs, f.eps, f.a);
-            return hipGetLastError();
+    if constexpr (!W8) {
+        if (f.a.phase) {
+            if constexpr (!BF16) {  // stamped instantiations exist for fp16 only (diagnostics)
+                hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, true>), grid, block, f.lds, st, f.in0, f.in1,
+                                   f.in2, f.row_index, f.Z, f.nslabs, f.eps, f.a);
+                return hipGetLastError();
+            }
         }
     }
-    if constexpr (!PAIR && KR <= 8) {  // single-matrix launches: 8 loads in flight per lane and batch (f.u, fast_eligible)
-        if (f.u == 8) {
-            hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, false, 8>), grid, block, f.lds, st, f.in0, f.in1,
-                               f.in2, f.row_index, f.Z, f.nslabs, f.eps, f.a);
-            return hipGetLastError();
-        }
-    }
-    hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, false>), grid, block, f.lds, st, f.in0, f.in1, f.in2,
+    hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, false, 4, W8>), grid, block, f.lds, st, f.in0, f.in1, f.in2,
                        f.row_index, f.Z, f.nslabs, f.eps, f.a);
     return hipGetLastError();
 }
 
-template <bool BF16, int MODE, bool PAIR, int LPR, int KR>
+template <bool BF16, int MODE, bool PAIR, int LPR, int KR, bool W8 = false>
 hipError_t launch_fast_k(const FastLaunch& f, hipStream_t st) {
     if constexpr (MODE == 1) {
-        if (f.Z == 1024 * KR) return launch_fast_e<BF16, MODE, PAIR, LPR, KR, true>(f, st);
+        if (f.Z == 1024 * KR) return launch_fast_e<BF16, MODE, PAIR, LPR, KR, true, W8>(f, st);
     }
-    return launch_fast_e<BF16, MODE, PAIR, LPR, KR, false>(f, st);
+    return launch_fast_e<BF16, MODE, PAIR, LPR, KR, false, W8>(f, st);
 }
 
-template <bool BF16, int MODE, bool PAIR, int LPR>
+template <bool BF16, int MODE, bool PAIR, int LPR, bool W8 = false>
 hipError_t launch_fast_r(const FastLaunch& f, hipStream_t st) {
     if constexpr (MODE == 1) {
         switch (f.kr) {
-            case 4: return launch_fast_k<BF16, MODE, PAIR, LPR, 4>(f, st);
-            case 8: return launch_fast_k<BF16, MODE, PAIR, LPR, 8>(f, st);
-            case 16: return launch_fast_k<BF16, MODE, PAIR, LPR, 16>(f, st);
+            case 4: return launch_fast_k<BF16, MODE, PAIR, LPR, 4, W8>(f, st);
+            case 8: return launch_fast_k<BF16, MODE, PAIR, LPR, 8, W8>(f, st);
+            case 16: return launch_fast_k<BF16, MODE, PAIR, LPR, 16, W8>(f, st);
             default: return hipErrorInvalidValue;
         }
     } else {
         switch (f.kr) {
-            case 1: return launch_fast_k<BF16, MODE, PAIR, LPR, 1>(f, st);
-            case 4: return launch_fast_k<BF16, MODE, PAIR, LPR, 4>(f, st);
-            case 8: return launch_fast_k<BF16, MODE, PAIR, LPR, 8>(f, st);
+            case 1: return launch_fast_k<BF16, MODE, PAIR, LPR, 1, W8>(f, st);
+            case 4: return launch_fast_k<BF16, MODE, PAIR, LPR, 4, W8>(f, st);
+            case 8: return launch_fast_k<BF16, MODE, PAIR, LPR, 8, W8>(f, st);
             default: return hipErrorInvalidValue;
         }
     }
@@ -537,6 +567,20 @@ hipError_t launch_fast_q(const FastLaunch& f, hipStream_t st) {
     switch (f.lpr) {
         case 8: return launch_fast_m<BF16, 8>(f, st);
         case 16: return launch_fast_m<BF16, 16>(f, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// int8 weight images: 16 lanes x 8 bytes = 128-column tiles (128-byte row segments), never paired
+template <bool BF16>
+hipError_t launch_fast_w8_q(const FastLaunch& f, hipStream_t st) {
+    if (f.pair || f.lpr != 16) return hipErrorInvalidValue;
+    switch (f.mode) {
+        case 0: return launch_fast_r<BF16, 0, false, 16, true>(f, st);
+        case 1: return launch_fast_r<BF16, 1, false, 16, true>(f, st);
+        case 2: return launch_fast_r<BF16, 2, false, 16, true>(f, st);
+        case 3: return launch_fast_r<BF16, 3, false, 16, true>(f, st);
+        case 4: return launch_fast_r<BF16, 4, false, 16, true>(f, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -21,6 +21,8 @@ struct FastArgs {
     int ws_stride;                  // (split + 3) & ~3, or 0: round and store y (split == 1)
     int att_hd, att_ns;             // MODE 4
     int cap;                        // list entries one wave can own
+    const uint16_t* scale0;         // int8 weights: per-column scales of image 0 / image 1 (element 0 = first column of the image)
+    const uint16_t* scale1;
     int w1_tile;                    // not PAIR: first tile that streams the second image w1 / ld1 (INT_MAX: one image)
     int exp;                        // experiment switches (teal_set_experiment; 0 in production): A/B inside one process
 };
@@ -31,11 +33,13 @@ struct FastLaunch {
     int Z, nslabs; float eps;
     FastArgs a;
     int mode, pair, lpr, kr, ntiles, split;
-    int u;  // 16-byte loads in flight per lane and batch: 4, or 8 (single-matrix launches, teal_set_experiment bit 6)
+    int w8;  // int8 weight image(s): the W8 instantiations (teal_gemv_fast_w8_*.hip)
     size_t lds;
 };
 
 hipError_t launch_fast_f16(const FastLaunch& f, hipStream_t st);   // teal_gemv_fast_f16.hip
 hipError_t launch_fast_bf16(const FastLaunch& f, hipStream_t st);  // teal_gemv_fast_bf16.hip
+hipError_t launch_fast_w8_f16(const FastLaunch& f, hipStream_t st);   // teal_gemv_fast_w8_f16.hip
+hipError_t launch_fast_w8_bf16(const FastLaunch& f, hipStream_t st);  // teal_gemv_fast_w8_bf16.hip
 
 }  // namespace teal

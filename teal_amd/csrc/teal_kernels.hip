@@ -241,10 +241,12 @@ Config pick_config(int Z, int ncols_total, int nseg_tiles_hint) {
 }
 
 
-// Does this launch qualify for the lean kernel (teal_gemv_fast.h)?  16-bit weights, whole chunks and tiles, one weight
-// image (or the gate|up pair), interleaved slabs or a single rounded output, wave-local lists that fit.
+// Does this launch qualify for the lean kernel (teal_gemv_fast.h)?  Whole chunks and tiles, one weight image (or two:
+// the gate|up pair, or gate | up as two unpaired segments), interleaved slabs or a single rounded output, wave-local
+// lists that fit; 16-bit weights, or int8 images in 128-column tiles (never paired).
 bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes, FastLaunch& f) {
-    if (!g_fast || p.w8 || c.waves != 16 || c.unroll != 4 || (c.lpr != 8 && c.lpr != 16) || p.swizzle) return false;
+    if (!g_fast || c.waves != 16 || c.unroll != 4 || (c.lpr != 8 && c.lpr != 16) || p.swizzle) return false;
+    if (p.w8 && (c.lpr != 16 || p.pair)) return false;
     if ((p.Z & 63) || p.Z > 65536 || !p.wl) return false;
     const int mode = p.in.mode;
     if (mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 4) return false;
@@ -265,6 +267,8 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
         // one weight image cut into threshold segments (q|k|v) — or exactly two images, one per segment (gate | up unpaired)
         const bool same_image = sg.w == p.seg[0].w && sg.ld == p.seg[0].ld && sg.col0 == p.seg[0].col0 + off;
         if (!same_image && !(nseg == 2 && i == 1)) return false;
+        if (p.w8 && same_image && reinterpret_cast<const uint16_t*>(sg.scale) != reinterpret_cast<const uint16_t*>(p.seg[0].scale) + off)
+            return false;  // one image: its scale vector is one vector
         if (!to_ws && reinterpret_cast<const uint16_t*>(sg.y) != reinterpret_cast<const uint16_t*>(p.seg[0].y) + off) return false;
         off += sg.ncols;
     }
@@ -283,8 +287,9 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
     }
     f = FastLaunch{};
     f.a.cap = rounds_owned * 64;
-    f.lds = 64 + (size_t)16 * f.a.cap * 4 + (size_t)16 * bn * 4 * (p.pair ? 2 : 1);
+    f.lds = 64 + (size_t)16 * f.a.cap * 4 + (size_t)16 * bn * 4 * (p.pair ? 2 : 1) + (p.w8 ? 128 : 0);
     if (f.lds > 64 * 1024) return false;
+    f.w8 = p.w8;
     f.mode = mode; f.pair = p.pair; f.lpr = c.lpr; f.kr = kr; f.ntiles = p.ntiles; f.split = c.split;
     f.Z = p.Z; f.nslabs = p.in.nslabs; f.eps = p.in.eps;
     switch (mode) {
@@ -297,11 +302,14 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
         case 4: f.in0 = p.in.att; f.a.att_hd = p.in.att_hd; f.a.att_ns = p.in.att_ns; break;
         default: f.in0 = p.x; break;
     }
-    f.a.w0 = reinterpret_cast<const uint16_t*>(p.seg[0].w) + p.seg[0].col0;
+    const size_t wb = p.w8 ? 1 : 2;  // bytes per weight
+    f.a.w0 = reinterpret_cast<const char*>(p.seg[0].w) + (size_t)p.seg[0].col0 * wb;
     f.a.ld0 = p.seg[0].ld;
     const bool two_images = !p.pair && p.nseg == 2 && !(p.seg[1].w == p.seg[0].w && p.seg[1].ld == p.seg[0].ld &&
                                                         p.seg[1].col0 == p.seg[0].col0 + p.seg[0].ncols);
-    f.a.w1 = (p.pair || two_images) ? reinterpret_cast<const uint16_t*>(p.seg[1].w) + p.seg[1].col0 : nullptr;
+    f.a.w1 = (p.pair || two_images) ? reinterpret_cast<const char*>(p.seg[1].w) + (size_t)p.seg[1].col0 * wb : nullptr;
+    f.a.scale0 = reinterpret_cast<const uint16_t*>(p.seg[0].scale);
+    f.a.scale1 = two_images ? reinterpret_cast<const uint16_t*>(p.seg[1].scale) : nullptr;
     f.a.ld1 = (p.pair || two_images) ? p.seg[1].ld : 0;
     f.a.w1_tile = two_images ? p.seg[1].tile0 : INT_MAX;
     f.a.y = p.seg[0].y;
@@ -314,7 +322,6 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
     f.a.seg_tile1 = (!p.pair && p.nseg > 1) ? p.seg[1].tile0 : INT_MAX;
     f.a.seg_tile2 = (!p.pair && p.nseg > 2) ? p.seg[2].tile0 : INT_MAX;
     f.a.exp = g_exp;
-    f.u = (g_exp & 64) ? 8 : 4;
     f.a.ws_stride = (to_ws || ticketed) ? ((c.split + 3) & ~3) : 0;
     f.a.ticket = ticketed ? p.tickets : nullptr;
     return true;
@@ -386,13 +393,16 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
             const int tiles = (total_cols + 127) / 128;
             const int rounds = (((p.Z + 63) >> 6) + 15) / 16;
             int split = 1;
-            if (to_ws) {  // slab output: the kept rows may be sliced (wave-local: <= rounds, interleaved slabs: <= 8)
+            if (to_ws || p.tickets) {  // slab output, or a rounded output folded in by arrival tickets: the kept rows may be
+                                       // sliced (wave-local: <= rounds, interleaved slabs: <= 8)
                 split = ncu / tiles;
                 if (split > rounds) split = rounds;
                 if (split > 8) split = 8;
                 if (split < 1) split = 1;
             }
-            if (tiles * split * 5 >= ncu * 3) {
+            // (half the CUs with 128-byte segments stream as much as all of them with 64-byte segments — the same number of
+            // requests per microsecond — and 128-column tiles are what the lean kernel is built for: wo, 32 tiles x 4 slices)
+            if (tiles * split * 2 >= ncu) {
                 c.lpr = 16;
                 c.split = split;
             }
@@ -471,10 +481,11 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
     {
         FastLaunch f;
         if (fast_eligible(p, c, to_ws, ws_bytes, f)) {
-            snprintf(g_last_desc, sizeof g_last_desc, "gemv_fast_kernel<%s,%d,%s,%d,%d,%s,false> grid (%d,%d) x 1024",
+            snprintf(g_last_desc, sizeof g_last_desc, "gemv_fast_kernel<%s,%d,%s,%d,%d,%s,false%s> grid (%d,%d) x 1024",
                      dtype == TEAL_BF16 ? "true" : "false", f.mode, f.pair ? "true" : "false", f.lpr, f.kr,
-                     (f.mode == 1 && f.Z == 1024 * f.kr) ? "true" : "false", f.ntiles, f.split);
-            const hipError_t e = dtype == TEAL_BF16 ? launch_fast_bf16(f, st) : launch_fast_f16(f, st);
+                     (f.mode == 1 && f.Z == 1024 * f.kr) ? "true" : "false", f.w8 ? ",4,true" : "", f.ntiles, f.split);
+            const hipError_t e = f.w8 ? (dtype == TEAL_BF16 ? launch_fast_w8_bf16(f, st) : launch_fast_w8_f16(f, st))
+                                      : (dtype == TEAL_BF16 ? launch_fast_bf16(f, st) : launch_fast_f16(f, st));
             return e == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
         }
     }

@@ -55,7 +55,23 @@ def test_fixture_reference_module_outputs(oracle, tag, dtype):
 @pytest.mark.parametrize("Z,N,dtype,tau", [(4096, 4096, 0, 0.5), (4096, 11008, 0, 0.5), (11008, 4096, 0, 0.35),
                                            (4096, 14336, 1, 0.4), (8192, 1024, 0, 0.9), (1000, 1000, 0, 0.5),
                                            (4096, 32000, 0, -1.0)])
-def test_int8_gemv_vs_truth(oracle, Z, N, dtype, tau):
+@pytest.mark.parametrize("fast", [1, 0])
+def test_int8_gemv_vs_truth(oracle, Z, N, dtype, tau, fast):
+    """fast = 1: the lean kernel's int8 instantiations where the shape qualifies (whole 128-column tiles, whole chunks);
+    fast = 0: the general kernel everywhere.  Same lane <-> row mapping and arithmetic order: identical bits."""
+    from teal_amd import _lib
+    L = _lib.load()
+    L.teal_set_fast(fast)
+    try:
+        _int8_gemv_vs_truth(oracle, Z, N, dtype, tau, L, fast)
+    finally:
+        L.teal_set_fast(1)
+
+
+_INT8_SEEN = {}
+
+
+def _int8_gemv_vs_truth(oracle, Z, N, dtype, tau, L, fast):
     q = hash_int8(oracle, N, Z, 91)
     xb = oracle.hash_uniform(Z, 92, 2.0, dtype)
     sc_f = (0.5 + np.arange(N) % 7) * 1e-3
@@ -67,9 +83,20 @@ def test_int8_gemv_vs_truth(oracle, Z, N, dtype, tau):
     truth = oracle.int8_truth64(xb, q, scb, tau, dtype=dtype)
     bad = np.abs(got - truth) > tolerance(oracle, truth, dtype)
     assert not bad.any(), (int(bad.sum()), float(np.abs(got - truth).max()))
+    desc = L.teal_last_launch_desc().decode()
+    is_lean = "gemv_fast_kernel" in desc and ",4,true>" in desc
+    assert not (is_lean and not fast), desc
+    if fast and (Z, N) in ((4096, 4096), (4096, 11008), (11008, 4096), (4096, 14336), (4096, 32000)):  # the Llama projection shapes
+        assert is_lean, desc
     # deterministic
     y2 = K().splitk_sparse_gemv_int8(x, W, torch_from_bits(scb, dtype, DEV), tau if tau > 0 else float("-inf"))
     assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
+    # lean and general kernels agree bit for bit (the parametrisation runs fast = 1 first)
+    key = (Z, N, dtype, tau)
+    if key in _INT8_SEEN:
+        assert torch.equal(_INT8_SEEN.pop(key), y.view(torch.int16).cpu()), (key, fast)
+    else:
+        _INT8_SEEN[key] = y.view(torch.int16).cpu()
 
 
 def test_int8_qkv_three_thresholds_and_geometries(oracle):
@@ -157,3 +184,55 @@ def test_int8_engine_matches_int8_module_path(dtype, sparsity):
                 assert torch.allclose(a, b, atol=tol, rtol=tol), (step, float((a - b).abs().max()))
             else:
                 assert torch.nn.functional.cosine_similarity(a, b, dim=0) > 0.98
+
+
+@pytest.mark.parametrize("name,tdt,sparsity", [("7B", torch.float16, 0.5), ("llama-3-8b", torch.bfloat16, 0.4)])
+def test_int8_engine_runs_lean_kernel_and_equals_general_at_real_width(name, tdt, sparsity):
+    """The fused int8 engine at real widths under sparsity: every GEMV launch of a decode step is a lean-kernel int8
+    instantiation (RMSNorm / attention-merge / silu*up producers, 128-column tiles; qkv and down row-sliced into slabs), and
+    the step is bit-identical to the same step on the general kernel, which tests above pin against the double-precision
+    truth and the reference module's fixture (gpt-fast/quantize.py:339-357)."""
+    from teal_amd import _lib
+    from teal_amd.gpt_fast import generate as G
+    from teal_amd.gpt_fast.engine import DecodeEngine
+    from teal_amd.quantize import quantize_model_int8
+    L = _lib.load()
+    model = quantize_model_int8(G.build_synthetic_model(name, DEV, tdt, seed=17, n_layer=2))
+    torch.cuda.empty_cache()
+    ths = G.apply_sparsity(model, sparsity=sparsity, hist_path=None, greedy_lookup=None, synthetic=True)
+    prompt = torch.randint(0, model.config.vocab_size, (6,), device=DEV, dtype=torch.int, generator=torch.Generator(device=DEV).manual_seed(3))
+    try:
+        with torch.no_grad():
+            model.max_seq_length = -1
+            model.setup_caches(1, 32)
+            model(prompt.view(1, -1), torch.arange(6, device=DEV))
+            eng = DecodeEngine(model, ths)
+            assert eng.int8 and not eng.pair
+            tok = torch.tensor([[29]], device=DEV, dtype=torch.int)
+            pos = torch.tensor([6], device=DEV, dtype=torch.int)
+            descs = {}
+
+            def hook(when, stage, i):
+                if when == "after" and stage != "attn":
+                    descs[(stage, i)] = L.teal_last_launch_desc().decode()
+
+            bufs = lambda: [b.clone() for b in (eng.s_qkv, eng.att_ws, eng.s_wo, eng.gu, eng.s_down, eng.resid[0], eng.resid[1], eng.logits)]  # noqa: E731
+            L.teal_set_fast(1)
+            eng(tok, pos, hook=hook)
+            lean = bufs()
+            assert len(descs) == 2 * 4 + 1
+            for k, d in descs.items():
+                if k[0] == "head" and model.config.vocab_size > 64 * 1024:
+                    continue  # a 128 k-entry vocabulary takes 256-column tiles: the general kernel
+                assert "gemv_fast_kernel" in d and ",4,true>" in d, (k, d)
+            kept = eng.kept_fractions(tok, pos)
+            assert all(0.2 < v < 0.85 for v in kept.values()), kept
+            L.teal_set_fast(0)
+            eng(tok, pos, hook=hook)
+            assert all("sparse_gemv_kernel<" in d for d in descs.values()), descs
+            for nm, a, b in zip(("s_qkv", "att_ws", "s_wo", "gate|up", "s_down", "resid A", "resid B", "logits"), lean, bufs()):
+                assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), nm
+    finally:
+        L.teal_set_fast(1)
+        del model
+        torch.cuda.empty_cache()
