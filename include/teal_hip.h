@@ -246,6 +246,16 @@ int teal_decode_attention_split_slabs(const float* qkv_slabs, int qkv_nslabs, co
                                       void* k_cache, void* v_cache, void* y, void* mask_out, float mask_tau, int n_head,
                                       int n_kv_head, int head_dim, int max_seq, int nsplit, void* partials,
                                       size_t partials_bytes, int dtype, void* stream);
+/* General form with the caller's workspace: exactly one of qkv (rounded projection) / qkv_slabs (+ qkv_nslabs) is given.
+ * Same launches and results as teal_decode_attention_split / _split_slabs.  Under teal_set_experiment bit 9, with
+ * y != NULL and a workspace prepared by teal_workspace_init(), the merge is FOLDED into the split launch: every workgroup
+ * publishes its partials write-through and takes a ticket on its head's (grouped-query: its KV head's) counter in the
+ * workspace header; the last to arrive merges, rounds, stores y and the masks and re-arms the counter — bit-identical y,
+ * one launch less, but measured no faster than split + merge (equal at 4-8 splits, slower at 16-32), hence not the default. */
+int teal_decode_attention_split_ws(const void* qkv, const float* qkv_slabs, int qkv_nslabs, const void* rope,
+                                   const int32_t* pos, void* k_cache, void* v_cache, void* y, void* mask_out,
+                                   float mask_tau, int n_head, int n_kv_head, int head_dim, int max_seq, int nsplit,
+                                   void* partials, size_t partials_bytes, int dtype, void* ws, size_t ws_bytes, void* stream);
 /* y == NULL: only the partials are written (no merge launch); with nsplit 4 or 8 a TEAL_IN_ATTN_MERGE wo
  * projection merges them in its own prologue (nsplit 4 or 8) — one launch less per layer, and 4 CUs per head pull the KV
  * cache instead of one (a single CU sustains ~50 GB/s, which bounds the one-workgroup-per-head kernel). */
@@ -288,7 +298,8 @@ const char* teal_last_launch_desc(void);
  *        of a DPP row rotate (lane ^ 8) and a ds_swizzle swap (lane ^ 16).  Results are bit-identical either way;
  * bit 3: grouped-query models keep the per-query-head split attention kernel at every cache length;
  * bit 4: the sampler runs as a single workgroup at every vocabulary size;
- * bit 5: no issue-priority ramp over the waves of a workgroup on short row lists. */
+ * bit 5: no issue-priority ramp over the waves of a workgroup on short row lists;
+ * bit 9: teal_decode_attention_split_ws folds the merge into the split launch (prepared workspace; measured no faster). */
 int teal_set_experiment(int mask);
 
 /* Lean kernel for qualifying shapes (default on; 0 forces the general kernel everywhere: A/B and parity tests). */

@@ -56,6 +56,11 @@ def lib() -> ctypes.CDLL:
                                                 c_int, c_int, c_int]
         L.teal_oracle_fast_sparse_gemv.argtypes = [u16p, u16p, u16p, c_float, c_int, c_int, c_int]
         L.teal_oracle_fast_dense_gemv.argtypes = [u16p, u16p, u16p, c_int, c_int, c_int]
+        L.teal_oracle_mat_create.argtypes = [u16p, c_int, c_int, c_int]
+        L.teal_oracle_mat_create.restype = ctypes.c_void_p
+        L.teal_oracle_mat_gemv.argtypes = [ctypes.c_void_p, u16p, u16p, c_float]
+        L.teal_oracle_mat_free.argtypes = [ctypes.c_void_p]
+        L.teal_oracle_mat_free.restype = None
         L.teal_oracle_hash_uniform.argtypes = [u16p, ctypes.c_size_t, ctypes.c_uint32, c_float, c_int]
         L.teal_oracle_num_threads.restype = c_int
         L.teal_oracle_set_threads.argtypes = [c_int]
@@ -203,6 +208,28 @@ def truth64_np(x_bits, wT_bits, Z, N, tau, dtype=F16) -> np.ndarray:
     return (W[keep] * x[keep, None]).sum(axis=0)
 
 
+def pick_threads_resident(x_bits, wT_bits, tau, Z, N, dtype=F16, candidates=(8, 16, 32, 64, 96, 128, 192, 256)) -> int:
+    """OpenMP width for the resident-matrix baseline: the fastest of the candidate widths on one GEMV (a Mat is bound to
+    the width it was created under, so each candidate prepares its own)."""
+    import os
+    import time
+    best, best_t = 1, float("inf")
+    ncpu = os.cpu_count() or 1
+    for n in sorted(set(c for c in candidates if c <= ncpu) | {min(ncpu, 8)}):
+        set_threads(n)
+        m = Mat(wT_bits, Z, N, dtype)
+        m.gemv(x_bits, tau)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            m.gemv(x_bits, tau)
+        t = (time.perf_counter() - t0) / 3
+        m.close()
+        if t < best_t:
+            best, best_t = n, t
+    set_threads(best)
+    return best
+
+
 # ----------------------------------------------------------------------------------------
 # int8 weight-only quantisation (numpy; gpt-fast/quantize.py) — pinned by tests/golden/kat_int8.npz
 # ----------------------------------------------------------------------------------------
@@ -270,6 +297,34 @@ def fast_dense_gemv(x_bits, wT_bits, Z, N, dtype=F16) -> np.ndarray:
     y = np.empty(N, dtype=np.uint16)
     _check(lib().teal_oracle_fast_dense_gemv(_u16(x_bits), _u16(wT_bits), _u16(y), Z, N, dtype), "dense")
     return y
+
+
+class Mat:
+    """Resident-matrix CPU baseline (teal_oracle_mat_*): W^T prepared once — tile-major, each region first touched by the
+    thread that streams it, scratch preallocated — then `gemv(x_bits, tau)` per call (tau < 0: every row, the dense path).
+    The OpenMP width must not change between creation and use."""
+
+    def __init__(self, wT_bits, Z, N, dtype=F16):
+        self.Z, self.N, self.dtype = int(Z), int(N), int(dtype)
+        self._h = lib().teal_oracle_mat_create(_u16(wT_bits), self.Z, self.N, self.dtype)
+        if not self._h:
+            raise MemoryError("teal_oracle_mat_create failed")
+        self._y = np.empty(self.N, dtype=np.uint16)
+
+    def gemv(self, x_bits, tau) -> np.ndarray:
+        _check(lib().teal_oracle_mat_gemv(self._h, _u16(x_bits), _u16(self._y), float(tau)), "mat_gemv")
+        return self._y
+
+    def close(self):
+        if self._h:
+            lib().teal_oracle_mat_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def num_threads() -> int:

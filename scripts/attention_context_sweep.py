@@ -20,9 +20,12 @@ def main():
     ap.add_argument("--voff", type=int, default=0, help="shift every V cache this many bytes into its allocation (DRAM channel phase of K vs V)")
     ap.add_argument("--models", nargs="*", default=["7B", "8B", "70B"])
     ap.add_argument("--ctx", type=int, nargs="*", default=[1024, 4096, 16384])
+    ap.add_argument("--fold", type=int, default=0, help="1: merge folded into the split launch (prepared workspace); 0: split + merge launch")
     a = ap.parse_args()
     L = _lib.load(); runtime.init()
-    L.teal_set_experiment(a.exp)
+    global WSP
+    WSP = runtime.new_workspace(64, 64)
+    L.teal_set_experiment(a.exp | (512 if a.fold else 0))
     dt = torch.float16
     hd = 128
     for name, n_head, n_kv in (("7B", 32, 32), ("8B", 32, 8), ("70B", 64, 8)):
@@ -48,9 +51,11 @@ def main():
                 ws = torch.zeros(n_head * ns * (hd + 2), device="cuda", dtype=torch.float32)
                 st = torch.cuda.Stream()
                 def call(i):
-                    return L.teal_decode_attention_split(qkv.data_ptr(), rope.data_ptr(), p.data_ptr(), kcs[i % nrot].data_ptr(),
-                                                         vcs[i % nrot].data_ptr(), y.data_ptr(), None, 0.0, n_head, n_kv, hd, S, ns,
-                                                         ws.data_ptr(), ws.numel() * 4, 0, st.cuda_stream)
+                    # --fold: prepared workspace -> the merge is folded into the split launch (arrival tickets); else split + merge launch
+                    return L.teal_decode_attention_split_ws(qkv.data_ptr(), None, 0, rope.data_ptr(), p.data_ptr(), kcs[i % nrot].data_ptr(),
+                                                            vcs[i % nrot].data_ptr(), y.data_ptr(), None, 0.0, n_head, n_kv, hd, S, ns,
+                                                            ws.data_ptr(), ws.numel() * 4, 0, WSP.data_ptr() if a.fold else None,
+                                                            WSP.numel() * 4 if a.fold else 0, st.cuda_stream)
                 with torch.cuda.stream(st):
                     rc = call(0)
                     if rc != 0:

@@ -197,6 +197,89 @@ __global__ __launch_bounds__(NT) void decode_attention_kernel(
     stamp_a(5);
 }
 
+// Merge of one head's split-KV partials {m_s, l_s, o_s[hd]} (s < nsplit <= 64), one thread per output column t < hd
+// (whole waves): lane s of every wave holds {m_s, l_s}, so the scale factors cost one load round trip; the o columns are
+// then summed in split order, 32 independent loads at a time.  Same arithmetic, in the same order, as the merge producer
+// of the GEMV launch.  COHERENT: the partials were written by OTHER workgroups of the running launch (the folded merge:
+// write-through stores + arrival ticket), so they are read past this XCD's L2 (agent-scope loads).
+template <bool BF16, bool COHERENT>
+__device__ __forceinline__ void merge_head(const float* __restrict__ p, uint16_t* __restrict__ y_head,
+                                           unsigned long long* __restrict__ mask_head, const float mask_tau, const int hd,
+                                           const int nsplit, const int t, const int lane) {
+    auto ld = [&](const float* q) -> float {
+        if constexpr (COHERENT) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return *q;
+    };
+    float m = -INFINITY, l = 0.0f;
+    if (lane < nsplit) {
+        m = ld(p + (size_t)lane * (hd + 2));
+        l = ld(p + (size_t)lane * (hd + 2) + 1);
+    }
+    const float M = wave_max_f(m);
+    const float f = l > 0.0f ? expf(m - M) : 0.0f;  // empty splits (l == 0, m == -inf) contribute nothing
+    const float lf = l * f;
+    float L = 0.0f, O = 0.0f;
+    constexpr int MB = 32;  // loads per round trip
+    for (int s0 = 0; s0 < nsplit; s0 += MB) {
+        float v[MB];
+#pragma unroll
+        for (int u = 0; u < MB; ++u) v[u] = ld(p + (size_t)min(s0 + u, nsplit - 1) * (hd + 2) + 2 + t);
+#pragma unroll
+        for (int u = 0; u < MB; ++u) {
+            if (s0 + u < nsplit) {  // uniform
+                const float fs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f), s0 + u));
+                const float ls = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf), s0 + u));
+                if (ls > 0.0f) {
+                    L += ls;
+                    O += v[u] * fs;
+                }
+            }
+        }
+    }
+    const uint16_t yb = float_to_bits<BF16>(O / L);
+    y_head[t] = yb;
+    if (mask_head) {
+        const float yv = bits_to_float(yb, BF16);
+        const unsigned long long mk = __ballot(keep_rule(yv, mask_tau) || (yv != yv));
+        if (lane == 0) mask_head[t >> 6] = mk;
+    }
+}
+
+// The merge FOLDED into the split launch (no merge launch): every workgroup of a group (the splits of one head, or of one
+// KV head with its `heads` query heads) publishes its partials write-through, drains, and takes a ticket on the group's
+// counter in the caller's prepared workspace; the last to arrive merges the group's heads and re-arms the counter
+// (gemv_fast_kernel's single-launch split-K uses the same scheme).  `store_partial` must have been used for every store.
+__device__ __forceinline__ void store_partial(float* q, const float v, const bool coherent) {
+    if (coherent) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *q = v;
+}
+template <bool BF16, int NT>
+__device__ __forceinline__ void fold_merge(unsigned* __restrict__ ticket, const int group, const int nsplit, const int head0,
+                                           const int heads, const int hd, const float* __restrict__ partials,
+                                           uint16_t* __restrict__ y, unsigned long long* __restrict__ mask_out,
+                                           const float mask_tau, unsigned* lds_flag) {
+    const int tid = threadIdx.x;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(&ticket[group], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = t == (unsigned)nsplit - 1u;
+        if (last) __hip_atomic_store(&ticket[group], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+        *lds_flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*lds_flag == 0u) return;
+    const int per_pass = NT / hd;  // heads merged at a time: one thread per output column
+    for (int r0 = 0; r0 < heads; r0 += per_pass) {
+        const int r = r0 + tid / hd;
+        if (r < heads && tid < per_pass * hd) {  // whole waves (hd is 64 or 128)
+            const int h = head0 + r;
+            merge_head<BF16, true>(partials + (size_t)h * nsplit * (hd + 2), y + (size_t)h * hd,
+                                   mask_out ? mask_out + ((size_t)h * hd >> 6) : nullptr, mask_tau, hd, nsplit, tid % hd, tid & 63);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Split-KV decode attention (flash-decoding): the cached positions of a head are dealt to `nsplit` workgroups in
 // groups of STEP = (waves x rows per wave) rows, round-robin (group g belongs to workgroup g mod nsplit), so that
@@ -213,9 +296,12 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
     const int* __restrict__ pos_ptr, const float* __restrict__ qkv_slabs, uint16_t* __restrict__ k_cache,
     uint16_t* __restrict__ v_cache, const uint16_t* __restrict__ qkv, float* __restrict__ partials,
     const uint16_t* __restrict__ rope, const int n_head, const int n_kv, const int max_seq, const int nsplit,
-    const float scale, const int qkv_nslabs, unsigned long long* __restrict__ phase, const int exp) {
+    const float scale, const int qkv_nslabs, unsigned long long* __restrict__ phase, const int exp,
+    unsigned* __restrict__ ticket, uint16_t* __restrict__ y, unsigned long long* __restrict__ mask_out, const float mask_tau) {
     constexpr int NW = NT / 64, hd = HD, SL = HD / 8, RW = 64 / SL;
     constexpr int PF = 4, STEP = NW * RW;
+    __shared__ unsigned fold_flag;
+    const bool fold = ticket != nullptr;  // merge folded into this launch (fold_merge): partials are published write-through
     const unsigned long long t_entry = wall_clock64();
     auto stamp_p = [&](const int i) { if (phase && threadIdx.x == 0) phase[(size_t)blockIdx.x * kPhaseRowA + i] = wall_clock64(); };
     extern __shared__ __align__(16) unsigned char smem[];
@@ -280,8 +366,9 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
     if (phase && threadIdx.x == 0) { phase[(size_t)blockIdx.x * kPhaseRowA] = t_entry; phase[(size_t)blockIdx.x * kPhaseRowA + 13] = ((unsigned long long)NW << 32) | gridDim.x; }
     stamp_p(1);
     if (sp * STEP >= n) {  // no row group of this workgroup is in range yet (short sequence, many splits)
-        if (tid < hd) out[2 + tid] = 0.0f;
-        if (tid == 0) { out[0] = -INFINITY; out[1] = 0.0f; }
+        if (tid < hd) store_partial(out + 2 + tid, 0.0f, fold);
+        if (tid == 0) { store_partial(out, -INFINITY, fold); store_partial(out + 1, 0.0f, fold); }
+        if (fold) fold_merge<BF16, NT>(ticket, h, nsplit, h, 1, hd, partials, y, mask_out, mask_tau, &fold_flag);
         return;
     }
     const int nsteps = ((n + STEP - 1) / STEP - sp + nsplit - 1) / nsplit;  // local steps with a row in range
@@ -414,9 +501,10 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
         float acc = 0.0f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) acc += part[w * hd + tid];
-        out[2 + tid] = acc;
+        store_partial(out + 2 + tid, acc, fold);
     }
-    if (tid == 0) { out[0] = mx; out[1] = tot; }
+    if (tid == 0) { store_partial(out, mx, fold); store_partial(out + 1, tot, fold); }
+    if (fold) fold_merge<BF16, NT>(ticket, h, nsplit, h, 1, hd, partials, y, mask_out, mask_tau, &fold_flag);
     stamp_p(7);
 }
 
@@ -496,9 +584,12 @@ __global__ __launch_bounds__(NT) void decode_attention_gqa_kernel(
     const int* __restrict__ pos_ptr, const float* __restrict__ qkv_slabs, uint16_t* __restrict__ k_cache,
     uint16_t* __restrict__ v_cache, const uint16_t* __restrict__ qkv, float* __restrict__ partials,
     const uint16_t* __restrict__ rope, const int n_head, const int n_kv, const int max_seq, const int nsplit,
-    const float scale, const int qkv_nslabs, const int lrows) {
+    const float scale, const int qkv_nslabs, const int lrows, unsigned* __restrict__ ticket, uint16_t* __restrict__ y,
+    unsigned long long* __restrict__ mask_out, const float mask_tau) {
     constexpr int NW = NT / 64, hd = HD, SL = HD / 8, RW = 64 / SL;
     constexpr int PF = 4, STEP = NW * RW;
+    __shared__ unsigned fold_flag;
+    const bool fold = ticket != nullptr;  // merge folded into this launch (fold_merge): partials are published write-through
     constexpr int NPAIR = (REP + 2) * (HD / 2), NITEM = (NPAIR + NT - 1) / NT;  // q pairs of REP heads, k pairs, v pairs
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -559,8 +650,9 @@ __global__ __launch_bounds__(NT) void decode_attention_gqa_kernel(
     const int pos = min(max(pos_ptr[0], 0), max_seq - 1), n = pos + 1;
     auto out_of = [&](const int r) { return partials + ((size_t)(kvh * REP + r) * nsplit + sp) * (hd + 2); };
     if (sp * STEP >= n) {  // no row group of this workgroup is in range yet
-        for (int c = tid; c < REP * hd; c += NT) out_of(c / hd)[2 + (c % hd)] = 0.0f;
-        if (tid < REP) { out_of(tid)[0] = -INFINITY; out_of(tid)[1] = 0.0f; }
+        for (int c = tid; c < REP * hd; c += NT) store_partial(out_of(c / hd) + 2 + (c % hd), 0.0f, fold);
+        if (tid < REP) { store_partial(out_of(tid), -INFINITY, fold); store_partial(out_of(tid) + 1, 0.0f, fold); }
+        if (fold) fold_merge<BF16, NT>(ticket, kvh, nsplit, kvh * REP, REP, hd, partials, y, mask_out, mask_tau, &fold_flag);
         return;
     }
     const int nsteps = ((n + STEP - 1) / STEP - sp + nsplit - 1) / nsplit;
@@ -711,7 +803,7 @@ __global__ __launch_bounds__(NT) void decode_attention_gqa_kernel(
         float acc = 0.0f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) acc += part[w * REP * hd + c];
-        out_of(c / hd)[2 + (c % hd)] = acc;
+        store_partial(out_of(c / hd) + 2 + (c % hd), acc, fold);
     }
     if (tid < REP) {
         float tot = 0.0f;
@@ -720,9 +812,10 @@ __global__ __launch_bounds__(NT) void decode_attention_gqa_kernel(
         float m = red[tid * NW];
 #pragma unroll
         for (int w = 1; w < NW; ++w) m = fmaxf(m, red[tid * NW + w]);
-        out_of(tid)[0] = m;
-        out_of(tid)[1] = tot;
+        store_partial(out_of(tid), m, fold);
+        store_partial(out_of(tid) + 1, tot, fold);
     }
+    if (fold) fold_merge<BF16, NT>(ticket, kvh, nsplit, kvh * REP, REP, hd, partials, y, mask_out, mask_tau, &fold_flag);
 }
 
 // Merge launch (split counts the wo launch's merge producer does not take): one workgroup per head.  Lane s of every
@@ -734,42 +827,10 @@ __global__ __launch_bounds__(128) void decode_attention_merge_kernel(const float
                                                                      uint16_t* __restrict__ y,
                                                                      unsigned long long* __restrict__ mask_out,
                                                                      const float mask_tau, const int hd, const int nsplit) {
-    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const float* p = partials + (size_t)h * nsplit * (hd + 2);
+    const int h = blockIdx.x, tid = threadIdx.x;
     if (tid >= hd) return;  // hd = 64 or 128: whole waves
-    float m = -INFINITY, l = 0.0f;
-    if (lane < nsplit) {
-        m = p[(size_t)lane * (hd + 2)];
-        l = p[(size_t)lane * (hd + 2) + 1];
-    }
-    const float M = wave_max_f(m);
-    const float f = l > 0.0f ? expf(m - M) : 0.0f;  // empty splits (l == 0, m == -inf) contribute nothing
-    const float lf = l * f;
-    float L = 0.0f, O = 0.0f;
-    constexpr int MB = 32;  // loads per round trip
-    for (int s0 = 0; s0 < nsplit; s0 += MB) {
-        float v[MB];
-#pragma unroll
-        for (int u = 0; u < MB; ++u) v[u] = p[(size_t)min(s0 + u, nsplit - 1) * (hd + 2) + 2 + tid];
-#pragma unroll
-        for (int u = 0; u < MB; ++u) {
-            if (s0 + u < nsplit) {  // uniform
-                const float fs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f), s0 + u));
-                const float ls = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf), s0 + u));
-                if (ls > 0.0f) {
-                    L += ls;
-                    O += v[u] * fs;
-                }
-            }
-        }
-    }
-    const uint16_t yb = float_to_bits<BF16>(O / L);
-    y[(size_t)h * hd + tid] = yb;
-    if (mask_out) {
-        const float yv = bits_to_float(yb, BF16);
-        const unsigned long long mk = __ballot(keep_rule(yv, mask_tau) || (yv != yv));
-        if (lane == 0) mask_out[((size_t)h * hd + tid) >> 6] = mk;
-    }
+    merge_head<BF16, false>(partials + (size_t)h * nsplit * (hd + 2), y + (size_t)h * hd,
+                            mask_out ? mask_out + ((size_t)h * hd >> 6) : nullptr, mask_tau, hd, nsplit, tid, tid & 63);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1413,7 +1474,7 @@ int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_
 static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv_nslabs, const void* rope, const int32_t* pos,
                                 void* k_cache, void* v_cache, void* y, void* mask_out, float mask_tau, int n_head,
                                 int n_kv_head, int head_dim, int max_seq, int nsplit, void* partials, size_t partials_bytes,
-                                int dtype, void* stream) {
+                                int dtype, void* ws, size_t ws_bytes, void* stream) {
     if ((!qkv && !qkv_slabs) || !rope || !pos || !k_cache || !v_cache || !partials) return TEAL_ERR_ARG;
     if (qkv_slabs && (qkv_nslabs < 1 || qkv_nslabs > 8 || !aligned16(qkv_slabs))) return TEAL_ERR_ARG;
     if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
@@ -1445,6 +1506,14 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
     // (the per-query-head kernel is 2-3 us faster below ~2 k positions: scripts/attention_context_sweep.py)
     const int rep = n_head / n_kv_head;
     bool gqa = ((rep == 8 && max_seq >= kGqaMinSeq8) || (rep == 4 && max_seq >= kGqaMinSeq)) && !(g_exp & 8);
+    // y requested (the consumer does not merge): the merge can be FOLDED into the split launch — the last workgroup of a head
+    // (or KV-head group) to arrive merges it (prepared workspace) — instead of a merge launch.  MEASURED, NOT FASTER
+    // (profiles/r03_attention_context_sweep.txt): equal at 4-8 splits, 1-7 us slower at 16-32 (the last arriver's drain,
+    // ticket and cross-XCD loads of every split sit behind the slowest workgroup, where the merge launch spreads them over
+    // one workgroup per head).  Off unless teal_set_experiment bit 9 asks for it; bit-identical results either way.
+    unsigned* tk = (y && ws_prepared(ws, ws_bytes) && n_head <= kTicketTiles && (g_exp & 512)) ? ws_tickets(ws) : nullptr;
+    auto* yo = reinterpret_cast<uint16_t*>(y);
+    auto* mo = reinterpret_cast<unsigned long long*>(mask_out);
     if (gqa) {
         constexpr int GNT = 512, GNW = GNT / 64;
         const int gstep = GNW * (64 / (head_dim / 8));
@@ -1454,7 +1523,7 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
         if (glds > (dctx->gqa_lds_ok ? kGqaMaxLds : 64 * 1024)) gqa = false;
         else {
             const dim3 ggrid(n_kv_head * nsplit), gblock(GNT);
-#define TEAL_ATTG(BF, HDV, REPV) hipLaunchKernelGGL((decode_attention_gqa_kernel<BF, HDV, GNT, REPV>), ggrid, gblock, glds, st, pos, qkv_slabs, kc, vc, q, pw, r, n_head, n_kv_head, max_seq, nsplit, scale, qkv_nslabs, glocal)
+#define TEAL_ATTG(BF, HDV, REPV) hipLaunchKernelGGL((decode_attention_gqa_kernel<BF, HDV, GNT, REPV>), ggrid, gblock, glds, st, pos, qkv_slabs, kc, vc, q, pw, r, n_head, n_kv_head, max_seq, nsplit, scale, qkv_nslabs, glocal, tk, yo, mo, mask_tau)
 #define TEAL_ATTG_R(BF, HDV) do { if (rep == 8) TEAL_ATTG(BF, HDV, 8); else TEAL_ATTG(BF, HDV, 4); } while (0)
             if (dtype == TEAL_BF16) { if (head_dim == 128) TEAL_ATTG_R(true, 128); else TEAL_ATTG_R(true, 64); }
             else { if (head_dim == 128) TEAL_ATTG_R(false, 128); else TEAL_ATTG_R(false, 64); }
@@ -1464,7 +1533,7 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
     }
     if (!gqa) {
         if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
-#define TEAL_ATTS(BF, HDV, NTV) hipLaunchKernelGGL((decode_attention_split_kernel<BF, HDV, NTV>), grid, block, lds, st, pos, qkv_slabs, kc, vc, q, pw, r, n_head, n_kv_head, max_seq, nsplit, scale, qkv_nslabs, ph, g_exp)
+#define TEAL_ATTS(BF, HDV, NTV) hipLaunchKernelGGL((decode_attention_split_kernel<BF, HDV, NTV>), grid, block, lds, st, pos, qkv_slabs, kc, vc, q, pw, r, n_head, n_kv_head, max_seq, nsplit, scale, qkv_nslabs, ph, g_exp, tk, yo, mo, mask_tau)
 #define TEAL_ATTS_NT(BF, HDV) do { if (nt == 1024) TEAL_ATTS(BF, HDV, 1024); else TEAL_ATTS(BF, HDV, 256); } while (0)
     if (dtype == TEAL_BF16) { if (head_dim == 128) TEAL_ATTS_NT(true, 128); else TEAL_ATTS_NT(true, 64); }
     else { if (head_dim == 128) TEAL_ATTS_NT(false, 128); else TEAL_ATTS_NT(false, 64); }
@@ -1472,9 +1541,7 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
 #undef TEAL_ATTS
     }
     if (hipGetLastError() != hipSuccess) return TEAL_ERR_LAUNCH;
-    if (!y) return TEAL_OK;  // partials only: the consumer merges (TEAL_IN_ATTN_MERGE)
-    auto* yo = reinterpret_cast<uint16_t*>(y);
-    auto* mo = reinterpret_cast<unsigned long long*>(mask_out);
+    if (!y || tk) return TEAL_OK;  // partials only: the consumer merges (TEAL_IN_ATTN_MERGE) — or merged inside the launch
     if (dtype == TEAL_BF16)
         hipLaunchKernelGGL((decode_attention_merge_kernel<true>), dim3(n_head), dim3(128), 0, st, pw, yo, mo, mask_tau, head_dim, nsplit);
     else
@@ -1487,7 +1554,7 @@ int teal_decode_attention_split(const void* qkv, const void* rope, const int32_t
                                 int max_seq, int nsplit, void* partials, size_t partials_bytes, int dtype, void* stream) {
     if (!qkv) return TEAL_ERR_ARG;
     return attention_split_impl(qkv, nullptr, 0, rope, pos, k_cache, v_cache, y, mask_out, mask_tau, n_head, n_kv_head,
-                                head_dim, max_seq, nsplit, partials, partials_bytes, dtype, stream);
+                                head_dim, max_seq, nsplit, partials, partials_bytes, dtype, nullptr, 0, stream);
 }
 
 int teal_decode_attention_split_slabs(const float* qkv_slabs, int qkv_nslabs, const void* rope, const int32_t* pos,
@@ -1496,7 +1563,16 @@ int teal_decode_attention_split_slabs(const float* qkv_slabs, int qkv_nslabs, co
                                       size_t partials_bytes, int dtype, void* stream) {
     if (!qkv_slabs) return TEAL_ERR_ARG;
     return attention_split_impl(nullptr, qkv_slabs, qkv_nslabs, rope, pos, k_cache, v_cache, y, mask_out, mask_tau, n_head,
-                                n_kv_head, head_dim, max_seq, nsplit, partials, partials_bytes, dtype, stream);
+                                n_kv_head, head_dim, max_seq, nsplit, partials, partials_bytes, dtype, nullptr, 0, stream);
+}
+
+int teal_decode_attention_split_ws(const void* qkv, const float* qkv_slabs, int qkv_nslabs, const void* rope, const int32_t* pos,
+                                   void* k_cache, void* v_cache, void* y, void* mask_out, float mask_tau, int n_head,
+                                   int n_kv_head, int head_dim, int max_seq, int nsplit, void* partials, size_t partials_bytes,
+                                   int dtype, void* ws, size_t ws_bytes, void* stream) {
+    if ((qkv != nullptr) == (qkv_slabs != nullptr)) return TEAL_ERR_ARG;  // exactly one form of the projection
+    return attention_split_impl(qkv, qkv_slabs, qkv_nslabs, rope, pos, k_cache, v_cache, y, mask_out, mask_tau, n_head,
+                                n_kv_head, head_dim, max_seq, nsplit, partials, partials_bytes, dtype, ws, ws_bytes, stream);
 }
 
 int teal_decode_attention(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,

@@ -298,12 +298,14 @@ class DecodeEngine:
         ymask = self.y_mask.data_ptr() if self.pair else None
         cb("before", "attn", i)
         if self.att_split:
-            rc = self.L.teal_decode_attention_split_slabs(self.s_qkv.data_ptr(), self.n_qkv.value, self.rope.data_ptr(), pos_ptr,
-                                                          kc.data_ptr(), vc.data_ptr(),
-                                                          None if self.att_fused_merge else self.y_attn.data_ptr(), ymask, tau_o,
-                                                          cfg.n_head, cfg.n_local_heads, cfg.head_dim, self.max_seq,
-                                                          self.att_split, self.att_ws.data_ptr(), self.att_ws.numel() * 4,
-                                                          self.code, self._stream)
+            # (with y requested — long contexts / grouped-query shapes — the merge is folded into the split launch through the
+            # arrival counters of the engine's workspace: no merge launch)
+            rc = self.L.teal_decode_attention_split_ws(None, self.s_qkv.data_ptr(), self.n_qkv.value, self.rope.data_ptr(), pos_ptr,
+                                                       kc.data_ptr(), vc.data_ptr(),
+                                                       None if self.att_fused_merge else self.y_attn.data_ptr(), ymask, tau_o,
+                                                       cfg.n_head, cfg.n_local_heads, cfg.head_dim, self.max_seq,
+                                                       self.att_split, self.att_ws.data_ptr(), self.att_ws.numel() * 4,
+                                                       self.code, self.ws.data_ptr(), self.ws.numel() * 4, self._stream)
         else:
             rc = self.L.teal_decode_attention_masked(self.qkv.data_ptr(), self.rope.data_ptr(), pos_ptr, kc.data_ptr(), vc.data_ptr(),
                                                      self.y_attn.data_ptr(), ymask, tau_o, cfg.n_head, cfg.n_local_heads,

@@ -385,6 +385,20 @@ def test_decode_attention_split_long_context(dtype):
         bits = (y2.float().abs() > 0.02).view(-1, 64)
         got = torch.stack([(m2 >> i) & 1 for i in range(64)], dim=1).bool()
         assert torch.equal(bits, got)
+        # merge FOLDED into the split launch (arrival tickets in a prepared workspace; teal_decode_attention_split_ws): the same
+        # y and masks, bit for bit, as split + merge launch — three times over, so that the re-armed counters are exercised
+        wsp = runtime.reserve_workspace(64, 64)
+        L.teal_set_experiment(512)  # bit 9: fold on (not the default: measured no faster than split + merge)
+        for it in range(3):
+            kc3, vc3 = kc.clone(), vc.clone()
+            y3, m3 = torch.zeros_like(y1), torch.zeros_like(m1)
+            ws3 = torch.full_like(ws, float("nan"))
+            assert L.teal_decode_attention_split_ws(qkv.data_ptr(), None, 0, rope.data_ptr(), p.data_ptr(), kc3.data_ptr(), vc3.data_ptr(),
+                                                    y3.data_ptr(), m3.data_ptr(), 0.02, n_head, n_kv, hd, S, nsplit, ws3.data_ptr(),
+                                                    ws3.numel() * 4, code, wsp.data_ptr(), wsp.numel() * 4, runtime.stream_ptr()) == 0
+            assert torch.equal(y3.view(torch.int16), y2.view(torch.int16)) and torch.equal(m3, m2), (n_head, n_kv, hd, pos, nsplit, it)
+            assert torch.equal(kc3, kc2) and torch.equal(vc3, vc2)
+        L.teal_set_experiment(0)
 
 
 @pytest.mark.parametrize("name,block,plen,fused", [("tiny-test", 4096, 3000, True), ("tiny-test", 8192, 5000, False),

@@ -150,3 +150,22 @@ def test_int8_quantiser_and_module_match_reference(oracle, golden_dir, tag, dtyp
         assert np.mean(got == want) > 0.9, key
         truth = oracle.int8_truth64(k[f"{tag}_x"], q, k[f"{tag}_scales"], tau, dtype=dtype)
         assert np.all(np.abs(want - truth) <= 1e-3 * np.maximum(1, np.abs(truth)) + 2 * oracle.ulp16(truth, dtype))
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_resident_cpu_baseline_matches_truth(oracle, dtype):
+    """the timed CPU baseline's resident-matrix form (teal_oracle_mat_*: tile-major copy, first-touch placement, no
+    per-call allocation) computes the same masked GEMV as the double-precision truth, sparse and dense, ragged widths too"""
+    O = oracle
+    for Z, N, tau in ((1024, 1536, 0.25), (700, 1000, 0.1), (4096, 4096, -1.0)):
+        x = O.hash_uniform(Z, 31 + Z, 1.0, dtype)
+        W = O.hash_uniform(Z * N, 17 + N, 1.0, dtype)
+        m = O.Mat(W, Z, N, dtype)
+        for t in (tau, -1.0):
+            got = O.from_bits(m.gemv(x, t).copy(), dtype)
+            truth = O.truth64(x, W, Z, N, t, dtype=dtype)
+            ulp = O.ulp16(np.maximum(np.abs(truth), 1e-30), dtype)
+            assert np.all(np.abs(got - truth) <= 1e-3 * np.maximum(1.0, np.abs(truth)) + ulp), (Z, N, t)
+        again = m.gemv(x, tau).copy()
+        assert np.array_equal(again, m.gemv(x, tau))  # deterministic: static schedule, partials summed in block order
+        m.close()
