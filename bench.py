@@ -303,6 +303,10 @@ def pmc_traffic(kernel_desc):
 def cpu_baseline(model, a, budget_s=12.0):
     """Oracle port (fp32 accumulate, OpenMP) on ONE layer's five sparse projections + the dense lm_head,
     inputs U(-.5,.5) with tau = s/2 (kept fraction 1-s), scaled to a whole token."""
+    # the oracle's OpenMP runtime (the system libgomp, not torch's bundled copy) reads these when it first starts: threads
+    # stay where they first touched their share of every matrix
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "threads")
     from oracle import teal_oracle as O
     cfg = model.config
     dt = model.output.weight.dtype
@@ -491,7 +495,7 @@ def main():
                 a_c = argparse.Namespace(**vars(a))
                 a_c.prompt_tokens, a_c.steps, a_c.warmup = ctx, min(a.steps, 60), min(a.warmup, 10)
                 model.config.block_size = max(model.config.block_size, 4096 if ctx > 1900 else 2048)
-                cstep, _ = make_engine_stepper(model, a_c)
+                cstep, _ = make_engine_stepper(model, a_c, ths=info["thresholds"])
                 tc = timed_decode(cstep, a_c.steps, a_c.warmup, 1)
                 out["value_at_context"][str(ctx)] = a_c.steps / tc
                 del cstep

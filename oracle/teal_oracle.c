@@ -458,7 +458,9 @@ int teal_oracle_mat_gemv(void* hv, const uint16_t* x, uint16_t* y, float tau) {
     while (pp < parts) h->first[++pp] = c;
     const int simd = have_avx2();
     const int ntasks = ntiles * parts;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel
+    {
+#pragma omp for schedule(static)
     for (int task = 0; task < ntasks; ++task) {
         const int t = task / parts, p2 = task % parts;
         float acc[TEAL_MAT_TILE];
@@ -479,12 +481,13 @@ int teal_oracle_mat_gemv(void* hv, const uint16_t* x, uint16_t* y, float tau) {
         }
         float* dst = h->partial + ((size_t)p2 * ntiles + t) * TEAL_MAT_TILE;
         for (int j = 0; j < TEAL_MAT_TILE; ++j) dst[j] = acc[j];
-    }
-#pragma omp parallel for schedule(static)
+    }  /* implicit barrier: one fork / join per GEMV */
+#pragma omp for schedule(static)
     for (int n = 0; n < N; ++n) {
         float sacc = 0.0f;
         for (int p2 = 0; p2 < parts; ++p2) sacc += h->partial[(size_t)p2 * ntiles * TEAL_MAT_TILE + n];
         y[n] = store16(sacc, dtype);
+    }
     }
     return 0;
 }

@@ -517,12 +517,15 @@ class DecodeEngine:
         return self.logits.device
 
 
-def make_engine_stepper(model: Transformer, a):
+def make_engine_stepper(model: Transformer, a, ths: Optional[List[Dict[str, float]]] = None):
     """bench.py helper: thresholds (synthetic calibration) + prefill through the module path + the
-    device-resident decode loop (one hipGraph replay per token); returns (step_fn, info)."""
+    device-resident decode loop (one hipGraph replay per token); returns (step_fn, info).  `ths`: start from these
+    thresholds on an already patched model (they are re-taken on the timed decode positions below) instead of the
+    synthetic calibration from scratch, whose forward hooks need the un-patched modules."""
     from . import generate as G
     dev = "cuda"
-    ths = G.apply_sparsity(model, sparsity=a.sparsity, hist_path=None, greedy_lookup=None, synthetic=True)
+    if ths is None:
+        ths = G.apply_sparsity(model, sparsity=a.sparsity, hist_path=None, greedy_lookup=None, synthetic=True)
     npr = int(getattr(a, "prompt_tokens", 6))
     prompt = torch.randint(0, model.config.vocab_size, (npr,), device=dev, dtype=torch.int,
                            generator=torch.Generator(device=dev).manual_seed(7))

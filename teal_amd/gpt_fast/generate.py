@@ -96,10 +96,22 @@ def load_checkpoint_model(checkpoint_path: Path, device: str, dtype: torch.dtype
         from teal_amd.quantize import convert_for_runtime_int8
         print("Using int8 weight-only quantization!")
         convert_for_runtime_int8(model, dtype)
+    int4 = "int4" in str(checkpoint_path)
+    if int4:  # gpt-fast/generate.py:236-242: model_int4.g32.pth -> groupsize 32 (a checkpoint written by teal_amd.quantize:
+        # quantize_model_int4(model).state_dict(); the reference's own int4 files hold a CUDA-only packed layout)
+        from teal_amd.quantize import convert_for_runtime_int4
+        groupsize = int(checkpoint_path.name.split(".")[-2][1:])
+        print("Using int4 weight-only quantization!")
+        convert_for_runtime_int4(model, groupsize)
     ckpt = torch.load(str(checkpoint_path), mmap=True, weights_only=True)
     if "model" in ckpt and "stories" in str(checkpoint_path):
         ckpt = ckpt["model"]
     model.load_state_dict(ckpt, assign=True)
+    if int4:  # packed uint8 weights and bf16 group parameters stay as they are; everything else takes the activation dtype
+        model = model.to(device=device)
+        for prm in model.parameters():
+            prm.data = prm.data.to(dtype)
+        return model.eval()
     if "int8" in str(checkpoint_path):  # keep the int8 buffers int8: only floating tensors take the activation dtype
         model = model.to(device=device)
         for prm in list(model.parameters()) + [b for b in model.buffers() if b.is_floating_point()]:

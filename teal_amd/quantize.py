@@ -178,16 +178,62 @@ class WeightOnlyInt4Linear(nn.Module):
         return m
 
 
-def quantize_model_int4(model: nn.Module, groupsize: int = 32, skip=("output",)) -> nn.Module:
+def int4_kernel_supports(in_features: int, out_features: int, groupsize: int, kv_size: int = 0) -> bool:
+    """Shape contract of teal_sparse_qkv_gemv_i4 (include/teal_hip.h): 128-column tiles (N, and for a fused wqkv the q and
+    kv widths, multiples of 128), whole groups (Z % G == 0, G in 32 / 64 / 128 / 256), Z <= 65536."""
+    return (groupsize in (32, 64, 128, 256) and in_features % groupsize == 0 and in_features <= 65536 and out_features % 128 == 0
+            and kv_size % 128 == 0 and (out_features - 2 * kv_size) % 128 == 0 and out_features - 2 * kv_size > 0)
+
+
+def _int4_eligible(name: str, child: nn.Linear, groupsize: int, kv_size: int) -> bool:
+    return int4_kernel_supports(child.in_features, child.out_features, groupsize, kv_size if name == "wqkv" else 0)
+
+
+def quantize_model_int4(model: nn.Module, groupsize: int = 32, skip=("output",), _kv: int = None) -> nn.Module:
     """Replace the projections' nn.Linear by WeightOnlyInt4Linear in place.  `skip`: child names kept in 16 bits (the
     lm_head: its 32000 / 128256 columns are no multiple of the kernel's 128-column tile for every vocabulary, and the
-    reference's handler pads / skips shapes it cannot pack, quantize.py:404-415)."""
-    for name, child in list(model.named_children()):
+    reference's handler pads / skips shapes it cannot pack, quantize.py:404-415).  A linear whose shape the sparse int4
+    kernel cannot take (teal_sparse_qkv_gemv_i4: 128-column tiles, whole groups) stays in 16 bits too — all five
+    projections of a block then do, so that a block is never half quantised — instead of failing at the first decode step."""
+    if _kv is None:
+        cfg = getattr(model, "config", None)
+        _kv = cfg.n_local_heads * cfg.head_dim if cfg is not None else 0
+    children = list(model.named_children())
+    lin_names = {"wqkv", "wo", "w1", "w2", "w3"}
+    for name, child in children:
         if isinstance(child, nn.Linear) and name not in skip:
             setattr(model, name, WeightOnlyInt4Linear.from_linear(child, groupsize))
             del child
+        elif isinstance(child, nn.Module) and hasattr(child, "attention") and hasattr(child, "feed_forward"):
+            # a transformer block: quantise its five projections together or not at all
+            lins = [(n, getattr(sub, n)) for sub in (child.attention, child.feed_forward) for n in lin_names if isinstance(getattr(sub, n, None), nn.Linear)]
+            if lins and all(_int4_eligible(n, l, groupsize, _kv) for n, l in lins):
+                quantize_model_int4(child, groupsize, skip, _kv)
         else:
-            quantize_model_int4(child, groupsize, skip)
+            quantize_model_int4(child, groupsize, skip, _kv)
+    return model
+
+
+def convert_for_runtime_int4(model: nn.Module, groupsize: int = 32, skip=("output",), _kv: int = None) -> nn.Module:
+    """Replace the projections by EMPTY WeightOnlyInt4Linear modules (role of WeightOnlyInt4QuantHandler.convert_for_runtime,
+    quantize.py:417-443): the shape a state dict written by quantize_model_int4(...).state_dict() loads into — packed
+    `weight` uint8 [Z][N / 2 + 64] (column-gathered nibble image) and `scales_and_zeros` bf16 [Z / G][N][2].
+    NOT interchangeable with the reference's *int4* checkpoints: those hold the CUDA tinygemm tile layout produced by
+    aten._convert_weight_to_int4pack (quantize.py:366-372), which only that kernel reads; scales_and_zeros is the same
+    tensor in both."""
+    if _kv is None:
+        cfg = getattr(model, "config", None)
+        _kv = cfg.n_local_heads * cfg.head_dim if cfg is not None else 0
+    lin_names = {"wqkv", "wo", "w1", "w2", "w3"}
+    for name, child in list(model.named_children()):
+        if isinstance(child, nn.Linear) and name not in skip:
+            setattr(model, name, WeightOnlyInt4Linear(child.in_features, child.out_features, groupsize, device=child.weight.device))
+        elif isinstance(child, nn.Module) and hasattr(child, "attention") and hasattr(child, "feed_forward"):
+            lins = [(n, getattr(sub, n)) for sub in (child.attention, child.feed_forward) for n in lin_names if isinstance(getattr(sub, n, None), nn.Linear)]
+            if lins and all(_int4_eligible(n, l, groupsize, _kv) for n, l in lins):
+                convert_for_runtime_int4(child, groupsize, skip, _kv)
+        else:
+            convert_for_runtime_int4(child, groupsize, skip, _kv)
     return model
 
 

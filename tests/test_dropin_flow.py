@@ -116,6 +116,18 @@ def test_checkpoint_and_histogram_flow(tmp_path, capsys):
     assert len(ri["sequences"][0]) == len(ra["sequences"][0])
     json.dumps(ri["sequences"])  # plain ints
 
+    # (iv) an *int4*.g<G>.pth checkpoint (written by teal_amd.quantize.quantize_model_int4; the reference's own int4 files
+    # hold a CUDA-only packed layout) takes the int4 branch with the group size parsed from the name (generate.py:236-242)
+    from teal_amd.quantize import quantize_model_int4
+    q4 = quantize_model_int4(G.build_synthetic_model("tiny-test", DEV, torch.float16, seed=21, std=0.05), 32)
+    torch.save(q4.state_dict(), ck / "model_int4.g32.pth")
+    del q4
+    capsys.readouterr()
+    r4 = G.main(_args(G, compile=True, **dict(common, checkpoint_path=ck / "model_int4.g32.pth")))
+    out = capsys.readouterr().out
+    assert "Using int4 weight-only quantization!" in out and r4["thresholds"] == ra["thresholds"]
+    assert len(r4["sequences"][0]) == len(ra["sequences"][0])
+
 
 def test_monkeypatch_layer_llama2_7b_width_with_committed_histograms():
     """monkeypatch_layer on a Llama-2-7B-width block with the reference's own Llama-2-7B histograms (layers 0 and 15,

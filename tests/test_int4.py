@@ -126,3 +126,38 @@ def test_int4_model_decode_matches_dequantised_dense():
         a1 = m(t, torch.tensor([6], device=DEV))   # decode: teal::sparse_gemv_int4 op by op
         b1 = ref(t, torch.tensor([6], device=DEV))
         assert torch.allclose(a1.float(), b1.float(), atol=3e-2, rtol=5e-2)
+
+
+def test_int4_model_quantiser_respects_the_kernel_shape_contract(tmp_path):
+    """quantize_model_int4 only converts blocks whose five projections the sparse int4 kernel can take (128-column tiles,
+    whole groups; teal_sparse_qkv_gemv_i4) — a model like stories15M (dim 288) stays in 16 bits instead of failing with
+    TEAL_ERR_SHAPE at the first decode step (round-2 advice) — and convert_for_runtime_int4 builds the modules a saved
+    int4 state dict loads into (the loader's *int4* branch, gpt-fast/generate.py:236-242)."""
+    from teal_amd.gpt_fast import generate as G
+    from teal_amd.quantize import (WeightOnlyInt4Linear, convert_for_runtime_int4, int4_kernel_supports, is_int4,
+                                   quantize_model_int4)
+    assert int4_kernel_supports(4096, 12288, 32, 4096) and int4_kernel_supports(4096, 6144, 128, 1024)
+    assert not int4_kernel_supports(288, 864, 32, 288) and not int4_kernel_supports(4096, 4096, 48)
+    assert not int4_kernel_supports(4096, 4160, 32, 32)
+    small = quantize_model_int4(G.build_synthetic_model("stories15M", "cpu", torch.float16, seed=1), 32)
+    assert not any(isinstance(m, WeightOnlyInt4Linear) for m in small.modules())
+    m = quantize_model_int4(G.build_synthetic_model("tiny-test", "cpu", torch.float16, seed=1), 32)
+    lay = m.layers[0]
+    assert all(is_int4(l) for l in (lay.attention.wqkv, lay.attention.wo, lay.feed_forward.w1, lay.feed_forward.w3, lay.feed_forward.w2))
+    assert not is_int4(m.output)  # lm_head stays in 16 bits
+    path = tmp_path / "tiny-test" / "model_int4.g32.pth"
+    path.parent.mkdir()
+    torch.save(m.state_dict(), path)
+    m2 = G.load_checkpoint_model(path, "cpu", torch.float16)
+    assert is_int4(m2.layers[1].feed_forward.w2) and m2.layers[1].feed_forward.w2.groupsize == 32
+    for (ka, va), (kb, vb) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka
+    assert m2.output.weight.dtype == torch.float16 and m2.layers[0].attention.wqkv.scales_and_zeros.dtype == torch.bfloat16
+    # dense forward of the loaded model = the quantised model's (dequantised matmul)
+    m.setup_caches(1, 16)
+    m2.setup_caches(1, 16)
+    toks = torch.randint(0, 512, (5,), dtype=torch.int)
+    with torch.no_grad():
+        a = m(toks.view(1, -1), torch.arange(5))
+        b = m2(toks.view(1, -1), torch.arange(5))
+    assert torch.equal(a, b)
