@@ -61,6 +61,8 @@ def lib() -> ctypes.CDLL:
         L.teal_oracle_mat_gemv.argtypes = [ctypes.c_void_p, u16p, u16p, c_float]
         L.teal_oracle_mat_free.argtypes = [ctypes.c_void_p]
         L.teal_oracle_mat_free.restype = None
+        L.teal_oracle_host_read_gbs.argtypes = [ctypes.c_size_t, c_int]
+        L.teal_oracle_host_read_gbs.restype = ctypes.c_double
         L.teal_oracle_hash_uniform.argtypes = [u16p, ctypes.c_size_t, ctypes.c_uint32, c_float, c_int]
         L.teal_oracle_num_threads.restype = c_int
         L.teal_oracle_set_threads.argtypes = [c_int]
@@ -325,6 +327,11 @@ class Mat:
             self.close()
         except Exception:
             pass
+
+
+def host_read_gbs(nbytes: int = 2 << 30, reps: int = 3) -> float:
+    """GB/s of a plain parallel sum over `nbytes` of first-touched memory at the current OpenMP width (the host's ceiling)."""
+    return float(abs(lib().teal_oracle_host_read_gbs(int(nbytes), int(reps))))
 
 
 def num_threads() -> int:

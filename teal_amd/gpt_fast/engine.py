@@ -77,7 +77,7 @@ class DecodeEngine:
     """
 
     @staticmethod
-    def supports(model: Transformer) -> Optional[str]:
+    def supports(model: Transformer, need_caches: bool = True) -> Optional[str]:
         """None if the fused step can run `model` as it stands, else the reason it cannot (the caller then keeps the
         op-by-op module path, which handles every shape torch does).  Mirrors the shape contracts of the launches:
         teal_decode_attention* (head_dim 64 / 128, [1][n_kv][max_seq][hd] caches), the register-resident RMSNorm
@@ -100,6 +100,8 @@ class DecodeEngine:
             return f"dim {cfg.dim} (need a multiple of 64, <= 16384, = n_head * head_dim)"
         if cfg.intermediate_size % 8 or cfg.intermediate_size > 65536 or kv % 8 or cfg.vocab_size % 8:
             return "intermediate_size / kv width / vocab_size must be multiples of 8 (intermediate_size <= 65536)"
+        if not need_caches:  # a static verdict (shapes and weight formats), before setup_caches has run
+            return None if model.output.weight.is_cuda else "model is not on a HIP device"
         if model.freqs_cis is None or model.freqs_cis.dtype != dt:
             return "caches are not set up (model.setup_caches) in the model dtype"
         for layer in model.layers:

@@ -436,6 +436,14 @@ def main(args) -> Dict:
     model_size = _get_model_size(model)
     decoder = GraphedDecoder(model, args.compile, args.temperature, args.top_k)
     use_engine = args.engine or (args.compile and thresholds is not None and not getattr(args, "no_engine", False))
+    if use_engine and not args.engine:
+        # --compile implies the device-resident engine loop only for models the fused step can run (int4 blocks, head_dim 48,
+        # ... decode through the patched modules under the same hipGraph capture instead)
+        from teal_amd.gpt_fast.engine import DecodeEngine
+        why = DecodeEngine.supports(model, need_caches=False)
+        if why is not None:
+            print(f"fused engine not used: {why}")
+            use_engine = False
     if use_engine:
         assert thresholds is not None, "--engine needs thresholds (--hist_path or --synthetic)"
         decoder = EngineDecoder(model, thresholds, args.compile, args.temperature, args.top_k)
