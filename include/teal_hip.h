@@ -18,6 +18,7 @@
  *   teal_sample_topk       <- gpt-fast/generate.py:49-66      logits_to_probs + multinomial_sample_one
  *   teal_sparse_qkv_gemv_i8 <- gpt-fast/quantize.py:339-357   WeightOnlyInt8Linear.forward on the masked x
  *   teal_sparse_qkv_gemv_i4 <- gpt-fast/quantize.py:58-162,483-526 group-quantised int4 linear on the masked x
+ *   teal_cmp_flag_gemv     <- scripts/benchmark_gemv.py:32-107,170-172 the Deja Vu comparator of the kernel benchmark
  *
  * Conventions
  *   - extern "C", plain pointers and sizes, no C++/torch types, no exceptions across the boundary.
@@ -275,6 +276,14 @@ int teal_sample_topk(const void* logits, int vocab, int dtype, int top_k, float 
 int teal_sample_topk_ws(const void* logits, int vocab, int dtype, int top_k, float temperature, void* rng_state,
                         int32_t* token_out, int32_t* pos_inout, int32_t* history, int history_len, void* ws,
                         size_t ws_bytes, void* stream);
+
+/* ---- benchmark comparator (scripts/benchmark_gemv.py only; not on the decode path) ----------- */
+
+/* The Deja Vu gather GEMV the reference's kernel benchmark plots next to TEAL's (scripts/benchmark_gemv.py:32-107,170-172),
+ * restated for CDNA4: flags[m] = |x[m]| > tau by a launch of its own, y32 zeroed, then a (row block, column tile) grid adds
+ * fp32 partial sums of the flagged rows into y32 with atomics.  y32: fp32 [N]; flags: Z bytes of scratch.  Three launches. */
+int teal_cmp_flag_gemv(const void* x, const void* wT, int ld, float* y32, unsigned char* flags, float tau, int Z, int N,
+                       int dtype, void* stream);
 
 /* ---- tuning / introspection ------------------------------------------------------------------ */
 

@@ -343,3 +343,23 @@ def test_c_abi_error_codes():
         import teal_amd.kernels as k
         k.splitk_sparse_gemv(torch.zeros(1, 1, 64, device=DEV), torch.zeros(64, 64, device=DEV).T.contiguous().T, 0.1, 0)
     torch.cuda.synchronize()
+
+
+def test_deja_vu_comparator_computes_the_same_masked_gemv():
+    """the benchmark's Deja Vu comparator (teal_cmp_flag_gemv: precomputed flags, fp32 atomics into a zeroed output;
+    scripts/benchmark_gemv.py:32-107 of the reference) against the product kernel on the benchmark's input law"""
+    from teal_amd import _lib, runtime
+    L = _lib.load()
+    runtime.init()
+    for Z, N, ld, tau in ((4096, 4096, 4160, 0.25), (1000, 520, 520, 0.1), (4096, 14336, 14400, -1.0)):
+        g = torch.Generator(device=DEV).manual_seed(Z + N)
+        x = (torch.rand(Z, device=DEV, generator=g) - 0.5).half()
+        buf = torch.zeros(Z, ld, device=DEV, dtype=torch.float16)
+        buf[:, :N] = (torch.rand(Z, N, device=DEV, generator=g) - 0.5).half()
+        y32 = torch.full((N,), 7.0, device=DEV, dtype=torch.float32)
+        flags = torch.zeros(Z, device=DEV, dtype=torch.uint8)
+        assert L.teal_cmp_flag_gemv(x.data_ptr(), buf.data_ptr(), ld, y32.data_ptr(), flags.data_ptr(), tau, Z, N, 0, runtime.stream_ptr()) == 0
+        keep = x.float().abs() > tau
+        assert torch.equal(flags.bool(), keep)
+        want = (buf[:, :N].double() * (x.double() * keep)[:, None]).sum(0)
+        assert torch.allclose(y32.double(), want, atol=1e-3, rtol=1e-4), float((y32.double() - want).abs().max())
