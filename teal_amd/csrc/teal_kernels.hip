@@ -483,7 +483,7 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
         if (fast_eligible(p, c, to_ws, ws_bytes, f)) {
             snprintf(g_last_desc, sizeof g_last_desc, "gemv_fast_kernel<%s,%d,%s,%d,%d,%s,false%s> grid (%d,%d) x 1024",
                      dtype == TEAL_BF16 ? "true" : "false", f.mode, f.pair ? "true" : "false", f.lpr, f.kr,
-                     (f.mode == 1 && f.Z == 1024 * f.kr) ? "true" : "false", f.w8 ? ",4,true" : "", f.ntiles, f.split);
+                     (f.mode == 1 && f.Z == 1024 * f.kr) ? "true" : "false", f.w8 ? ",4,true" : ",4,false", f.ntiles, f.split);
             const hipError_t e = f.w8 ? (dtype == TEAL_BF16 ? launch_fast_w8_bf16(f, st) : launch_fast_w8_f16(f, st))
                                       : (dtype == TEAL_BF16 ? launch_fast_bf16(f, st) : launch_fast_f16(f, st));
             return e == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
