@@ -46,8 +46,9 @@ def parse():
     ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--sparsity", type=float, default=0.5)
     ap.add_argument("--prompt_tokens", type=int, default=6, help="prefill length (the headline config uses the reference's 6-token prompt)")
-    ap.add_argument("--weights", default="16bit", choices=["16bit", "int8"],
-                    help="int8 = weight-only int8 projections + lm_head (teal_amd/quantize.py); NOT the headline config")
+    ap.add_argument("--weights", default="16bit", choices=["16bit", "int8", "int4"],
+                    help="int8 = weight-only int8 projections + lm_head; int4 = group-quantised (g32) projections, 16-bit lm_head "
+                         "(teal_amd/quantize.py); NOT the headline config")
     ap.add_argument("--pair", type=int, default=None, help="engine: 1/0 force the fused gate|up PAIR launch on/off (A/B)")
     ap.add_argument("--tuning", default="", help="lpr,waves,split,unroll override for every GEMV launch (A/B sweeps)")
     ap.add_argument("--att_split", type=int, default=0, help="override the engine's split-KV factor (A/B; 0 = automatic)")
@@ -427,6 +428,11 @@ def main():
         quantize_model_int8(model)
         torch.cuda.empty_cache()
         assert mode == "engine"
+    if a.weights == "int4":
+        from teal_amd.quantize import quantize_model_int4
+        quantize_model_int4(model, 32)
+        torch.cuda.empty_cache()
+        assert mode == "engine"
     cfg = model.config
     extra = {}
     if mode == "engine":
@@ -448,6 +454,10 @@ def main():
         out["metric"] = out["metric"].replace("fp16", "int8-weight/fp16-activation")
         out["dtype"] = out["dtype"] + " activations, int8 weights (per-channel scales)"
         out["config"]["workload"] += ", int8 weight-only"
+    if a.weights == "int4":
+        out["metric"] = out["metric"].replace("fp16", "int4-g32-weight/fp16-activation")
+        out["dtype"] = out["dtype"] + " activations, int4 group-quantised weights (g32), 16-bit lm_head"
+        out["config"]["workload"] += ", int4 weight-only (Int4DecodeEngine: 10 launches per layer)"
     out.update(info.get("report", {}))
     if rank == 0 and mode == "engine":
         eng = info["engine"]
@@ -462,7 +472,10 @@ def main():
             out["tokens_per_sec_reference_definition"] = 200.0 / (t_pf + 200.0 * t / a.steps)
             out["prefill_ms"] = t_pf * 1e3
     if rank == 0 and world == 1:
-        out["roofline"] = roofline_engine_gateup(info["engine"], a) if mode == "engine" else roofline_dominant_kernel(model, a)
+        if a.weights == "int4":
+            out["roofline"] = None  # (the roofline object describes the 16-bit / int8 engine's dominant launch)
+        else:
+            out["roofline"] = roofline_engine_gateup(info["engine"], a) if mode == "engine" else roofline_dominant_kernel(model, a)
         if not a.no_dense:
             # dense comparator on the same harness: same kernels with every row kept (threshold < 0)
             a_d = argparse.Namespace(**vars(a))
@@ -479,7 +492,7 @@ def main():
             out["speedup_vs_dense"] = tps / dense_tps
             out["dense_comparator"] = ("the same fused engine with every row kept (thresholds < 0: same kernels, same launches) — "
                                        "the strongest dense fp16 path on this box; the reference's own dense path follows")
-            if mode == "engine" and a.weights != "int8":
+            if mode == "engine" and a.weights == "16bit":
                 # the reference's dense path as it exists here: the un-patched gpt-fast model (torch.matmul / hipBLASLt,
                 # eager glue; no Inductor on this image) under the same hipGraph capture
                 rmodel = G.build_synthetic_model(a.model, "cuda", dt, n_layer=a.n_layer)
@@ -490,7 +503,7 @@ def main():
                 out["speedup_vs_reference_dense_path"] = tps / (nref / tr)
                 del rmodel, rstep
                 torch.cuda.empty_cache()
-        if mode == "engine" and not a.no_context_sweep and a.prompt_tokens < 500:
+        if mode == "engine" and not a.no_context_sweep and a.prompt_tokens < 500 and a.weights != "int4":
             # The headline decodes at the reference's default prompt (6 tokens): cache positions 6..~230, the short-context
             # best case of the attention launch.  Same model, same thresholds law, longer contexts (a prefill of that many
             # random tokens through the module path, thresholds re-taken on the timed decode positions):
@@ -507,7 +520,7 @@ def main():
                 torch.cuda.empty_cache()
             out["value_at_context_note"] = ("tokens/s of the same decode step with ~1000 / ~3800 cached positions (block_size raised to "
                                             "4096 for the latter); `value` is the reference's default 6-token prompt")
-        if not a.no_cpu_baseline and a.weights != "int8":
+        if not a.no_cpu_baseline and a.weights == "16bit":
             out["cpu_baseline"] = cpu_baseline(model, a)
     elif rank == 0:
         out["roofline"] = None

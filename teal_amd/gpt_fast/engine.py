@@ -543,7 +543,11 @@ def make_engine_stepper(model: Transformer, a, ths: Optional[List[Dict[str, floa
         torch.cuda.synchronize()
         prefill_s = time.perf_counter() - t0
         tok = G.sample(logits, temperature=0.8, top_k=200)[0]
-        eng = DecodeEngine(model, ths, att_split=int(getattr(a, "att_split", 0)), pair=getattr(a, "pair", None))
+        from .engine_int4 import pick_engine
+        cls, why = pick_engine(model)
+        if cls is None:
+            raise ValueError(f"no fused engine for this model: {why}")
+        eng = cls(model, ths, att_split=int(getattr(a, "att_split", 0)), pair=getattr(a, "pair", None))
         span = min(a.warmup + a.steps + 4, eng.max_seq - npr)
         if a.sparsity > 0 and getattr(a, "decode_calibration", True):
             # thresholds for the kept fraction ON THE MEASURED DECODE POSITIONS (apply_sparsity's synthetic mode already

@@ -175,13 +175,15 @@ def refine_thresholds_on_decode(model: Transformer, sparsities: Dict[str, List[f
         return ths
     model.max_seq_length, model.max_batch_size = -1, -1
     model.setup_caches(max_batch_size=1, max_seq_length=n_prompt + span + 8)
-    if DecodeEngine.supports(model) is not None:  # e.g. head_dim 48: the module path decodes it, with the prefill thresholds
+    from teal_amd.gpt_fast.engine_int4 import pick_engine
+    cls, _why = pick_engine(model)
+    if cls is None:  # e.g. head_dim 48: the module path decodes it, with the prefill thresholds
         model.max_seq_length, model.max_batch_size = -1, -1
         return ths
     toks = torch.randint(0, model.config.vocab_size, (n_prompt,), device=dev, dtype=torch.int,
                          generator=torch.Generator(device=dev).manual_seed(97))
     model(toks.view(1, -1), torch.arange(n_prompt, device=dev))
-    eng = DecodeEngine(model, ths)
+    eng = cls(model, ths)
     ths = eng.calibrate_on_decode(sparsities, toks[-1:].clone(), n_prompt, span)
     for layer, th in zip(model.layers, ths):
         at, ff = layer.attention, layer.feed_forward
@@ -212,8 +214,7 @@ def apply_sparsity(model: Transformer, *, sparsity: float, hist_path: Optional[s
         ths = calibrate_thresholds(model, sparsities)
         for i, layer in enumerate(model.layers):
             monkeypatch_layer(i, layer, sparsity, None, device, thresholds=ths[i])
-        int4 = hasattr(model.layers[0].attention.wqkv, "scales_and_zeros")  # int4 blocks run op by op: no fused engine
-        if decode_calibration and device == "cuda" and not int4 and any(float(v) > 0 for vals in sparsities.values() for v in vals):
+        if decode_calibration and device == "cuda" and any(float(v) > 0 for vals in sparsities.values() for v in vals):
             ths = refine_thresholds_on_decode(model, sparsities, ths)
     else:
         ths = [monkeypatch_layer(i, layer, sparsity, hist_path, device, sparsities=sparsities)
@@ -369,8 +370,11 @@ class EngineDecoder:
         # (same size or not), not only when the context length changed
         key = self._cache_key()
         if self._engine is None or self._key != key:
-            from teal_amd.gpt_fast.engine import DecodeEngine
-            self._engine, self._key = DecodeEngine(self.torch_model, self.thresholds), key
+            from teal_amd.gpt_fast.engine_int4 import pick_engine
+            cls, why = pick_engine(self.torch_model)
+            if cls is None:
+                raise ValueError(f"no fused engine for this model: {why}")
+            self._engine, self._key = cls(self.torch_model, self.thresholds), key
         return self._engine
 
 
@@ -439,8 +443,8 @@ def main(args) -> Dict:
     if use_engine and not args.engine:
         # --compile implies the device-resident engine loop only for models the fused step can run (int4 blocks, head_dim 48,
         # ... decode through the patched modules under the same hipGraph capture instead)
-        from teal_amd.gpt_fast.engine import DecodeEngine
-        why = DecodeEngine.supports(model, need_caches=False)
+        from teal_amd.gpt_fast.engine_int4 import pick_engine
+        _, why = pick_engine(model, need_caches=False)
         if why is not None:
             print(f"fused engine not used: {why}")
             use_engine = False
@@ -452,7 +456,8 @@ def main(args) -> Dict:
         from teal_amd.monkeypatch import UP_SHIFT_BYTES, to_column_major
         for layer in model.layers:
             for lin in (layer.attention.wqkv, layer.attention.wo, layer.feed_forward.w1, layer.feed_forward.w3, layer.feed_forward.w2):
-                to_column_major(lin, shift_bytes=UP_SHIFT_BYTES if lin is layer.feed_forward.w3 else 0)
+                if not hasattr(lin, "scales_and_zeros"):  # (an int4 image is packed column-gathered already)
+                    to_column_major(lin, shift_bytes=UP_SHIFT_BYTES if lin is layer.feed_forward.w3 else 0)
         to_column_major(model.output)
     prefill = GraphedPrefill(model) if getattr(args, "compile_prefill", False) else None
     tps, seqs = [], []

@@ -267,8 +267,6 @@ class Transformer(nn.Module):
             at, ff = layer.attention, layer.feed_forward
             if not (hasattr(at, "thresh_q") and hasattr(at, "gemv1") and hasattr(ff, "thresh_gate") and hasattr(ff, "gemv2")):
                 return None
-            if getattr(at, "int4", False):  # int4 projections run op by op (the fused step covers 16-bit and int8 weights)
-                return None
             ths.append({"q": float(at.thresh_q), "k": float(at.thresh_k), "v": float(at.thresh_v), "o": float(at.thresh_o),
                         "gate": float(ff.thresh_gate), "up": float(ff.thresh_up), "down": float(ff.thresh_down)})
         return ths
@@ -293,11 +291,11 @@ class Transformer(nn.Module):
             return None
         key = self._engine_key(ths)
         if getattr(self, "_eng_key", None) != key:
-            from .engine import DecodeEngine
-            why = DecodeEngine.supports(self)
+            from .engine_int4 import pick_engine
+            cls, why = pick_engine(self)  # DecodeEngine (16-bit / int8 weights), Int4DecodeEngine, or a reason for neither
             object.__setattr__(self, "_eng_why", why)
             # not a submodule: the engine only borrows this model
-            object.__setattr__(self, "_eng", None if why is not None else DecodeEngine(self, ths))
+            object.__setattr__(self, "_eng", None if cls is None else cls(self, ths))
             self._eng_key = self._engine_key(ths)  # after the build: the engine re-lays lm_head out column-major
         return self._eng
 

@@ -161,3 +161,52 @@ def test_int4_model_quantiser_respects_the_kernel_shape_contract(tmp_path):
         a = m(toks.view(1, -1), torch.arange(5))
         b = m2(toks.view(1, -1), torch.arange(5))
     assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,sparsity", [(torch.float16, 0.0), (torch.bfloat16, 0.0), (torch.float16, 0.5)])
+def test_int4_engine_matches_int4_module_path(dtype, sparsity):
+    """Int4DecodeEngine (glue launches + int4 sparse GEMVs through the C ABI, one hipGraph replay per token) against the
+    op-by-op module path on the same int4 blocks: equal to rounding with every row kept, cosine > 0.98 at 50 % (near-tau
+    activations may flip); the captured step replays bit-identically; a single-token call of the patched model uses it."""
+    from teal_amd.gpt_fast import generate as G
+    from teal_amd.gpt_fast.engine_int4 import Int4DecodeEngine, pick_engine
+    from teal_amd.quantize import quantize_model_int4
+    ref = quantize_model_int4(G.build_synthetic_model("tiny-test", DEV, dtype, seed=3, std=0.05), 32)
+    ref.fused_decode = False  # op-by-op module path
+    eng_m = quantize_model_int4(G.build_synthetic_model("tiny-test", DEV, dtype, seed=3, std=0.05), 32)
+    ths = G.apply_sparsity(ref, sparsity=sparsity, hist_path=None, greedy_lookup=None, synthetic=True)
+    G.apply_sparsity(eng_m, sparsity=sparsity, hist_path=None, greedy_lookup=None, synthetic=True, decode_calibration=False)
+    prompt = torch.tensor([5, 17, 301, 44, 9], device=DEV, dtype=torch.int)
+    with torch.no_grad():
+        for m in (ref, eng_m):
+            m.max_seq_length = -1
+            m.setup_caches(1, 64)
+            m(prompt.view(1, -1), torch.arange(5, device=DEV))
+        assert pick_engine(eng_m)[0] is Int4DecodeEngine
+        eng = Int4DecodeEngine(eng_m, ths)
+        for step, tok_id in enumerate((7, 100, 3)):
+            tok = torch.tensor([[tok_id]], device=DEV, dtype=torch.int)
+            pos = torch.tensor([5 + step], device=DEV, dtype=torch.int)
+            a, b = ref(tok, pos).float().view(-1), eng(tok, pos).float().view(-1)
+            if sparsity == 0.0:
+                tol = 8e-3 if dtype == torch.float16 else 6e-2
+                assert torch.allclose(a, b, atol=tol, rtol=tol), (step, float((a - b).abs().max()))
+            else:
+                assert torch.nn.functional.cosine_similarity(a, b, dim=0) > 0.98
+        for la, lb in zip(ref.layers, eng_m.layers):  # both appended the same K/V rows
+            if sparsity == 0.0:
+                tolk = 2e-2 if dtype == torch.float16 else 8e-2
+                assert torch.allclose(la.attention.kv_cache.k_cache.float(), lb.attention.kv_cache.k_cache.float(), atol=tolk, rtol=2e-2)
+        # the device-resident loop: one hipGraph replay per token, same tokens as eager launches
+        first = torch.tensor([11], device=DEV, dtype=torch.int)
+        eng.manual_seed(5)
+        t_graph = eng.decode_n(first, 8, 6, temperature=0.8, top_k=50, use_graph=True)
+        eng.manual_seed(5)
+        t_eager = eng.decode_n(first, 8, 6, temperature=0.8, top_k=50, use_graph=False)
+        assert torch.equal(t_graph, t_eager)
+        kept = eng.kept_fractions(torch.tensor([[7]], device=DEV, dtype=torch.int), torch.tensor([14], device=DEV, dtype=torch.int))
+        assert set(kept) == set(eng.SITE) and all(0.0 <= v <= 1.0 for v in kept.values())
+        # a single-token call of the patched model takes the same engine
+        eng_m(torch.tensor([[7]], device=DEV, dtype=torch.int), torch.tensor([15], device=DEV))
+        assert isinstance(eng_m._eng, Int4DecodeEngine)
