@@ -277,6 +277,16 @@ int teal_sample_topk_ws(const void* logits, int vocab, int dtype, int top_k, flo
                         int32_t* token_out, int32_t* pos_inout, int32_t* history, int history_len, void* ws,
                         size_t ws_bytes, void* stream);
 
+/* The two element-wise steps of a decode layer as launches of their own, for weight formats whose GEMV takes a plain activation
+ * (the int4 kernel; teal_amd/gpt_fast/engine_int4.py); the 16-bit / int8 engines fold them into the GEMV launches as producers.
+ *   teal_resid_rmsnorm: h = resid_in (+ add, rounded); x_out = RMSNorm(h) * norm_weight; resid_out = h (optional, must not alias
+ *                       resid_in); row_index = optional device int32, row = row_index[0] of resid_in (embedding lookup); Z <= 16384.
+ *                       gpt-fast/model.py:158-161,289-291
+ *   teal_silu_mul:      h = silu(gate) * up with the roundings of the unfused sequence.               gpt-fast/model.py:258-259 */
+int teal_resid_rmsnorm(const void* resid_in, const int32_t* row_index, const void* add, const void* norm_weight, float eps,
+                       void* resid_out, void* x_out, int Z, int dtype, void* stream);
+int teal_silu_mul(const void* gate, const void* up, void* h, int Z, int dtype, void* stream);
+
 /* ---- benchmark comparator (scripts/benchmark_gemv.py only; not on the decode path) ----------- */
 
 /* The Deja Vu gather GEMV the reference's kernel benchmark plots next to TEAL's (scripts/benchmark_gemv.py:32-107,170-172),
