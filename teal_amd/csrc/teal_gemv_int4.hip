@@ -87,13 +87,21 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const Int4Args a
                 const float x2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), b[2]));
                 const float x3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), b[3]));
                 xr[r] = okr ? (rs == 0 ? x0 : (rs == 1 ? x1 : (rs == 2 ? x2 : x3))) : 0.0f;
-                d[r] = 0x88888888u;  // q = 8 everywhere: contributes x * 8 to A and x to X, i.e. nothing, and xr is 0 anyway
+                d[r] = 0x88888888u;  // (a row that is not there: its x is 0, so it adds nothing to A or X)
                 if (okr) d[r] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(wp + (size_t)(row0 + br) * a.ldb));
             }
+            // The launch is bound by vector-ALU issue, not by memory (25 us for 17 MB at 7B shapes): nibble -> float as
+            // bfe + cvt + fma costs 3 instructions per weight.  Two nibbles at a time become halves without a conversion:
+            // (d >> 4j) & 0x000F000F under the exponent bits 0x6400 is the pair {1024 + q_j, 1024 + q_(j+4)} (the byte trick of
+            // the int8 kernel, teal_gemv_kernel.h), consumed by the mixed-precision FMA; the constant leaves with X below.
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) A[k] = fmaf((float)((d[r] >> (4 * k)) & 15u), xr[r], A[k]);
+                for (int j = 0; j < 4; ++j) {
+                    const f16x2 hq = __builtin_bit_cast(f16x2, ((d[r] >> (4 * j)) & 0x000F000Fu) | 0x64006400u);
+                    A[j] = fmaf((float)hq.x, xr[r], A[j]);
+                    A[j + 4] = fmaf((float)hq.y, xr[r], A[j + 4]);
+                }
                 X += xr[r];
             }
         }
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const Int4Args a
         for (int k = 0; k < 8; ++k) {
             const uint32_t pr = k < 4 ? sz0[k] : sz1[k - 4];  // bf16 pair: scale (low half), zero (high half)
             const float sc = __uint_as_float(pr << 16), zr = __uint_as_float(pr & 0xFFFF0000u);
-            total[k] += sc * (A[k] - 8.0f * X) + zr * X;
+            total[k] += sc * (A[k] - 1032.0f * X) + zr * X;  // A carries 1024 + q: (q - 8) = (1024 + q) - 1032
         }
     }
     // reduce: the four row groups of the wave, then the waves in fixed order
