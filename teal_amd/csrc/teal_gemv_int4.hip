@@ -9,13 +9,12 @@
 // wq[Z][ldb] bytes, byte j of row m = columns 2j (low nibble) and 2j + 1 (high nibble); scales_and_zeros [Z / G][N][2]
 // bf16 exactly as the reference stores them (quantize.py:79-93).
 //
-// Kernel: one 16-wave workgroup = one 128-column tile x one slice of the quantisation groups.  A wave owns whole
-// groups; per 32-row unit it ballots the keep mask, deals the kept rows round-robin to its four 16-lane row groups
-// (a lane = 8 columns = one dword of a 64-byte row segment), accumulates A = sum x*q and X = sum x per group in fp32
-// and applies scale / zero ONCE per (group, column):  y += scale * (A - 8 X) + zero * X  — the group parameters cost
-// 32 bytes per lane and group instead of per row.  Split-K over groups is folded into the one launch by arrival
-// tickets (the last slice of a tile sums the partials in slice order: deterministic, no atomics on the data).
-// HBM-bound skinny GEMV; no MFMA on purpose.
+// Kernel: one 16-wave workgroup = one 128-column tile x one slice of the 32-row units.  A wave owns units; per unit it
+// ballots the keep mask, compacts the kept rows into its LDS list, deals them to its four 16-lane row groups (a lane = 8
+// columns = one dword of a 64-byte row segment), accumulates A = sum x * (1024 + q) and X = sum x in fp32 and applies
+// scale / zero ONCE per (unit, column):  y += scale * (A - 1032 X) + zero * X  — the group parameters cost 32 bytes per
+// lane and unit instead of per row.  Split-K over units is folded into the one launch by arrival tickets (the last slice
+// of a tile sums the partials in slice order: deterministic, no atomics on the data).  No MFMA on purpose.
 #include "teal_common.h"
 
 #include <limits.h>
@@ -36,10 +35,20 @@ struct Int4Args {
     int ws_stride;
 };
 
+// Round 3 form.  Round 2's kernel walked a wave's groups one after the other — activation load -> ballot -> a serial
+// scalar chain (count-trailing-zeros per kept row) dealing the rows to the lane groups -> row loads -> arithmetic — i.e.
+// two dependent memory round trips and ~100 scalar instructions per 32-row unit: 24 us per 7B launch for 17 MB.  Now, like
+// the 16-bit kernel (teal_gemv_fast.h): a wave handles its 32-row units in PASSES of four; all activations and group
+// parameters of the pass leave first; the ballots compact (row, x) pairs into the wave's LDS list with mbcnt ranks (no
+// scalar chain); then EVERY row load of the pass is issued before the first is consumed.  scale / zero are applied per
+// UNIT with the parameters of the unit's group — y += scale * (A_u - 1032 X_u) + zero * X_u is linear in the units of a
+// group — so units are independent whatever the group size (A carries 1024 + q: two nibbles become two halves by one and_or
+// under the exponent bits, the byte trick of the int8 kernel).
 template <bool BF16>
 __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const Int4Args a) {
-    constexpr int WAVES = 16, BN = 128;
+    constexpr int WAVES = 16, BN = 128, UP = 4;  // UP: units per pass
     __shared__ float red[WAVES * BN];
+    __shared__ uint32_t lists[WAVES][UP * 32];
     __shared__ float tflag;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -49,69 +58,87 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const Int4Args a
     if (tile >= a.seg_tile1) s = 1;
     if (tile >= a.seg_tile2) s = 2;
     const float tau = s == 0 ? a.tau0 : (s == 1 ? a.tau1 : a.tau2);
-    const int ngroups = a.Z / a.G, upg = a.G / 32;  // 32-row units per group
+    const int nunits = a.Z >> 5;
     const uint32_t col0 = (uint32_t)tile * BN + cl * 8;
     const unsigned char* wp = a.wq + (size_t)tile * (BN / 2) + cl * 4;
+    uint32_t* list = lists[wave];
     float total[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) total[k] = 0.0f;
-    // groups of this workgroup's slice, dealt to the waves round-robin
-    for (int gq = slice + split * wave; gq < ngroups; gq += split * WAVES) {
-        float A[8], X = 0.0f;
+    // unit u belongs to slice u % split, and inside the slice to wave (u / split) % 16
+    const int ustride = split * WAVES;
+    for (int u0 = slice + split * wave; u0 < nunits; u0 += ustride * UP) {
+        // ---- 1. activations and group parameters of the pass ------------------------------------------------------
+        uint32_t xb[UP];
+        u32x4 sz0[UP], sz1[UP];
+        bool live[UP];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) A[k] = 0.0f;
-        // group parameters: requested now, used after the rows (32 B per lane)
-        const u32x4* szp = reinterpret_cast<const u32x4*>(a.sz + ((size_t)gq * a.N + col0) * 2);
-        const u32x4 sz0 = szp[0], sz1 = szp[1];
-        for (int u = 0; u < upg; ++u) {
-            const int row0 = gq * a.G + u * 32;
-            const float xv = bits_to_float(a.x[row0 + (lane & 31)], BF16);
-            uint32_t mask = (uint32_t)__ballot(keep_rule(xv, tau) || (xv != xv));  // lanes 32..63 mirror 0..31
-            // up to 8 rounds of 4 kept rows; every load of the unit is issued before the first use
-            uint32_t d[8];
-            float xr[8];
+        for (int i = 0; i < UP; ++i) {
+            const int u = u0 + i * ustride;
+            live[i] = u < nunits;  // wave-uniform
+            const int uu = live[i] ? u : u0;
+            xb[i] = a.x[(uu << 5) + (lane & 31)];
+            const u32x4* szp = reinterpret_cast<const u32x4*>(a.sz + ((size_t)((uu << 5) / a.G) * a.N + col0) * 2);
+            sz0[i] = szp[0];
+            sz1[i] = szp[1];
+        }
+        // ---- 2. ballots -> (row in unit : 16 | x bits : 16) pairs in the wave's list, ascending -------------------------
+        int off[UP + 1];
+        off[0] = 0;
+#pragma unroll
+        for (int i = 0; i < UP; ++i) {
+            const float v = bits_to_float(xb[i], BF16);
+            const uint32_t mask = live[i] ? (uint32_t)__ballot(keep_rule(v, tau) || (v != v)) : 0u;  // lanes 32..63 mirror 0..31
+            if (lane < 32 && ((mask >> lane) & 1u))
+                list[off[i] + __builtin_amdgcn_mbcnt_lo(mask, 0u)] = ((uint32_t)lane << 16) | xb[i];
+            off[i + 1] = off[i] + __popc(mask);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- 3. every row load of the pass (up to 8 steps of 4 rows per unit) ----------------------------------------------
+        uint32_t d[UP][8];
+#pragma unroll
+        for (int i = 0; i < UP; ++i) {
+            const int row0 = (live[i] ? u0 + i * ustride : u0) << 5;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                int b[4];
-                bool ok[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    ok[j] = mask != 0u;
-                    b[j] = ok[j] ? __builtin_ctz(mask) : 0;
-                    mask &= mask - 1u;
+                d[i][r] = 0u;
+                if (off[i] + 4 * r < off[i + 1]) {  // wave-uniform: this step has rows
+                    const int e = off[i] + 4 * r + rs;
+                    if (e < off[i + 1])
+                        d[i][r] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(wp + (size_t)(row0 + (int)(list[e] >> 16)) * a.ldb));
                 }
-                const int br = rs == 0 ? b[0] : (rs == 1 ? b[1] : (rs == 2 ? b[2] : b[3]));
-                const bool okr = rs == 0 ? ok[0] : (rs == 1 ? ok[1] : (rs == 2 ? ok[2] : ok[3]));
-                const float x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), b[0]));
-                const float x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), b[1]));
-                const float x2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), b[2]));
-                const float x3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), b[3]));
-                xr[r] = okr ? (rs == 0 ? x0 : (rs == 1 ? x1 : (rs == 2 ? x2 : x3))) : 0.0f;
-                d[r] = 0x88888888u;  // (a row that is not there: its x is 0, so it adds nothing to A or X)
-                if (okr) d[r] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(wp + (size_t)(row0 + br) * a.ldb));
             }
-            // The launch is bound by vector-ALU issue, not by memory (25 us for 17 MB at 7B shapes): nibble -> float as
-            // bfe + cvt + fma costs 3 instructions per weight.  Two nibbles at a time become halves without a conversion:
-            // (d >> 4j) & 0x000F000F under the exponent bits 0x6400 is the pair {1024 + q_j, 1024 + q_(j+4)} (the byte trick of
-            // the int8 kernel, teal_gemv_kernel.h), consumed by the mixed-precision FMA; the constant leaves with X below.
+        }
+        // ---- 4. arithmetic, unit by unit; scale / zero once per (unit, column) -------------------------------------------
+#pragma unroll
+        for (int i = 0; i < UP; ++i) {
+            float A[8], X = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) A[k] = 0.0f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
+                if (off[i] + 4 * r < off[i + 1]) {
+                    const int e = off[i] + 4 * r + rs;
+                    const float xr = e < off[i + 1] ? bits_to_float(list[e] & 0xFFFFu, BF16) : 0.0f;  // a lane without a row adds 0
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f16x2 hq = __builtin_bit_cast(f16x2, ((d[r] >> (4 * j)) & 0x000F000Fu) | 0x64006400u);
-                    A[j] = fmaf((float)hq.x, xr[r], A[j]);
-                    A[j + 4] = fmaf((float)hq.y, xr[r], A[j + 4]);
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const f16x2 hq = __builtin_bit_cast(f16x2, ((d[i][r] >> (4 * jj)) & 0x000F000Fu) | 0x64006400u);
+                        A[jj] = fmaf((float)hq.x, xr, A[jj]);
+                        A[jj + 4] = fmaf((float)hq.y, xr, A[jj + 4]);
+                    }
+                    X += xr;
                 }
-                X += xr[r];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t pr = k < 4 ? sz0[i][k] : sz1[i][k - 4];  // bf16 pair: scale (low half), zero (high half)
+                const float sc = __uint_as_float(pr << 16), zr = __uint_as_float(pr & 0xFFFF0000u);
+                total[k] += sc * (A[k] - 1032.0f * X) + zr * X;  // (q - 8) = (1024 + q) - 1032; a dead unit has X = A = 0
             }
         }
-        // scale / zero once per (group, column): y += scale * (A - 8 X) + zero * X
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t pr = k < 4 ? sz0[k] : sz1[k - 4];  // bf16 pair: scale (low half), zero (high half)
-            const float sc = __uint_as_float(pr << 16), zr = __uint_as_float(pr & 0xFFFF0000u);
-            total[k] += sc * (A[k] - 1032.0f * X) + zr * X;  // A carries 1024 + q: (q - 8) = (1024 + q) - 1032
-        }
+        __builtin_amdgcn_wave_barrier();  // the list is rewritten by the next pass
     }
     // reduce: the four row groups of the wave, then the waves in fixed order
 #pragma unroll
@@ -165,10 +192,10 @@ extern "C" int teal_sparse_qkv_gemv_i4(const void* x, const void* wq, const void
     if (!aligned16(scales_and_zeros) || (reinterpret_cast<uintptr_t>(wq) & 3u)) return TEAL_ERR_ALIGN;
     DeviceCtx* dc = device_ctx();
     if (!dc) return TEAL_ERR_NO_DEVICE;
-    const int ntiles = N / 128, ngroups = Z / groupsize;
+    const int ntiles = N / 128, nunits = Z / 32;
     int split = dc->num_cu / ntiles;
     if (split > 8) split = 8;
-    if (split * 16 > ngroups) split = ngroups / 16;  // every wave of every slice owns at least one group
+    if (split * 16 > nunits) split = nunits / 16;  // every wave of every slice owns at least one 32-row unit
     if (split < 1) split = 1;
     Int4Args a = {};
     a.x = reinterpret_cast<const uint16_t*>(x);
