@@ -457,7 +457,7 @@ def main():
     if a.weights == "int4":
         out["metric"] = out["metric"].replace("fp16", "int4-g32-weight/fp16-activation")
         out["dtype"] = out["dtype"] + " activations, int4 group-quantised weights (g32), 16-bit lm_head"
-        out["config"]["workload"] += ", int4 weight-only (Int4DecodeEngine: 10 launches per layer)"
+        out["config"]["workload"] += ", int4 group-quantised projections (g32), 16-bit lm_head"
     out.update(info.get("report", {}))
     if rank == 0 and mode == "engine":
         eng = info["engine"]

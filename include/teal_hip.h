@@ -207,7 +207,13 @@ typedef struct teal_gemv_out {
                             * scale[i] = per-output-column scales in the activation dtype (element 0 = column col0[i]);
                             * y = round(fp32(sum q*x) * fp32(scale)) — one rounding, where the reference's
                             * F.linear(x, w.to(dtype)) * scales rounds twice */
-    const void* scale[3];  /* int8 only */
+    const void* scale[3];  /* int8: see above.  int4 (weight_bits = 4, gpt-fast/quantize.py:58-162, 483-526): w[i] = packed image
+                            * of W^T, [Z][ld BYTES], byte j of a row = columns 2j (low nibble) and 2j + 1; scale[i] = the
+                            * reference's scales_and_zeros tensor of that image, bf16 [Z / groupsize][scale_ld[i]][2]; col0
+                            * addresses both.  ncols multiples of 128; in modes PLAIN, RESID_NORM (interleaved slabs, <= 8),
+                            * SILU_MUL, ATTN_MERGE; out modes ROUNDED and SLABS (Z <= 32768 with a producer) */
+    int scale_ld[3];       /* int4 only: columns per group row of scale[i] (the image's N) */
+    int groupsize;         /* int4 only: 32, 64, 128 or 256 rows per quantisation group; Z a multiple */
 } teal_gemv_out_t;
 
 /* One launch: [fused producer] -> mask + compaction -> gathered GEMV over every segment.
@@ -277,15 +283,6 @@ int teal_sample_topk_ws(const void* logits, int vocab, int dtype, int top_k, flo
                         int32_t* token_out, int32_t* pos_inout, int32_t* history, int history_len, void* ws,
                         size_t ws_bytes, void* stream);
 
-/* The two element-wise steps of a decode layer as launches of their own, for weight formats whose GEMV takes a plain activation
- * (the int4 kernel; teal_amd/gpt_fast/engine_int4.py); the 16-bit / int8 engines fold them into the GEMV launches as producers.
- *   teal_resid_rmsnorm: h = resid_in (+ add, rounded); x_out = RMSNorm(h) * norm_weight; resid_out = h (optional, must not alias
- *                       resid_in); row_index = optional device int32, row = row_index[0] of resid_in (embedding lookup); Z <= 16384.
- *                       gpt-fast/model.py:158-161,289-291
- *   teal_silu_mul:      h = silu(gate) * up with the roundings of the unfused sequence.               gpt-fast/model.py:258-259 */
-int teal_resid_rmsnorm(const void* resid_in, const int32_t* row_index, const void* add, const void* norm_weight, float eps,
-                       void* resid_out, void* x_out, int Z, int dtype, void* stream);
-int teal_silu_mul(const void* gate, const void* up, void* h, int Z, int dtype, void* stream);
 
 /* ---- benchmark comparator (scripts/benchmark_gemv.py only; not on the decode path) ----------- */
 

@@ -19,7 +19,7 @@ CSRC = os.path.join(_PKG, "csrc")
 # (weight width, activation dtype) so that they compile in parallel
 SOURCES = ("teal_kernels.hip", "teal_attention.hip", "teal_gemv_w16_f16.hip", "teal_gemv_w16_bf16.hip",
            "teal_gemv_w8_f16.hip", "teal_gemv_w8_bf16.hip", "teal_gemv_fast_f16.hip", "teal_gemv_fast_bf16.hip", "teal_gemv_int4.hip",
-           "teal_gemv_fast_w8_f16.hip", "teal_gemv_fast_w8_bf16.hip", "teal_comparators.hip", "teal_glue.hip")
+           "teal_gemv_fast_w8_f16.hip", "teal_gemv_fast_w8_bf16.hip", "teal_comparators.hip")
 # translation units whose kernels take their hot arguments as scalar parameters: the command processor preloads the
 # first 11 dwords into SGPRs at wave launch (no scalar-cache miss before the first activation load)
 PRELOAD = {"teal_gemv_fast_f16.hip": 11, "teal_gemv_fast_bf16.hip": 11, "teal_gemv_fast_w8_f16.hip": 11,
@@ -33,7 +33,7 @@ EXPORTS = (
     "teal_version", "teal_strerror", "teal_init", "teal_workspace_bytes", "teal_compact",
     "teal_sparse_gemv", "teal_sparse_qkv_gemv", "teal_dense_gemv", "teal_sparse_gateup_silu",
     "teal_set_tuning", "teal_get_config", "teal_set_phase_buffer", "teal_fused_gemv", "teal_decode_attention", "teal_sample_topk", "teal_set_swizzle", "teal_set_wave_local", "teal_sparse_qkv_gemv_ld", "teal_decode_attention_masked", "teal_decode_attention_split", "teal_sparse_qkv_gemv_i8", "teal_decode_attention_split_slabs", "teal_set_phase_stride", "teal_set_fast", "teal_last_launch_desc", "teal_sparse_qkv_gemv_i4", "teal_set_experiment",
-    "teal_workspace_init", "teal_workspace_release", "teal_sample_topk_ws", "teal_decode_attention_split_ws", "teal_cmp_flag_gemv", "teal_resid_rmsnorm", "teal_silu_mul",
+    "teal_workspace_init", "teal_workspace_release", "teal_sample_topk_ws", "teal_decode_attention_split_ws", "teal_cmp_flag_gemv",
 )
 
 _lib = None
@@ -128,8 +128,6 @@ def load() -> ctypes.CDLL:
     L.teal_decode_attention_split.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, ci, vp, sz, ci, vp]
     L.teal_decode_attention_split_slabs.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, ci, vp, sz, ci, vp]
     L.teal_decode_attention_split_ws.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, ci, vp, sz, ci, vp, sz, vp]
-    L.teal_resid_rmsnorm.argtypes = [vp, vp, vp, vp, cf, vp, vp, ci, ci, vp]
-    L.teal_silu_mul.argtypes = [vp, vp, vp, ci, ci, vp]
     L.teal_cmp_flag_gemv.argtypes = [vp, vp, ci, vp, vp, cf, ci, ci, ci, vp]
     L.teal_decode_attention.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
     L.teal_get_config.argtypes = [ci, ci, ci, ctypes.POINTER(ci)]

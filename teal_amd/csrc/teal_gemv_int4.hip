@@ -15,52 +15,210 @@
 // scale / zero ONCE per (unit, column):  y += scale * (A - 1032 X) + zero * X  — the group parameters cost 32 bytes per
 // lane and unit instead of per row.  Split-K over units is folded into the one launch by arrival tickets (the last slice
 // of a tile sums the partials in slice order: deterministic, no atomics on the data).  No MFMA on purpose.
+//
+// The kernel takes the producers of the fused decode step like the 16-bit one (teal_gemv_fast.h): MODE 1 residual + fp32
+// slabs -> RMSNorm, MODE 2 silu(gate) * up, MODE 4 split-KV attention merge — each workgroup recomputes the activation
+// vector into LDS (16 bits per element) and its waves take their units from there — and leaves either rounded outputs or
+// its fp32 split-K partials as slabs for the next launch's producer, so an int4 layer is 5 launches too.
 #include "teal_common.h"
 
 #include <limits.h>
 
 namespace teal {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct Int4Args {
-    const uint16_t* x;
-    const unsigned char* wq;
-    const uint16_t* sz;   // [Z / G][N][2] bf16 (scale, zero)
-    uint16_t* y;
-    float* ws;            // [ncols][ws_stride] partials (split > 1)
-    unsigned* ticket;
-    int Z, N, ldb, G;     // ldb: row stride of wq in bytes
-    int seg_tile1, seg_tile2;
-    float tau0, tau1, tau2;
-    int ws_stride;
+struct I4Seg {
+    const unsigned char* wq;  // first byte of the segment's columns in row 0
+    const uint16_t* sz;       // (scale, zero) of the segment's first column in group 0
+    uint16_t* y;              // rounded output of the segment (null when the launch leaves slabs)
+    int ldb, szld;            // row stride of wq in bytes; columns per row of sz
+    int tile0;                // first 128-column tile of the segment
+    float tau;
 };
 
-// Round 3 form.  Round 2's kernel walked a wave's groups one after the other — activation load -> ballot -> a serial
-// scalar chain (count-trailing-zeros per kept row) dealing the rows to the lane groups -> row loads -> arithmetic — i.e.
-// two dependent memory round trips and ~100 scalar instructions per 32-row unit: 24 us per 7B launch for 17 MB.  Now, like
-// the 16-bit kernel (teal_gemv_fast.h): a wave handles its 32-row units in PASSES of four; all activations and group
-// parameters of the pass leave first; the ballots compact (row, x) pairs into the wave's LDS list with mbcnt ranks (no
-// scalar chain); then EVERY row load of the pass is issued before the first is consumed.  scale / zero are applied per
-// UNIT with the parameters of the unit's group — y += scale * (A_u - 1032 X_u) + zero * X_u is linear in the units of a
-// group — so units are independent whatever the group size (A carries 1024 + q: two nibbles become two halves by one and_or
-// under the exponent bits, the byte trick of the int8 kernel).
-template <bool BF16>
-__global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const Int4Args a) {
+struct I4Args {
+    I4Seg seg[3];
+    int nseg, Z, G;
+    // producer
+    const uint16_t* x;        // MODE 0: x[Z]; MODE 2: gate[Z] | up[Z]; MODE 1: residual (table with row_index)
+    const int* row_index;
+    const float* slabs;       // MODE 1: interleaved fp32 partials [Z][(nslabs + 3) & ~3] folded into the residual
+    int nslabs;
+    const uint16_t* norm_w;
+    float eps;
+    uint16_t* resid_out;
+    const float* att;         // MODE 4: partials [Z / hd][ns][hd + 2]
+    int att_hd, att_ns;
+    // split-K partials / slabs: element (column c, slice s) at ws[c * ws_es + s * ws_ss]
+    float* ws;
+    int ws_es, ws_ss;
+    unsigned* ticket;         // null: split == 1, or the partials stay as slabs for the consumer
+};
+
+// A wave handles its 32-row units in PASSES of four; all activations and group parameters of the pass leave first; the
+// ballots compact (row, x) pairs into the wave's LDS list with mbcnt ranks (round 2 dealt the rows through a serial scalar
+// count-trailing-zeros chain: 24 us per 7B launch for 17 MB); then EVERY row load of the pass is issued before the first is
+// consumed.  scale / zero are applied per UNIT with the parameters of the unit's group — y += scale * (A_u - 1032 X_u) +
+// zero * X_u is linear in the units of a group — so units are independent whatever the group size (A carries 1024 + q: two
+// nibbles become two halves by one and_or under the exponent bits, the byte trick of the int8 kernel).
+template <bool BF16, int MODE>
+__global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) {
     constexpr int WAVES = 16, BN = 128, UP = 4;  // UP: units per pass
+    extern __shared__ __align__(16) uint16_t xs[];  // MODE != 0: the activation vector, Z entries
     __shared__ float red[WAVES * BN];
     __shared__ uint32_t lists[WAVES][UP * 32];
+    __shared__ float wsum[WAVES];
     __shared__ float tflag;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x, slice = blockIdx.y, split = gridDim.y;
     const int rs = lane >> 4, cl = lane & 15;  // row group of the wave, 4-byte column slot of the tile
+    const int Z = a.Z;
+
+    // ---- producer -------------------------------------------------------------------------------------------------------
+    if constexpr (MODE == 1) {
+        // h = resid + round(sum slabs);  x = round(round(h * rstd) * w)          gpt-fast/model.py:158-161, 289-291
+        const uint16_t* resid = a.x;
+        if (a.row_index) resid += (size_t)a.row_index[0] * (size_t)Z;  // embedding row of the current token
+        const int kmax = (Z + 1023) >> 10;  // <= 16 elements per thread
+        const uint32_t stride = (uint32_t)(a.nslabs + 3) & ~3u;
+        uint32_t wb[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int m = tid + (k << 10);
+            wb[k] = (k < kmax && m < Z) ? a.norm_w[m] : 0u;
+        }
+        float ss = 0.0f;
+#pragma unroll
+        for (int k0 = 0; k0 < 16; k0 += 4) {
+            if (k0 < kmax) {
+                uint32_t rb[4];
+                f32x4 v0[4], v1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t m = (uint32_t)min(tid + ((k0 + j) << 10), Z - 1);
+                    rb[j] = resid[m];
+                    if (a.nslabs > 0) v0[j] = *reinterpret_cast<const f32x4*>(a.slabs + m * stride);
+                    if (a.nslabs > 4) v1[j] = *reinterpret_cast<const f32x4*>(a.slabs + m * stride + 4);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = tid + ((k0 + j) << 10);
+                    float r = bits_to_float(rb[j], BF16);
+                    if (a.nslabs > 0) {  // slab order 0, 1, 2, ... (the order of the ordered reduce); an absent slab adds 0.0f
+                        float sacc = 0.0f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) sacc += (q < a.nslabs) ? v0[j][q] : 0.0f;
+                        if (a.nslabs > 4) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) sacc += (4 + q < a.nslabs) ? v1[j][q] : 0.0f;
+                        }
+                        const float yv = bits_to_float(float_to_bits<BF16>(sacc), BF16);
+                        r = bits_to_float(float_to_bits<BF16>(r + yv), BF16);
+                    }
+                    if (m < Z) {
+                        xs[m] = float_to_bits<BF16>(r);  // exact: r is a 16-bit value
+                        ss = fmaf(r, r, ss);
+                    }
+                }
+            }
+        }
+        ss = wave_sum_f(ss);
+        if (lane == 0) wsum[wave] = ss;
+        __syncthreads();
+        float tot = lane < WAVES ? wsum[lane] : 0.0f;
+        tot = wave_sum_f(tot);
+        const float rstd = rsqrtf(tot / (float)Z + a.eps);
+        const bool writer = a.resid_out && tile == 0 && slice == 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int m = tid + (k << 10);
+            if (k < kmax && m < Z) {
+                const uint32_t hb = xs[m];  // this thread's own element
+                const float xn = bits_to_float(float_to_bits<BF16>(bits_to_float(hb, BF16) * rstd), BF16);
+                xs[m] = float_to_bits<BF16>(xn * bits_to_float(wb[k], BF16));
+                if (writer) a.resid_out[m] = (uint16_t)hb;
+            }
+        }
+        __syncthreads();
+    } else if constexpr (MODE == 2) {
+        // x = round(round(silu(gate)) * up)                                          gpt-fast/model.py:258-259
+        for (int m0 = tid; m0 < Z; m0 += 4096) {
+            uint32_t gb[4], ub[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // all gate / up loads of the block first
+                const uint32_t m = (uint32_t)min(m0 + (j << 10), Z - 1);
+                gb[j] = a.x[m];
+                ub[j] = a.x[(uint32_t)Z + m];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = m0 + (j << 10);
+                const float gt = bits_to_float(gb[j], BF16);
+                const float sl = bits_to_float(float_to_bits<BF16>(gt / (1.0f + expf(-gt))), BF16);
+                if (m < Z) xs[m] = float_to_bits<BF16>(sl * bits_to_float(ub[j], BF16));
+            }
+        }
+        __syncthreads();
+    } else if constexpr (MODE == 4) {
+        // attention output merged from the split-KV partials {max, sum, o[hd]} per (head, split); the arithmetic of the
+        // 16-bit kernel's merge producer: pairwise-tree sum of the rescaled denominators, fmaf chain over the splits
+        const int hd = a.att_hd, hs = hd + 2;
+        auto merge = [&](auto ns_tag) {
+            constexpr int NS = decltype(ns_tag)::value;
+            constexpr int EB = NS == 4 ? 4 : 2;  // elements per thread and block of loads
+            for (int m0 = tid; m0 < Z; m0 += EB * 1024) {
+                float2 st[EB][NS];
+                float ov[EB][NS];
+#pragma unroll
+                for (int j = 0; j < EB; ++j) {
+                    const int m = min(m0 + (j << 10), Z - 1);
+                    const int h = m / hd, d = m - h * hd;
+                    const float* b = a.att + (size_t)h * NS * hs;
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) {
+                        st[j][q] = *reinterpret_cast<const float2*>(b + q * hs);
+                        ov[j][q] = b[q * hs + 2 + d];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < EB; ++j) {
+                    float M = st[j][0].x;
+#pragma unroll
+                    for (int q = 1; q < NS; ++q) M = fmaxf(M, st[j][q].x);
+                    float f[NS], t[NS];
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) {
+                        f[q] = st[j][q].y > 0.0f ? expf(st[j][q].x - M) : 0.0f;
+                        t[q] = st[j][q].y * f[q];
+                    }
+                    float Ls = (t[0] + t[1]) + (t[2] + t[3]);
+                    if constexpr (NS == 8) Ls = Ls + ((t[7] + t[6]) + (t[5] + t[4]));
+                    float Os = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) Os = fmaf(ov[j][q], f[q] / Ls, Os);
+                    const int m = m0 + (j << 10);
+                    if (m < Z) xs[m] = float_to_bits<BF16>(Os);
+                }
+            }
+        };
+        if (a.att_ns == 8) merge(std::integral_constant<int, 8>{});
+        else merge(std::integral_constant<int, 4>{});
+        __syncthreads();
+    }
+
+    // ---- this workgroup's column tile: segment, threshold, weight image ---------------------------------------------------
     int s = 0;
-    if (tile >= a.seg_tile1) s = 1;
-    if (tile >= a.seg_tile2) s = 2;
-    const float tau = s == 0 ? a.tau0 : (s == 1 ? a.tau1 : a.tau2);
-    const int nunits = a.Z >> 5;
-    const uint32_t col0 = (uint32_t)tile * BN + cl * 8;
-    const unsigned char* wp = a.wq + (size_t)tile * (BN / 2) + cl * 4;
+    if (a.nseg > 1 && tile >= a.seg[1].tile0) s = 1;
+    if (a.nseg > 2 && tile >= a.seg[2].tile0) s = 2;
+    const I4Seg& sg = a.seg[s];
+    const float tau = sg.tau;
+    const int ldb = sg.ldb, szld = sg.szld;
+    const uint32_t scol = (uint32_t)(tile - sg.tile0) * BN + cl * 8;  // the lane's first column inside the segment
+    const unsigned char* wp = sg.wq + (scol >> 1);
+    const uint16_t* szb = sg.sz + (size_t)scol * 2;
+    const int nunits = Z >> 5;
     uint32_t* list = lists[wave];
     float total[8];
 #pragma unroll
@@ -68,7 +226,7 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const Int4Args a
     // unit u belongs to slice u % split, and inside the slice to wave (u / split) % 16
     const int ustride = split * WAVES;
     for (int u0 = slice + split * wave; u0 < nunits; u0 += ustride * UP) {
-        // ---- 1. activations and group parameters of the pass ------------------------------------------------------
+        // ---- 1. activations and group parameters of the pass ------------------------------------------------------------
         uint32_t xb[UP];
         u32x4 sz0[UP], sz1[UP];
         bool live[UP];
@@ -77,8 +235,9 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const Int4Args a
             const int u = u0 + i * ustride;
             live[i] = u < nunits;  // wave-uniform
             const int uu = live[i] ? u : u0;
-            xb[i] = a.x[(uu << 5) + (lane & 31)];
-            const u32x4* szp = reinterpret_cast<const u32x4*>(a.sz + ((size_t)((uu << 5) / a.G) * a.N + col0) * 2);
+            if constexpr (MODE == 0) xb[i] = a.x[(uu << 5) + (lane & 31)];
+            else xb[i] = xs[(uu << 5) + (lane & 31)];
+            const u32x4* szp = reinterpret_cast<const u32x4*>(szb + (size_t)((uu << 5) / a.G) * szld * 2);
             sz0[i] = szp[0];
             sz1[i] = szp[1];
         }
@@ -96,7 +255,7 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const Int4Args a
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- 3. every row load of the pass (up to 8 steps of 4 rows per unit) ----------------------------------------------
+        // ---- 3. every row load of the pass (up to 8 steps of 4 rows per unit) --------------------------------------------
         uint32_t d[UP][8];
 #pragma unroll
         for (int i = 0; i < UP; ++i) {
@@ -107,7 +266,7 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const Int4Args a
                 if (off[i] + 4 * r < off[i + 1]) {  // wave-uniform: this step has rows
                     const int e = off[i] + 4 * r + rs;
                     if (e < off[i + 1])
-                        d[i][r] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(wp + (size_t)(row0 + (int)(list[e] >> 16)) * a.ldb));
+                        d[i][r] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(wp + (size_t)(row0 + (int)(list[e] >> 16)) * ldb));
                 }
             }
         }
@@ -140,7 +299,7 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const Int4Args a
         }
         __builtin_amdgcn_wave_barrier();  // the list is rewritten by the next pass
     }
-    // reduce: the four row groups of the wave, then the waves in fixed order
+    // ---- reduce: the four row groups of the wave, then the waves in fixed order -------------------------------------------
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         total[k] += __shfl_xor(total[k], 16);
@@ -151,15 +310,17 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const Int4Args a
         for (int k = 0; k < 8; ++k) red[wave * BN + lane * 8 + k] = total[k];
     }
     __syncthreads();
-    const uint32_t c = (uint32_t)tile * BN + tid;
+    const uint32_t c = (uint32_t)tile * BN + tid;  // column in the concatenation of the segments (slab / partial index)
+    uint16_t* yp = sg.y ? sg.y + (uint32_t)(tile - sg.tile0) * BN + tid : nullptr;
     float sum = 0.0f;
     if (tid < BN) {
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) sum += red[w * BN + tid];
-        if (split == 1) a.y[c] = float_to_bits<BF16>(sum);
-        else __hip_atomic_store(&a.ws[c * (uint32_t)a.ws_stride + slice], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!a.ws) *yp = float_to_bits<BF16>(sum);
+        else if (a.ticket) __hip_atomic_store(&a.ws[c * (uint32_t)a.ws_es + (uint32_t)slice * a.ws_ss], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else a.ws[c * (uint32_t)a.ws_es + (uint32_t)slice * a.ws_ss] = sum;  // slabs for the next launch's producer
     }
-    if (split > 1) {  // arrival tickets: see gemv_fast_kernel
+    if (a.ticket) {  // arrival tickets: see gemv_fast_kernel
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -170,11 +331,130 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const Int4Args a
         if (tflag != 0.0f && tid < BN) {
             float acc = 0.0f;
             for (int sl = 0; sl < split; ++sl)
-                acc += __hip_atomic_load(&a.ws[c * (uint32_t)a.ws_stride + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a.y[c] = float_to_bits<BF16>(acc);
+                acc += __hip_atomic_load(&a.ws[c * (uint32_t)a.ws_es + (uint32_t)sl * a.ws_ss], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *yp = float_to_bits<BF16>(acc);
             if (tid == 0) __hip_atomic_store(&a.ticket[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+}
+
+template <bool BF16>
+static hipError_t launch_i4(const I4Args& a, int mode, dim3 grid, size_t lds, hipStream_t st) {
+    const dim3 block(1024);
+    switch (mode) {
+        case TEAL_IN_PLAIN: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 0>), grid, block, 0, st, a); break;
+        case TEAL_IN_RESID_NORM: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 1>), grid, block, lds, st, a); break;
+        case TEAL_IN_SILU_MUL: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 2>), grid, block, lds, st, a); break;
+        default: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 4>), grid, block, lds, st, a); break;
+    }
+    return hipGetLastError();
+}
+
+// 16 KB of static LDS + 2 bytes per activation: Z beyond 24 K (the 70B down projection) needs the opt-in
+bool int4_device_init() {
+    bool ok = true;
+    const int bytes = 2 * kI4MaxZ;
+#define TEAL_I4_ATTR(BF, M) ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_gemv_int4_kernel<BF, M>), \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess
+    TEAL_I4_ATTR(false, 1); TEAL_I4_ATTR(false, 2); TEAL_I4_ATTR(false, 4);
+    TEAL_I4_ATTR(true, 1); TEAL_I4_ATTR(true, 2); TEAL_I4_ATTR(true, 4);
+#undef TEAL_I4_ATTR
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}
+
+// One launch over int4 weights: [producer] -> mask + compaction -> gathered GEMV over every segment (teal_fused_gemv with
+// weight_bits = 4, and the plain entry point below).  split-K factor: enough slices to cover the CUs, at most 8, every
+// wave of every slice owning at least one unit; without a destination for the partials (no prepared workspace and no
+// slabs requested) the launch keeps every unit of a tile in one workgroup.
+int fused_gemv_i4(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z, int dtype, void* ws, size_t ws_bytes,
+                  int* nslabs_out, hipStream_t st) {
+    const int G = out->groupsize;
+    if (G != 32 && G != 64 && G != 128 && G != 256) return TEAL_ERR_ARG;
+    if (Z <= 0 || (Z % G) || Z > 65536) return TEAL_ERR_SHAPE;
+    if (out->nseg < 1 || out->nseg > 3) return TEAL_ERR_ARG;
+    if (out->mode != TEAL_OUT_ROUNDED && out->mode != TEAL_OUT_SLABS) return TEAL_ERR_ARG;  // no paired gate|up form
+    DeviceCtx* dc = device_ctx();
+    if (!dc) return TEAL_ERR_NO_DEVICE;
+    I4Args a = {};
+    a.nseg = out->nseg; a.Z = Z; a.G = G;
+    int ntiles = 0, N = 0;
+    for (int i = 0; i < out->nseg; ++i) {
+        const int nc = out->ncols[i], c0 = out->col0[i], ldb = out->ld[i], szld = out->scale_ld[i];
+        if (!out->w[i] || !out->scale[i] || nc <= 0 || (nc % 128) || c0 < 0 || (c0 & 7)) return TEAL_ERR_SHAPE;
+        if (ldb < (c0 + nc) / 2 || (ldb & 3) || szld < c0 + nc) return TEAL_ERR_SHAPE;
+        if ((reinterpret_cast<uintptr_t>(out->w[i]) & 3u) || !aligned16(out->scale[i])) return TEAL_ERR_ALIGN;
+        if (out->mode == TEAL_OUT_ROUNDED && !out->y[i]) return TEAL_ERR_ARG;
+        I4Seg& sg = a.seg[i];
+        sg.wq = reinterpret_cast<const unsigned char*>(out->w[i]) + c0 / 2;
+        sg.sz = reinterpret_cast<const uint16_t*>(out->scale[i]) + (size_t)c0 * 2;
+        sg.y = out->mode == TEAL_OUT_ROUNDED ? reinterpret_cast<uint16_t*>(out->y[i]) : nullptr;
+        sg.ldb = ldb; sg.szld = szld; sg.tile0 = ntiles; sg.tau = out->tau[i];
+        ntiles += nc / 128;
+        N += nc;
+    }
+    size_t lds = 0;
+    switch (in->mode) {
+        case TEAL_IN_PLAIN:
+            if (!in->x) return TEAL_ERR_ARG;
+            a.x = reinterpret_cast<const uint16_t*>(in->x);
+            break;
+        case TEAL_IN_SILU_MUL:
+            if (!in->x) return TEAL_ERR_ARG;
+            a.x = reinterpret_cast<const uint16_t*>(in->x);
+            lds = (size_t)Z * 2;
+            break;
+        case TEAL_IN_ATTN_MERGE:
+            if (!in->x || (in->att_head_dim != 64 && in->att_head_dim != 128) || Z % in->att_head_dim ||
+                (in->att_nsplit != 0 && in->att_nsplit != 4 && in->att_nsplit != 8))
+                return TEAL_ERR_ARG;
+            a.att = reinterpret_cast<const float*>(in->x);
+            a.att_hd = in->att_head_dim;
+            a.att_ns = in->att_nsplit ? in->att_nsplit : 4;
+            lds = (size_t)Z * 2;
+            break;
+        case TEAL_IN_RESID_NORM:
+            if (!in->resid_in || !in->norm_weight || in->nslabs < 0 || (in->nslabs > 0 && !in->slabs)) return TEAL_ERR_ARG;
+            if (in->resid_out == in->resid_in && !in->row_index) return TEAL_ERR_ARG;  // must ping-pong
+            if (in->nslabs > 0 && (!in->slabs_interleaved || in->nslabs > 8 || !aligned16(in->slabs))) return TEAL_ERR_ARG;
+            if (Z > 16384) return TEAL_ERR_SHAPE;  // 16 elements per thread
+            a.x = reinterpret_cast<const uint16_t*>(in->resid_in);
+            a.row_index = in->row_index;
+            a.slabs = in->slabs;
+            a.nslabs = in->nslabs;
+            a.norm_w = reinterpret_cast<const uint16_t*>(in->norm_weight);
+            a.eps = in->eps;
+            a.resid_out = reinterpret_cast<uint16_t*>(in->resid_out);
+            lds = (size_t)Z * 2;
+            break;
+        default: return TEAL_ERR_ARG;  // TEAL_IN_MASKED: no int4 form
+    }
+    if (lds > 2 * (size_t)kI4MaxZ || (lds > 47 * 1024 && !dc->i4_lds_ok)) return TEAL_ERR_SHAPE;  // 16.3 KB static + dynamic <= 64 KB
+    const int nunits = Z / 32;
+    int split = dc->num_cu / ntiles;
+    if (split > 8) split = 8;
+    if (split * 16 > nunits) split = nunits / 16;  // every wave of every slice owns at least one 32-row unit
+    if (split < 1) split = 1;
+    if (out->mode == TEAL_OUT_SLABS) {
+        if (!out->slabs || !aligned16(out->slabs) || ws_prepared(out->slabs, out->slabs_bytes)) return TEAL_ERR_ARG;
+        a.ws = out->slabs;
+        if (out->slabs_interleaved) { a.ws_es = (split + 3) & ~3; a.ws_ss = 1; }
+        else { a.ws_es = 1; a.ws_ss = N; }
+        if (out->slabs_bytes < (size_t)(out->slabs_interleaved ? a.ws_es : split) * N * sizeof(float)) return TEAL_ERR_WORKSPACE;
+    } else if (split > 1) {
+        if (!ws_prepared(ws, ws_bytes) || ntiles > kTicketTiles) split = 1;
+        else {
+            a.ws_es = (split + 3) & ~3; a.ws_ss = 1;
+            if (ws_bytes - kWsHeaderBytes < (size_t)a.ws_es * N * sizeof(float)) return TEAL_ERR_WORKSPACE;
+            a.ws = ws_slabs(ws);
+            a.ticket = ws_tickets(ws);
+        }
+    }
+    const dim3 grid(ntiles, split);
+    const hipError_t e = dtype == TEAL_BF16 ? launch_i4<true>(a, in->mode, grid, lds, st) : launch_i4<false>(a, in->mode, grid, lds, st);
+    if (e != hipSuccess) return TEAL_ERR_LAUNCH;
+    if (nslabs_out) *nslabs_out = split;
+    return TEAL_OK;
 }
 
 }  // namespace teal
@@ -189,38 +469,21 @@ extern "C" int teal_sparse_qkv_gemv_i4(const void* x, const void* wq, const void
     if (groupsize != 32 && groupsize != 64 && groupsize != 128 && groupsize != 256) return TEAL_ERR_ARG;
     if ((N % 128) || (Z % groupsize) || Z > 65536 || ldb < N / 2 || (ldb & 3)) return TEAL_ERR_SHAPE;
     if (N_q <= 0 || N_kv < 0 || N_q + 2 * N_kv != N || (N_q % 128) || (N_kv % 128)) return TEAL_ERR_SHAPE;
-    if (!aligned16(scales_and_zeros) || (reinterpret_cast<uintptr_t>(wq) & 3u)) return TEAL_ERR_ALIGN;
-    DeviceCtx* dc = device_ctx();
-    if (!dc) return TEAL_ERR_NO_DEVICE;
-    const int ntiles = N / 128, nunits = Z / 32;
-    int split = dc->num_cu / ntiles;
-    if (split > 8) split = 8;
-    if (split * 16 > nunits) split = nunits / 16;  // every wave of every slice owns at least one 32-row unit
-    if (split < 1) split = 1;
-    Int4Args a = {};
-    a.x = reinterpret_cast<const uint16_t*>(x);
-    a.wq = reinterpret_cast<const unsigned char*>(wq);
-    a.sz = reinterpret_cast<const uint16_t*>(scales_and_zeros);
-    a.y = reinterpret_cast<uint16_t*>(y);
-    a.Z = Z; a.N = N; a.ldb = ldb; a.G = groupsize;
-    a.tau0 = tau_q; a.tau1 = tau_k; a.tau2 = tau_v;
-    a.seg_tile1 = N_kv > 0 ? N_q / 128 : INT_MAX;
-    a.seg_tile2 = N_kv > 0 ? (N_q + N_kv) / 128 : INT_MAX;
-    if (split > 1) {
-        // split-K over the groups needs the arrival counters of a prepared workspace (teal_workspace_init); without one
-        // the launch keeps every group of a tile in one workgroup
-        if (!ws_prepared(ws, ws_bytes) || ntiles > kTicketTiles) split = 1;
-        else {
-            a.ws_stride = (split + 3) & ~3;
-            if (ws_bytes - kWsHeaderBytes < (size_t)a.ws_stride * N * sizeof(float)) return TEAL_ERR_WORKSPACE;
-            if (!aligned16(ws)) return TEAL_ERR_ALIGN;
-            a.ws = ws_slabs(ws);
-            a.ticket = ws_tickets(ws);
-        }
+    teal_gemv_in_t in = {};
+    in.mode = TEAL_IN_PLAIN;
+    in.x = x;
+    teal_gemv_out_t out = {};
+    out.nseg = N_kv > 0 ? 3 : 1;
+    const int c0[3] = {0, N_q, N_q + N_kv}, nc[3] = {N_q, N_kv, N_kv};
+    const float tau[3] = {tau_q, tau_k, tau_v};
+    for (int i = 0; i < out.nseg; ++i) {
+        out.w[i] = wq; out.scale[i] = scales_and_zeros;
+        out.ld[i] = ldb; out.scale_ld[i] = N;
+        out.col0[i] = c0[i]; out.ncols[i] = nc[i]; out.tau[i] = tau[i];
+        out.y[i] = reinterpret_cast<uint16_t*>(y) + c0[i];
     }
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid(ntiles, split), block(1024);
-    if (dtype == TEAL_BF16) hipLaunchKernelGGL((sparse_gemv_int4_kernel<true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((sparse_gemv_int4_kernel<false>), grid, block, 0, st, a);
-    return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
+    out.mode = TEAL_OUT_ROUNDED;
+    out.weight_bits = 4;
+    out.groupsize = groupsize;
+    return fused_gemv_i4(&in, &out, Z, dtype, ws, ws_bytes, nullptr, reinterpret_cast<hipStream_t>(stream));
 }

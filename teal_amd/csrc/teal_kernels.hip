@@ -152,6 +152,7 @@ DeviceCtx* device_ctx() {
         return nullptr;
     }
     c->gqa_lds_ok = attention_device_init();
+    c->i4_lds_ok = int4_device_init();
     c->num_cu = cu;
     return c;
 }
@@ -762,6 +763,7 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
     if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
     if (Z > 65536) return TEAL_ERR_SHAPE;
     if (!device_ctx()) return TEAL_ERR_NO_DEVICE;
+    if (out->weight_bits == 4) return fused_gemv_i4(in, out, Z, dtype, ws, ws_bytes, nslabs_out, reinterpret_cast<hipStream_t>(stream));
     Params p = {};
     p.Z = Z;
     p.in.mode = in->mode;

@@ -46,12 +46,14 @@ class GemvOut(ctypes.Structure):  # teal_gemv_out_t
                 ("col0", ctypes.c_int * 3), ("ncols", ctypes.c_int * 3), ("tau", ctypes.c_float * 3),
                 ("y", ctypes.c_void_p * 3), ("mode", ctypes.c_int), ("slabs", ctypes.c_void_p),
                 ("slabs_bytes", ctypes.c_size_t), ("mask_out", ctypes.c_void_p), ("mask_tau", ctypes.c_float),
-                ("slabs_interleaved", ctypes.c_int), ("weight_bits", ctypes.c_int), ("scale", ctypes.c_void_p * 3)]
+                ("slabs_interleaved", ctypes.c_int), ("weight_bits", ctypes.c_int), ("scale", ctypes.c_void_p * 3),
+                ("scale_ld", ctypes.c_int * 3), ("groupsize", ctypes.c_int)]
 
 
 def _out(segs, mode, slabs: Optional[torch.Tensor] = None) -> GemvOut:
-    """segs: list of (weight_ptr, ld, col0, ncols, tau, y_ptr[, scale_ptr]); a scale pointer (per-column scales of
-    the segment, element 0 = column col0) marks int8 weights."""
+    """segs: list of (weight_ptr, ld, col0, ncols, tau, y_ptr[, scale_ptr[, (scale_ld, groupsize)]]); a scale pointer
+    marks quantised weights: int8 (per-column scales of the segment, element 0 = column col0) or, with the
+    (scale_ld, groupsize) pair, int4 (the scales_and_zeros tensor of the whole image, col0 addressing both)."""
     o = GemvOut()
     o.nseg = len(segs)
     for i, seg in enumerate(segs):
@@ -60,6 +62,9 @@ def _out(segs, mode, slabs: Optional[torch.Tensor] = None) -> GemvOut:
         if len(seg) > 6 and seg[6]:
             o.scale[i] = seg[6]
             o.weight_bits = 8
+            if len(seg) > 7 and seg[7]:
+                o.scale_ld[i], o.groupsize = seg[7]
+                o.weight_bits = 4
     o.mode = mode
     if slabs is not None:
         o.slabs = slabs.data_ptr()
@@ -85,14 +90,26 @@ class DecodeEngine:
         cfg = model.config
         lins = [lin for layer in model.layers for lin in (layer.attention.wqkv, layer.attention.wo, layer.feed_forward.w1,
                                                          layer.feed_forward.w3, layer.feed_forward.w2)] + [model.output]
-        if any(hasattr(lin, "scales_and_zeros") for lin in lins):
-            return "int4 group-quantised linears run op by op"
-        i8 = [lin.weight.dtype == torch.int8 for lin in lins]
-        if any(i8) and not all(i8):
-            return "mixed int8 / 16-bit linears"
-        dt = model.output.scales.dtype if all(i8) else model.output.weight.dtype
-        if dt not in (torch.float16, torch.bfloat16) or any((not b) and lin.weight.dtype != dt for b, lin in zip(i8, lins)):
-            return f"weights are not uniformly fp16 / bf16 (or int8 with such scales): {dt}"
+        i4 = [hasattr(lin, "scales_and_zeros") for lin in lins]
+        if any(i4):
+            # int4 group-quantised projections (teal_amd/quantize.py) with a 16-bit lm_head, as quantize_model_int4 leaves them
+            from ..quantize import int4_kernel_supports
+            if not all(i4[:-1]) or i4[-1] or model.output.weight.dtype not in (torch.float16, torch.bfloat16):
+                return "int4 blocks need every projection int4 group-quantised and the lm_head in fp16 / bf16"
+            kvw = cfg.n_local_heads * cfg.head_dim
+            for j, lin in enumerate(lins[:-1]):
+                if not int4_kernel_supports(lin.in_features, lin.out_features, lin.groupsize, kvw if j % 5 == 0 else 0):
+                    return f"int4 linear {lin.in_features}x{lin.out_features} g{lin.groupsize} is outside the int4 kernel's shape contract"
+            if cfg.intermediate_size > 32768:
+                return "intermediate_size > 32768 (the int4 launch keeps the activation vector in LDS)"
+            i8, dt = [False] * len(lins), model.output.weight.dtype
+        else:
+            i8 = [lin.weight.dtype == torch.int8 for lin in lins]
+            if any(i8) and not all(i8):
+                return "mixed int8 / 16-bit linears"
+            dt = model.output.scales.dtype if all(i8) else model.output.weight.dtype
+            if dt not in (torch.float16, torch.bfloat16) or any((not b) and lin.weight.dtype != dt for b, lin in zip(i8, lins)):
+                return f"weights are not uniformly fp16 / bf16 (or int8 with such scales): {dt}"
         if cfg.head_dim not in (64, 128):
             return f"head_dim {cfg.head_dim} (the attention launches are built for 64 and 128)"
         kv = cfg.n_local_heads * cfg.head_dim
@@ -125,8 +142,8 @@ class DecodeEngine:
         dt = model.output.scales.dtype if hasattr(model.output, "scales") else model.output.weight.dtype
         lins = [lin for layer in model.layers for lin in (layer.attention.wqkv, layer.attention.wo, layer.feed_forward.w1,
                                                          layer.feed_forward.w3, layer.feed_forward.w2)] + [model.output]
-        self.int8 = lins[0].weight.dtype == torch.int8  # int8 weight-only projections (teal_amd/quantize.py)
-        assert all((lin.weight.dtype == torch.int8) == self.int8 for lin in lins), "mixed int8 / 16-bit linears"
+        self.int4 = hasattr(lins[0], "scales_and_zeros")  # int4 group-quantised projections, 16-bit lm_head
+        self.int8 = lins[0].weight.dtype == torch.int8    # int8 weight-only linears (teal_amd/quantize.py)
         self.dtype, self.code = dt, runtime.dtype_code(dt)
         assert model.freqs_cis is not None, "call model.setup_caches() first"
         dim, inter, hd = cfg.dim, cfg.intermediate_size, cfg.head_dim
@@ -135,7 +152,8 @@ class DecodeEngine:
         for layer in model.layers:
             for lin in (layer.attention.wqkv, layer.attention.wo, layer.feed_forward.w1, layer.feed_forward.w3,
                         layer.feed_forward.w2):
-                to_column_major(lin, shift_bytes=UP_SHIFT_BYTES if lin is layer.feed_forward.w3 else 0)
+                if not self.int4:  # (an int4 linear holds the packed image of W^T already)
+                    to_column_major(lin, shift_bytes=UP_SHIFT_BYTES if lin is layer.feed_forward.w3 else 0)
         to_column_major(model.output)
         e = lambda *shape, dtype=dt: torch.zeros(*shape, device=dev, dtype=dtype)  # noqa: E731
         self.resid = [e(dim), e(dim)]
@@ -145,6 +163,8 @@ class DecodeEngine:
         self.h_mask = e((inter + 63) // 64, dtype=torch.int64)                 # keep masks of h_mlp vs tau_down
         # gate|up as one PAIR launch needs whole 64-column chunks and Z small enough for a single list
         can_pair = inter % 64 == 0 and dim % 64 == 0 and (dim + 1) * 4 <= 44 * 1024
+        if self.int4:
+            pair = False  # the int4 kernel has no paired form
         if pair is None and self.int8:
             pair = False  # int8 rows are half as long: the PAIR launch's 172 workgroups are request-bound
         if pair is None:
@@ -213,13 +233,20 @@ class DecodeEngine:
                            norm_weight=layer.attention_norm.weight.data_ptr(), eps=self.eps, resid_out=B.data_ptr())
             es = 2  # bytes per activation / scale element
 
-            def sc(lin, col0=0):  # per-column scales of an int8 linear, from column col0 (None: 16-bit weights)
-                return lin.scales.data_ptr() + es * col0 if self.int8 else None
+            def sc(lin, col0=0):
+                # int8: per-column scales from column col0; int4: the image's scales_and_zeros and (its columns per group
+                # row, group size) — col0 of the segment addresses into it; 16-bit weights: nothing
+                if self.int4:
+                    return lin.scales_and_zeros.data_ptr(), (lin.out_features, lin.groupsize)
+                return (lin.scales.data_ptr() + es * col0 if self.int8 else None), None
 
-            wq, ldq = at.wqkv.weight.data_ptr(), at.wqkv.weight.stride(1)
-            k1_segs = [(wq, ldq, 0, dim, th["q"], self.qkv.data_ptr(), sc(at.wqkv)),
-                       (wq, ldq, dim, kv, th["k"], self.qkv.data_ptr() + 2 * dim, sc(at.wqkv, dim)),
-                       (wq, ldq, dim + kv, kv, th["v"], self.qkv.data_ptr() + 2 * (dim + kv), sc(at.wqkv, dim + kv))]
+            def seg(lin, col0, ncols, tau, y):  # one threshold segment of a linear's weight image
+                ld = lin.weight.stride(0) if self.int4 else lin.weight.stride(1)  # int4: bytes per row of the packed image
+                return (lin.weight.data_ptr(), ld, col0, ncols, tau, y) + sc(lin, col0)
+
+            k1_segs = [seg(at.wqkv, 0, dim, th["q"], self.qkv.data_ptr()),
+                       seg(at.wqkv, dim, kv, th["k"], self.qkv.data_ptr() + 2 * dim),
+                       seg(at.wqkv, dim + kv, kv, th["v"], self.qkv.data_ptr() + 2 * (dim + kv))]
             # split attention: the projection writes fp32 slabs that the attention launch sums itself, so a narrow
             # (GQA) wqkv is row-sliced over all CUs without a reduce launch in between
             k1_out = _out(k1_segs, TEAL_OUT_SLABS, self.s_qkv) if self.att_split else _out(k1_segs, TEAL_OUT_ROUNDED)
@@ -229,21 +256,20 @@ class DecodeEngine:
                 k3_in = GemvIn(mode=TEAL_IN_MASKED, x=self.y_attn.data_ptr(), masks=self.y_mask.data_ptr())
             else:
                 k3_in = GemvIn(mode=TEAL_IN_PLAIN, x=self.y_attn.data_ptr())
-            k3_out = _out([(at.wo.weight.data_ptr(), at.wo.weight.stride(1), 0, dim, th["o"], None, sc(at.wo))], TEAL_OUT_SLABS, self.s_wo)
+            k3_out = _out([seg(at.wo, 0, dim, th["o"], None)], TEAL_OUT_SLABS, self.s_wo)
             k4_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=B.data_ptr(), slabs=self.s_wo.data_ptr(), nslabs=0, slabs_interleaved=1,
                            norm_weight=layer.ffn_norm.weight.data_ptr(), eps=self.eps, resid_out=A.data_ptr())
-            k4_out = _out([(ff.w1.weight.data_ptr(), ff.w1.weight.stride(1), 0, inter, th["gate"], self.gu.data_ptr(), sc(ff.w1)),
-                           (ff.w3.weight.data_ptr(), ff.w3.weight.stride(1), 0, inter, th["up"], self.gu.data_ptr() + 2 * inter, sc(ff.w3))],
-                          TEAL_OUT_ROUNDED)
+            k4_out = _out([seg(ff.w1, 0, inter, th["gate"], self.gu.data_ptr()),
+                           seg(ff.w3, 0, inter, th["up"], self.gu.data_ptr() + 2 * inter)], TEAL_OUT_ROUNDED)
             if self.pair:
-                k4_out = _out([(ff.w1.weight.data_ptr(), ff.w1.weight.stride(1), 0, inter, th["gate"], self.h_mlp.data_ptr(), sc(ff.w1)),
-                               (ff.w3.weight.data_ptr(), ff.w3.weight.stride(1), 0, inter, th["up"], None, sc(ff.w3))], TEAL_OUT_PAIR_SILU)
+                k4_out = _out([seg(ff.w1, 0, inter, th["gate"], self.h_mlp.data_ptr()), seg(ff.w3, 0, inter, th["up"], None)],
+                              TEAL_OUT_PAIR_SILU)
                 k4_out.mask_out = self.h_mask.data_ptr()
                 k4_out.mask_tau = th["down"]
                 k5_in = GemvIn(mode=TEAL_IN_MASKED, x=self.h_mlp.data_ptr(), masks=self.h_mask.data_ptr())
             else:
                 k5_in = GemvIn(mode=TEAL_IN_SILU_MUL, x=self.gu.data_ptr())
-            k5_out = _out([(ff.w2.weight.data_ptr(), ff.w2.weight.stride(1), 0, dim, th["down"], None, sc(ff.w2))], TEAL_OUT_SLABS, self.s_down)
+            k5_out = _out([seg(ff.w2, 0, dim, th["down"], None)], TEAL_OUT_SLABS, self.s_down)
             kc, vc = at.kv_cache.k_cache, at.kv_cache.v_cache
             assert kc.is_contiguous() and kc.shape[0] == 1 and kc.shape[2] == self.max_seq
             self.stages.append((k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out, th["o"]))
@@ -543,7 +569,6 @@ def make_engine_stepper(model: Transformer, a, ths: Optional[List[Dict[str, floa
         torch.cuda.synchronize()
         prefill_s = time.perf_counter() - t0
         tok = G.sample(logits, temperature=0.8, top_k=200)[0]
-        from .engine_int4 import pick_engine
         cls, why = pick_engine(model)
         if cls is None:
             raise ValueError(f"no fused engine for this model: {why}")
@@ -571,3 +596,10 @@ def make_engine_stepper(model: Transformer, a, ths: Optional[List[Dict[str, floa
         state["pos"] += 1
 
     return step, {"thresholds": ths, "engine": eng, "prefill_s": prefill_s, "first_token": tok, "pos0": npr, "span": span}
+
+
+def pick_engine(model: Transformer, need_caches: bool = True):
+    """(DecodeEngine, None) if the fused decode step can run `model` as it stands (16-bit, int8 or int4 group-quantised
+    projections), else (None, reason): the caller keeps the op-by-op module path."""
+    why = DecodeEngine.supports(model, need_caches)
+    return (DecodeEngine, None) if why is None else (None, why)

@@ -175,7 +175,7 @@ def refine_thresholds_on_decode(model: Transformer, sparsities: Dict[str, List[f
         return ths
     model.max_seq_length, model.max_batch_size = -1, -1
     model.setup_caches(max_batch_size=1, max_seq_length=n_prompt + span + 8)
-    from teal_amd.gpt_fast.engine_int4 import pick_engine
+    from teal_amd.gpt_fast.engine import pick_engine
     cls, _why = pick_engine(model)
     if cls is None:  # e.g. head_dim 48: the module path decodes it, with the prefill thresholds
         model.max_seq_length, model.max_batch_size = -1, -1
@@ -370,7 +370,7 @@ class EngineDecoder:
         # (same size or not), not only when the context length changed
         key = self._cache_key()
         if self._engine is None or self._key != key:
-            from teal_amd.gpt_fast.engine_int4 import pick_engine
+            from teal_amd.gpt_fast.engine import pick_engine
             cls, why = pick_engine(self.torch_model)
             if cls is None:
                 raise ValueError(f"no fused engine for this model: {why}")
@@ -443,7 +443,7 @@ def main(args) -> Dict:
     if use_engine and not args.engine:
         # --compile implies the device-resident engine loop only for models the fused step can run (int4 blocks, head_dim 48,
         # ... decode through the patched modules under the same hipGraph capture instead)
-        from teal_amd.gpt_fast.engine_int4 import pick_engine
+        from teal_amd.gpt_fast.engine import pick_engine
         _, why = pick_engine(model, need_caches=False)
         if why is not None:
             print(f"fused engine not used: {why}")

@@ -291,8 +291,8 @@ class Transformer(nn.Module):
             return None
         key = self._engine_key(ths)
         if getattr(self, "_eng_key", None) != key:
-            from .engine_int4 import pick_engine
-            cls, why = pick_engine(self)  # DecodeEngine (16-bit / int8 weights), Int4DecodeEngine, or a reason for neither
+            from .engine import pick_engine
+            cls, why = pick_engine(self)  # DecodeEngine, or the reason it cannot run this model
             object.__setattr__(self, "_eng_why", why)
             # not a submodule: the engine only borrows this model
             object.__setattr__(self, "_eng", None if cls is None else cls(self, ths))

@@ -126,7 +126,7 @@ def test_checkpoint_and_histogram_flow(tmp_path, capsys):
     r4 = G.main(_args(G, compile=True, **dict(common, checkpoint_path=ck / "model_int4.g32.pth")))
     out = capsys.readouterr().out
     assert "Using int4 weight-only quantization!" in out and r4["thresholds"] == ra["thresholds"]
-    assert r4["decoder"] == "EngineDecoder"  # the int4 engine (teal_amd/gpt_fast/engine_int4.py)
+    assert r4["decoder"] == "EngineDecoder"  # the fused engine over int4 blocks
     assert len(r4["sequences"][0]) == len(ra["sequences"][0])
 
 

@@ -163,14 +163,138 @@ def test_int4_model_quantiser_respects_the_kernel_shape_contract(tmp_path):
     assert torch.equal(a, b)
 
 
+def _gap_tau(xabs: torch.Tensor, frac: float) -> float:
+    """a threshold near the `frac` quantile of |x| sitting in the middle of the widest gap there: a producer that differs
+    from the torch restatement by an ulp cannot flip a row across it"""
+    v = torch.sort(xabs.float().cpu()).values
+    k = int(frac * len(v))
+    lo, hi = max(1, k - 24), min(len(v) - 1, k + 24)
+    gaps = v[lo + 1: hi + 1] - v[lo: hi]
+    g = int(torch.argmax(gaps)) + lo
+    return float((v[g] + v[g + 1]) / 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_int4_fused_producers_and_slabs(dtype):
+    """teal_fused_gemv with weight_bits = 4 (include/teal_hip.h): each producer (RESID_NORM over interleaved slabs, SILU_MUL,
+    ATTN_MERGE at 4 and 8 splits) against the PLAIN int4 launch on the torch restatement of the activation vector, with the
+    thresholds placed in gaps of |x|; resid_out bit-exact; the SLABS output summed in slice order equals the ROUNDED one
+    bit for bit (same partials, same order)."""
+    import ctypes
+    from teal_amd import _lib, runtime
+    from teal_amd.gpt_fast.engine import (TEAL_IN_ATTN_MERGE, TEAL_IN_PLAIN, TEAL_IN_RESID_NORM, TEAL_IN_SILU_MUL, TEAL_OUT_ROUNDED,
+                                          TEAL_OUT_SLABS, GemvIn, _out)
+    from teal_amd.quantize import group_quantize_tensor, pack_int4_colmajor
+    L = _lib.load()
+    runtime.init()
+    code = runtime.dtype_code(dtype)
+    g = torch.Generator().manual_seed(11)
+    st = runtime.stream_ptr()
+
+    def linear(Z, N, G):
+        w = (torch.randn(N, Z, generator=g) * 0.03).to(torch.bfloat16)
+        q, sz = group_quantize_tensor(w, 4, G)
+        return pack_int4_colmajor(q).to(DEV), sz.to(DEV)
+
+    def run(gin, Z, N, G, packed, sz, taus, mode, ws, slabs=None):
+        """two threshold segments over one image; -> (y, nslabs)"""
+        y = torch.zeros(N, device=DEV, dtype=dtype)
+        h = N // 2
+        segs = [(packed.data_ptr(), packed.stride(0), 0, h, taus[0], y.data_ptr(), sz.data_ptr(), (N, G)),
+                (packed.data_ptr(), packed.stride(0), h, N - h, taus[1], y.data_ptr() + 2 * h, sz.data_ptr(), (N, G))]
+        gout = _out(segs, mode, slabs)
+        n = ctypes.c_int(0)
+        rc = L.teal_fused_gemv(ctypes.byref(gin), ctypes.byref(gout), Z, code, ws.data_ptr(), ws.numel() * 4, ctypes.byref(n), st)
+        _lib.check(rc, "teal_fused_gemv")
+        torch.cuda.synchronize()
+        return y, n.value
+
+    def check(gin, x_ref, Z, N, G, tol):
+        packed, sz = linear(Z, N, G)
+        ws = runtime.new_workspace(Z, N)
+        for frac in (0.0, 0.5):
+            taus = (-1.0, -1.0) if frac == 0.0 else (_gap_tau(x_ref.abs(), 0.5), _gap_tau(x_ref.abs(), 0.4))
+            y, n = run(gin, Z, N, G, packed, sz, taus, TEAL_OUT_ROUNDED, ws)
+            plain = GemvIn(mode=TEAL_IN_PLAIN, x=x_ref.data_ptr())
+            y_ref, n_ref = run(plain, Z, N, G, packed, sz, taus, TEAL_OUT_ROUNDED, ws)
+            assert n == n_ref and n > 1, "split-K through the arrival tickets"
+            assert torch.allclose(y.float(), y_ref.float(), atol=tol, rtol=tol), (frac, float((y.float() - y_ref.float()).abs().max()))
+            slabs = torch.full((N, (n + 3) & ~3), float("nan"), device=DEV, dtype=torch.float32)
+            _, n2 = run(gin, Z, N, G, packed, sz, taus, TEAL_OUT_SLABS, ws, slabs)
+            assert n2 == n
+            t = torch.zeros(N, device=DEV, dtype=torch.float32)
+            for j in range(n):
+                t = t + slabs[:, j]
+            assert torch.equal(t.to(dtype).view(torch.int16), y.view(torch.int16)), "slabs summed in slice order == rounded output"
+
+    tol = 6e-3 if dtype == torch.float16 else 4e-2
+    # RESID_NORM: h = resid + round(sum of 3 slabs); x = round(round(h * rstd) * w)
+    Z, N, G = 4096, 512, 32
+    resid = torch.randn(Z, generator=g).to(dtype).to(DEV)
+    sl = torch.zeros(Z, 4, dtype=torch.float32)
+    sl[:, :3] = torch.randn(Z, 3, generator=g) * 0.3
+    sl = sl.to(DEV)
+    nw = (1.0 + 0.1 * torch.randn(Z, generator=g)).to(dtype).to(DEV)
+    rout = torch.zeros(Z, device=DEV, dtype=dtype)
+    ysum = ((sl[:, 0] + sl[:, 1]) + sl[:, 2]).to(dtype)
+    h = (resid.float() + ysum.float()).to(dtype)
+    hf = h.float()
+    x_ref = ((hf * torch.rsqrt(hf.pow(2).mean() + 1e-5)).to(dtype).float() * nw.float()).to(dtype)
+    gin = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=resid.data_ptr(), slabs=sl.data_ptr(), nslabs=3, slabs_interleaved=1,
+                 norm_weight=nw.data_ptr(), eps=1e-5, resid_out=rout.data_ptr())
+    check(gin, x_ref, Z, N, G, tol)
+    assert torch.equal(rout.view(torch.int16), h.view(torch.int16)), "updated residual, bit-exact"
+    # embedding lookup form (layer 0): row_index, no slabs
+    table = torch.randn(7, Z, generator=g).to(dtype).to(DEV)
+    idx = torch.tensor([5], device=DEV, dtype=torch.int32)
+    hf = table[5].float()
+    x_ref = ((hf * torch.rsqrt(hf.pow(2).mean() + 1e-5)).to(dtype).float() * nw.float()).to(dtype)
+    gin = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=table.data_ptr(), row_index=idx.data_ptr(), nslabs=0, slabs_interleaved=1,
+                 norm_weight=nw.data_ptr(), eps=1e-5, resid_out=rout.data_ptr())
+    check(gin, x_ref, Z, N, G, tol)
+    assert torch.equal(rout, table[5])
+    # SILU_MUL over a width that is no multiple of 1024 (several blocks of loads per thread, a ragged last one)
+    Z, N, G = 5504, 256, 64
+    gu = torch.randn(2 * Z, generator=g).to(dtype).to(DEV)
+    x_ref = (torch.nn.functional.silu(gu[:Z].float()).to(dtype).float() * gu[Z:].float()).to(dtype)
+    check(GemvIn(mode=TEAL_IN_SILU_MUL, x=gu.data_ptr()), x_ref, Z, N, G, tol)
+    # ATTN_MERGE: partials {max, sum, o[hd]} per (head, split)
+    for ns, hd in ((4, 128), (8, 64)):
+        Z, N, G = 2048, 512, 128
+        nh = Z // hd
+        p = torch.zeros(nh, ns, hd + 2)
+        p[:, :, 0] = torch.randn(nh, ns, generator=g)
+        p[:, :, 1] = torch.rand(nh, ns, generator=g) * 1.5 + 0.5
+        p[:, :, 2:] = torch.randn(nh, ns, hd, generator=g) * p[:, :, 1:2]
+        p[1, 2, 1] = 0.0  # an empty split contributes nothing
+        p = p.to(DEV)
+        m, l, o = p[:, :, 0], p[:, :, 1], p[:, :, 2:]
+        f = torch.where(l > 0, torch.exp(m - m.max(dim=1, keepdim=True).values), torch.zeros_like(m))
+        x_ref = ((o * (f / (l * f).sum(1, keepdim=True))[:, :, None]).sum(1)).reshape(-1).to(dtype)
+        check(GemvIn(mode=TEAL_IN_ATTN_MERGE, x=p.data_ptr(), att_head_dim=hd, att_nsplit=ns), x_ref, Z, N, G, tol)
+    # contract: planar / more than 8 input slabs and the paired output have no int4 form
+    packed, sz = linear(4096, 256, 32)
+    ws = runtime.new_workspace(4096, 256)
+    y = torch.zeros(256, device=DEV, dtype=dtype)
+    bad = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=resid.data_ptr(), slabs=sl.data_ptr(), nslabs=3, slabs_interleaved=0,
+                 norm_weight=nw.data_ptr(), eps=1e-5, resid_out=rout.data_ptr())
+    gout = _out([(packed.data_ptr(), packed.stride(0), 0, 256, 0.5, y.data_ptr(), sz.data_ptr(), (256, 32))], TEAL_OUT_ROUNDED)
+    assert L.teal_fused_gemv(ctypes.byref(bad), ctypes.byref(gout), 4096, code, ws.data_ptr(), ws.numel() * 4, None, st) != 0
+    gout.groupsize = 48
+    ok_in = GemvIn(mode=TEAL_IN_PLAIN, x=resid.data_ptr())
+    assert L.teal_fused_gemv(ctypes.byref(ok_in), ctypes.byref(gout), 4096, code, ws.data_ptr(), ws.numel() * 4, None, st) != 0
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,sparsity", [(torch.float16, 0.0), (torch.bfloat16, 0.0), (torch.float16, 0.5)])
 def test_int4_engine_matches_int4_module_path(dtype, sparsity):
-    """Int4DecodeEngine (glue launches + int4 sparse GEMVs through the C ABI, one hipGraph replay per token) against the
-    op-by-op module path on the same int4 blocks: equal to rounding with every row kept, cosine > 0.98 at 50 % (near-tau
-    activations may flip); the captured step replays bit-identically; a single-token call of the patched model uses it."""
+    """DecodeEngine over int4 group-quantised blocks (5 launches per layer through teal_fused_gemv with weight_bits = 4, one
+    hipGraph replay per token) against the op-by-op module path on the same int4 blocks: equal to rounding with every row
+    kept, cosine > 0.98 at 50 % (near-tau activations may flip); the captured step replays bit-identically; a single-token
+    call of the patched model uses it."""
     from teal_amd.gpt_fast import generate as G
-    from teal_amd.gpt_fast.engine_int4 import Int4DecodeEngine, pick_engine
+    from teal_amd.gpt_fast.engine import DecodeEngine, pick_engine
     from teal_amd.quantize import quantize_model_int4
     ref = quantize_model_int4(G.build_synthetic_model("tiny-test", DEV, dtype, seed=3, std=0.05), 32)
     ref.fused_decode = False  # op-by-op module path
@@ -183,8 +307,9 @@ def test_int4_engine_matches_int4_module_path(dtype, sparsity):
             m.max_seq_length = -1
             m.setup_caches(1, 64)
             m(prompt.view(1, -1), torch.arange(5, device=DEV))
-        assert pick_engine(eng_m)[0] is Int4DecodeEngine
-        eng = Int4DecodeEngine(eng_m, ths)
+        assert pick_engine(eng_m)[0] is DecodeEngine
+        eng = DecodeEngine(eng_m, ths)
+        assert eng.int4 and not eng.pair and eng.att_fused_merge
         for step, tok_id in enumerate((7, 100, 3)):
             tok = torch.tensor([[tok_id]], device=DEV, dtype=torch.int)
             pos = torch.tensor([5 + step], device=DEV, dtype=torch.int)
@@ -209,4 +334,4 @@ def test_int4_engine_matches_int4_module_path(dtype, sparsity):
         assert set(kept) == set(eng.SITE) and all(0.0 <= v <= 1.0 for v in kept.values())
         # a single-token call of the patched model takes the same engine
         eng_m(torch.tensor([[7]], device=DEV, dtype=torch.int), torch.tensor([15], device=DEV))
-        assert isinstance(eng_m._eng, Int4DecodeEngine)
+        assert isinstance(eng_m._eng, DecodeEngine) and eng_m._eng.int4
