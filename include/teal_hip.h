@@ -211,7 +211,7 @@ typedef struct teal_gemv_out {
                             * of W^T, [Z][ld BYTES], byte j of a row = columns 2j (low nibble) and 2j + 1; scale[i] = the
                             * reference's scales_and_zeros tensor of that image, bf16 [Z / groupsize][scale_ld[i]][2]; col0
                             * addresses both.  ncols multiples of 128; in modes PLAIN, RESID_NORM (interleaved slabs, <= 8),
-                            * SILU_MUL, ATTN_MERGE; out modes ROUNDED and SLABS (Z <= 32768 with a producer) */
+                            * SILU_MUL, ATTN_MERGE; out modes ROUNDED and SLABS */
     int scale_ld[3];       /* int4 only: columns per group row of scale[i] (the image's N) */
     int groupsize;         /* int4 only: 32, 64, 128 or 256 rows per quantisation group; Z a multiple */
 } teal_gemv_out_t;

@@ -18,11 +18,11 @@ csv.field_size_limit(1 << 24)
 
 def short(n):
     for kn in ("gemv_fast_kernel", "sparse_gemv_kernel", "decode_attention_split_kernel", "decode_attention_gqa_kernel",
-               "decode_attention_merge_kernel", "sample_topk_window_kernel", "sample_topk_multi_kernel"):
+               "decode_attention_merge_kernel", "sample_topk_window_kernel", "sample_topk_multi_kernel", "sparse_gemv_int4_kernel"):
         m = re.search(kn + r"<([^>]*)>", n)
         if m:
             return kn + "<" + m.group(1).replace(" ", "") + ">"
-    for k in ("decode_attention_kernel", "sparse_gemv_int4_kernel", "sample_topk_kernel", "splitk_reduce_kernel", "compact_kernel", "gateup_silu_epilogue_kernel"):
+    for k in ("decode_attention_kernel", "sample_topk_kernel", "splitk_reduce_kernel", "compact_kernel", "gateup_silu_epilogue_kernel"):
         if k in n:
             return k
     return n[:70]

@@ -85,7 +85,6 @@ struct Config {
 struct DeviceCtx {
     int num_cu;       // 0: not initialised yet
     bool gqa_lds_ok;  // the grouped-query attention kernel may take kGqaMaxLds of LDS on this device
-    bool i4_lds_ok;   // the int4 kernel's producers may keep up to kI4MaxZ activations in LDS on this device
 };
 DeviceCtx* device_ctx();                   // context of the CURRENT device (nullptr: no device)
 inline int num_cu_or(int dflt) {           // CU count of the current device, or dflt without a device (host-only queries)
@@ -93,8 +92,6 @@ inline int num_cu_or(int dflt) {           // CU count of the current device, or
     return c && c->num_cu > 0 ? c->num_cu : dflt;
 }
 bool attention_device_init();              // teal_attention.hip: per-kernel attributes of the current device
-constexpr int kI4MaxZ = 32768;             // rows an int4 launch with a producer may have (activation vector in LDS)
-bool int4_device_init();                   // teal_gemv_int4.hip: per-kernel attributes of the current device
 // teal_fused_gemv over int4 group-quantised weights (out->weight_bits == 4): teal_gemv_int4.hip
 int fused_gemv_i4(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z, int dtype, void* ws, size_t ws_bytes,
                   int* nslabs_out, hipStream_t st);

@@ -17,9 +17,10 @@
 // of a tile sums the partials in slice order: deterministic, no atomics on the data).  No MFMA on purpose.
 //
 // The kernel takes the producers of the fused decode step like the 16-bit one (teal_gemv_fast.h): MODE 1 residual + fp32
-// slabs -> RMSNorm, MODE 2 silu(gate) * up, MODE 4 split-KV attention merge — each workgroup recomputes the activation
-// vector into LDS (16 bits per element) and its waves take their units from there — and leaves either rounded outputs or
-// its fp32 split-K partials as slabs for the next launch's producer, so an int4 layer is 5 launches too.
+// slabs -> RMSNorm (every workgroup recomputes the vector into LDS: the norm needs all of it), MODE 2 silu(gate) * up and
+// MODE 4 split-KV attention merge (element-wise: each wave builds the 32 activations of its own units in registers) — and
+// leaves either rounded outputs or its fp32 split-K partials as slabs for the next launch's producer, so an int4 layer is
+// 5 launches too.
 #include "teal_common.h"
 
 #include <limits.h>
@@ -27,6 +28,7 @@
 namespace teal {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kPhaseRow = 32;  // uint64 stamps per workgroup (as in teal_gemv_kernel.h)
 
 struct I4Seg {
     const unsigned char* wq;  // first byte of the segment's columns in row 0
@@ -54,6 +56,7 @@ struct I4Args {
     float* ws;
     int ws_es, ws_ss;
     unsigned* ticket;         // null: split == 1, or the partials stay as slabs for the consumer
+    unsigned long long* phase;  // PHASE instantiations: kPhaseRow stamps per workgroup (teal_set_phase_buffer)
 };
 
 // A wave handles its 32-row units in PASSES of four; all activations and group parameters of the pass leave first; the
@@ -62,10 +65,15 @@ struct I4Args {
 // consumed.  scale / zero are applied per UNIT with the parameters of the unit's group — y += scale * (A_u - 1032 X_u) +
 // zero * X_u is linear in the units of a group — so units are independent whatever the group size (A carries 1024 + q: two
 // nibbles become two halves by one and_or under the exponent bits, the byte trick of the int8 kernel).
-template <bool BF16, int MODE>
+// PHASE (measurement builds only): thread 0 stamps [0] entry, [1] arguments in registers, [2] producer done (MODE 1), and for
+// its wave's first pass [3] activations ready, [4] list written, [5] every load issued, [6] first unit consumed, [7] pass
+// done; [8] all passes done, [9] past the reduce barrier, [10] outputs stored.  100 MHz wall clock (scripts/int4_phase.py).
+template <bool BF16, int MODE, bool PHASE = false>
 __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) {
     constexpr int WAVES = 16, BN = 128, UP = 4;  // UP: units per pass
-    extern __shared__ __align__(16) uint16_t xs[];  // MODE != 0: the activation vector, Z entries
+    unsigned long long t_entry = 0;
+    if constexpr (PHASE) t_entry = wall_clock64();
+    extern __shared__ __align__(16) uint16_t xs[];  // MODE 1: the normalised activation vector, Z entries
     __shared__ float red[WAVES * BN];
     __shared__ uint32_t lists[WAVES][UP * 32];
     __shared__ float wsum[WAVES];
@@ -75,6 +83,25 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
     const int tile = blockIdx.x, slice = blockIdx.y, split = gridDim.y;
     const int rs = lane >> 4, cl = lane & 15;  // row group of the wave, 4-byte column slot of the tile
     const int Z = a.Z;
+    bool first_pass = true;
+    auto stamp = [&](const int i) {
+        if constexpr (PHASE) {
+            if (a.phase && tid == 0 && first_pass) a.phase[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kPhaseRow + i] = wall_clock64();
+        }
+    };
+    // ONE batch of scalar loads for every kernel argument, up front (an "s" input forces the value into an SGPR here):
+    // left to the compiler they are fetched where first used — a chain of dependent scalar-cache misses through the
+    // prologue and again in the epilogue
+#define TEAL_I4_SEG_ARGS(g) "s"((g).wq), "s"((g).sz), "s"((g).y), "s"((g).ldb), "s"((g).szld), "s"((g).tile0), "s"((g).tau)
+    asm volatile("" ::TEAL_I4_SEG_ARGS(a.seg[0]), TEAL_I4_SEG_ARGS(a.seg[1]), TEAL_I4_SEG_ARGS(a.seg[2]));
+    asm volatile("" ::"s"(a.nseg), "s"(a.Z), "s"(a.G), "s"(a.x), "s"(a.row_index), "s"(a.slabs), "s"(a.nslabs), "s"(a.norm_w),
+                 "s"(a.eps), "s"(a.resid_out), "s"(a.att), "s"(a.att_hd), "s"(a.att_ns), "s"(a.ws), "s"(a.ws_es), "s"(a.ws_ss),
+                 "s"(a.ticket));
+#undef TEAL_I4_SEG_ARGS
+    if constexpr (PHASE) {
+        if (a.phase && tid == 0) a.phase[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kPhaseRow] = t_entry;
+    }
+    stamp(1);
 
     // ---- producer -------------------------------------------------------------------------------------------------------
     if constexpr (MODE == 1) {
@@ -142,38 +169,77 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
             }
         }
         __syncthreads();
-    } else if constexpr (MODE == 2) {
-        // x = round(round(silu(gate)) * up)                                          gpt-fast/model.py:258-259
-        for (int m0 = tid; m0 < Z; m0 += 4096) {
-            uint32_t gb[4], ub[4];
+    }
+
+    stamp(2);
+    // ---- this workgroup's column tile: segment, threshold, weight image ---------------------------------------------------
+    // (selected field by field from kernel arguments already in SGPRs: indexing a.seg[] by a run-time s would be a
+    // dependent scalar load)
+    int s = 0;
+    if (a.nseg > 1 && tile >= a.seg[1].tile0) s = 1;
+    if (a.nseg > 2 && tile >= a.seg[2].tile0) s = 2;
+#define TEAL_I4_SEG(f) (s == 0 ? a.seg[0].f : (s == 1 ? a.seg[1].f : a.seg[2].f))
+    const unsigned char* seg_wq = TEAL_I4_SEG(wq);
+    const uint16_t* seg_sz = TEAL_I4_SEG(sz);
+    uint16_t* seg_y = TEAL_I4_SEG(y);
+    const int ldb = TEAL_I4_SEG(ldb), szld = TEAL_I4_SEG(szld), seg_tile0 = TEAL_I4_SEG(tile0);
+    const float tau = TEAL_I4_SEG(tau);
+#undef TEAL_I4_SEG
+    const uint32_t scol = (uint32_t)(tile - seg_tile0) * BN + cl * 8;  // the lane's first column inside the segment
+    const unsigned char* wp = seg_wq + (scol >> 1);
+    const uint16_t* szb = seg_sz + (size_t)scol * 2;
+    const int nunits = Z >> 5;
+    uint32_t* list = lists[wave];
+    float total[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {  // all gate / up loads of the block first
-                const uint32_t m = (uint32_t)min(m0 + (j << 10), Z - 1);
-                gb[j] = a.x[m];
-                ub[j] = a.x[(uint32_t)Z + m];
-            }
+    for (int k = 0; k < 8; ++k) total[k] = 0.0f;
+    // unit u belongs to slice u % split, and inside the slice to wave (u / split) % 16
+    const int ustride = split * WAVES;
+    for (int u0 = slice + split * wave; u0 < nunits; u0 += ustride * UP) {
+        // ---- 1. activations of the pass ----------------------------------------------------------------------------------------
+        // The element-wise producers (MODE 2, MODE 4) run HERE, per unit, in the registers of the wave that owns the unit:
+        // a workgroup touches only its own slice of gate | up (of the attention partials), not the whole vector.
+        uint32_t xb[UP];
+        bool live[UP];
+        uint32_t m_el[UP];  // the lane's element of unit i (lanes 32..63 mirror 0..31)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = m0 + (j << 10);
-                const float gt = bits_to_float(gb[j], BF16);
-                const float sl = bits_to_float(float_to_bits<BF16>(gt / (1.0f + expf(-gt))), BF16);
-                if (m < Z) xs[m] = float_to_bits<BF16>(sl * bits_to_float(ub[j], BF16));
-            }
+        for (int i = 0; i < UP; ++i) {
+            const int u = u0 + i * ustride;
+            live[i] = u < nunits;  // wave-uniform
+            const int uu = live[i] ? u : u0;
+            m_el[i] = (uint32_t)(uu << 5) + (lane & 31);
         }
-        __syncthreads();
-    } else if constexpr (MODE == 4) {
-        // attention output merged from the split-KV partials {max, sum, o[hd]} per (head, split); the arithmetic of the
-        // 16-bit kernel's merge producer: pairwise-tree sum of the rescaled denominators, fmaf chain over the splits
-        const int hd = a.att_hd, hs = hd + 2;
-        auto merge = [&](auto ns_tag) {
-            constexpr int NS = decltype(ns_tag)::value;
-            constexpr int EB = NS == 4 ? 4 : 2;  // elements per thread and block of loads
-            for (int m0 = tid; m0 < Z; m0 += EB * 1024) {
-                float2 st[EB][NS];
-                float ov[EB][NS];
+        if constexpr (MODE == 0) {
 #pragma unroll
-                for (int j = 0; j < EB; ++j) {
-                    const int m = min(m0 + (j << 10), Z - 1);
+            for (int i = 0; i < UP; ++i) xb[i] = a.x[m_el[i]];
+        } else if constexpr (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < UP; ++i) xb[i] = xs[m_el[i]];
+        } else if constexpr (MODE == 2) {
+            // x = round(round(silu(gate)) * up)                                      gpt-fast/model.py:258-259
+            uint32_t gb[UP], ub[UP];
+#pragma unroll
+            for (int i = 0; i < UP; ++i) {  // all gate / up loads of the pass first
+                gb[i] = a.x[m_el[i]];
+                ub[i] = a.x[(uint32_t)Z + m_el[i]];
+            }
+#pragma unroll
+            for (int i = 0; i < UP; ++i) {
+                const float gt = bits_to_float(gb[i], BF16);
+                const float sl = bits_to_float(float_to_bits<BF16>(gt / (1.0f + expf(-gt))), BF16);
+                xb[i] = float_to_bits<BF16>(sl * bits_to_float(ub[i], BF16));
+            }
+        } else {
+            // attention output merged from the split-KV partials {max, sum, o[hd]} per (head, split); the arithmetic of the
+            // 16-bit kernel's merge producer: pairwise-tree sum of the rescaled denominators, fmaf chain over the splits
+            const int hd = a.att_hd, hs = hd + 2;
+            auto merge = [&](auto ns_tag, auto i0_tag, auto n_tag) {
+                constexpr int NS = decltype(ns_tag)::value, I0 = decltype(i0_tag)::value, NU = decltype(n_tag)::value;
+                float2 st[NU][NS];
+                float ov[NU][NS];
+#pragma unroll
+                for (int j = 0; j < NU; ++j) {
+                    const int m = (int)m_el[I0 + j];
                     const int h = m / hd, d = m - h * hd;
                     const float* b = a.att + (size_t)h * NS * hs;
 #pragma unroll
@@ -183,7 +249,7 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < EB; ++j) {
+                for (int j = 0; j < NU; ++j) {
                     float M = st[j][0].x;
 #pragma unroll
                     for (int q = 1; q < NS; ++q) M = fmaxf(M, st[j][q].x);
@@ -198,49 +264,18 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
                     float Os = 0.0f;
 #pragma unroll
                     for (int q = 0; q < NS; ++q) Os = fmaf(ov[j][q], f[q] / Ls, Os);
-                    const int m = m0 + (j << 10);
-                    if (m < Z) xs[m] = float_to_bits<BF16>(Os);
+                    xb[I0 + j] = float_to_bits<BF16>(Os);
                 }
+            };
+            using I = std::integral_constant<int, 0>;
+            if (a.att_ns == 8) {  // 24 registers of partials per unit: two units at a time
+                merge(std::integral_constant<int, 8>{}, I{}, std::integral_constant<int, 2>{});
+                merge(std::integral_constant<int, 8>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+            } else {
+                merge(std::integral_constant<int, 4>{}, I{}, std::integral_constant<int, 4>{});
             }
-        };
-        if (a.att_ns == 8) merge(std::integral_constant<int, 8>{});
-        else merge(std::integral_constant<int, 4>{});
-        __syncthreads();
-    }
-
-    // ---- this workgroup's column tile: segment, threshold, weight image ---------------------------------------------------
-    int s = 0;
-    if (a.nseg > 1 && tile >= a.seg[1].tile0) s = 1;
-    if (a.nseg > 2 && tile >= a.seg[2].tile0) s = 2;
-    const I4Seg& sg = a.seg[s];
-    const float tau = sg.tau;
-    const int ldb = sg.ldb, szld = sg.szld;
-    const uint32_t scol = (uint32_t)(tile - sg.tile0) * BN + cl * 8;  // the lane's first column inside the segment
-    const unsigned char* wp = sg.wq + (scol >> 1);
-    const uint16_t* szb = sg.sz + (size_t)scol * 2;
-    const int nunits = Z >> 5;
-    uint32_t* list = lists[wave];
-    float total[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) total[k] = 0.0f;
-    // unit u belongs to slice u % split, and inside the slice to wave (u / split) % 16
-    const int ustride = split * WAVES;
-    for (int u0 = slice + split * wave; u0 < nunits; u0 += ustride * UP) {
-        // ---- 1. activations and group parameters of the pass ------------------------------------------------------------
-        uint32_t xb[UP];
-        u32x4 sz0[UP], sz1[UP];
-        bool live[UP];
-#pragma unroll
-        for (int i = 0; i < UP; ++i) {
-            const int u = u0 + i * ustride;
-            live[i] = u < nunits;  // wave-uniform
-            const int uu = live[i] ? u : u0;
-            if constexpr (MODE == 0) xb[i] = a.x[(uu << 5) + (lane & 31)];
-            else xb[i] = xs[(uu << 5) + (lane & 31)];
-            const u32x4* szp = reinterpret_cast<const u32x4*>(szb + (size_t)((uu << 5) / a.G) * szld * 2);
-            sz0[i] = szp[0];
-            sz1[i] = szp[1];
         }
+        stamp(3);
         // ---- 2. ballots -> (row in unit : 16 | x bits : 16) pairs in the wave's list, ascending -------------------------
         int off[UP + 1];
         off[0] = 0;
@@ -255,7 +290,17 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- 3. every row load of the pass (up to 8 steps of 4 rows per unit) --------------------------------------------
+        stamp(4);
+        // ---- 3. group parameters (wanted at the end of the pass only: requested after the producer has let go of its
+        //         registers) and every row load of the pass (up to 8 steps of 4 rows per unit) --------------------------------
+        u32x4 sz0[UP], sz1[UP];
+#pragma unroll
+        for (int i = 0; i < UP; ++i) {
+            const int uu = live[i] ? u0 + i * ustride : u0;  // wave-uniform: the group index stays in scalar registers
+            const u32x4* szp = reinterpret_cast<const u32x4*>(szb + (size_t)((uu << 5) / a.G) * szld * 2);
+            sz0[i] = szp[0];
+            sz1[i] = szp[1];
+        }
         uint32_t d[UP][8];
 #pragma unroll
         for (int i = 0; i < UP; ++i) {
@@ -270,9 +315,11 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
                 }
             }
         }
+        stamp(5);
         // ---- 4. arithmetic, unit by unit; scale / zero once per (unit, column) -------------------------------------------
 #pragma unroll
         for (int i = 0; i < UP; ++i) {
+            if (i == 1) stamp(6);
             float A[8], X = 0.0f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) A[k] = 0.0f;
@@ -297,21 +344,26 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
                 total[k] += sc * (A[k] - 1032.0f * X) + zr * X;  // (q - 8) = (1024 + q) - 1032; a dead unit has X = A = 0
             }
         }
+        stamp(7);
+        first_pass = false;
         __builtin_amdgcn_wave_barrier();  // the list is rewritten by the next pass
     }
+    first_pass = true;
+    stamp(8);
     // ---- reduce: the four row groups of the wave, then the waves in fixed order -------------------------------------------
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        total[k] += __shfl_xor(total[k], 16);
-        total[k] += __shfl_xor(total[k], 32);
+        total[k] = xor_add<16>(total[k]);
+        total[k] = xor_add<32>(total[k]);
     }
     if (lane < 16) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) red[wave * BN + lane * 8 + k] = total[k];
     }
     __syncthreads();
+    stamp(9);
     const uint32_t c = (uint32_t)tile * BN + tid;  // column in the concatenation of the segments (slab / partial index)
-    uint16_t* yp = sg.y ? sg.y + (uint32_t)(tile - sg.tile0) * BN + tid : nullptr;
+    uint16_t* yp = seg_y ? seg_y + (uint32_t)(tile - seg_tile0) * BN + tid : nullptr;
     float sum = 0.0f;
     if (tid < BN) {
 #pragma unroll
@@ -336,31 +388,22 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
             if (tid == 0) __hip_atomic_store(&a.ticket[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if constexpr (PHASE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(10);
+    }
 }
 
-template <bool BF16>
+template <bool BF16, bool PHASE>
 static hipError_t launch_i4(const I4Args& a, int mode, dim3 grid, size_t lds, hipStream_t st) {
     const dim3 block(1024);
     switch (mode) {
-        case TEAL_IN_PLAIN: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 0>), grid, block, 0, st, a); break;
-        case TEAL_IN_RESID_NORM: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 1>), grid, block, lds, st, a); break;
-        case TEAL_IN_SILU_MUL: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 2>), grid, block, lds, st, a); break;
-        default: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 4>), grid, block, lds, st, a); break;
+        case TEAL_IN_PLAIN: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 0, PHASE>), grid, block, 0, st, a); break;
+        case TEAL_IN_RESID_NORM: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 1, PHASE>), grid, block, lds, st, a); break;
+        case TEAL_IN_SILU_MUL: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 2, PHASE>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 4, PHASE>), grid, block, 0, st, a); break;
     }
     return hipGetLastError();
-}
-
-// 16 KB of static LDS + 2 bytes per activation: Z beyond 24 K (the 70B down projection) needs the opt-in
-bool int4_device_init() {
-    bool ok = true;
-    const int bytes = 2 * kI4MaxZ;
-#define TEAL_I4_ATTR(BF, M) ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_gemv_int4_kernel<BF, M>), \
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess
-    TEAL_I4_ATTR(false, 1); TEAL_I4_ATTR(false, 2); TEAL_I4_ATTR(false, 4);
-    TEAL_I4_ATTR(true, 1); TEAL_I4_ATTR(true, 2); TEAL_I4_ATTR(true, 4);
-#undef TEAL_I4_ATTR
-    if (!ok) (void)hipGetLastError();
-    return ok;
 }
 
 // One launch over int4 weights: [producer] -> mask + compaction -> gathered GEMV over every segment (teal_fused_gemv with
@@ -402,7 +445,6 @@ int fused_gemv_i4(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z, i
         case TEAL_IN_SILU_MUL:
             if (!in->x) return TEAL_ERR_ARG;
             a.x = reinterpret_cast<const uint16_t*>(in->x);
-            lds = (size_t)Z * 2;
             break;
         case TEAL_IN_ATTN_MERGE:
             if (!in->x || (in->att_head_dim != 64 && in->att_head_dim != 128) || Z % in->att_head_dim ||
@@ -411,13 +453,12 @@ int fused_gemv_i4(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z, i
             a.att = reinterpret_cast<const float*>(in->x);
             a.att_hd = in->att_head_dim;
             a.att_ns = in->att_nsplit ? in->att_nsplit : 4;
-            lds = (size_t)Z * 2;
             break;
         case TEAL_IN_RESID_NORM:
             if (!in->resid_in || !in->norm_weight || in->nslabs < 0 || (in->nslabs > 0 && !in->slabs)) return TEAL_ERR_ARG;
             if (in->resid_out == in->resid_in && !in->row_index) return TEAL_ERR_ARG;  // must ping-pong
             if (in->nslabs > 0 && (!in->slabs_interleaved || in->nslabs > 8 || !aligned16(in->slabs))) return TEAL_ERR_ARG;
-            if (Z > 16384) return TEAL_ERR_SHAPE;  // 16 elements per thread
+            if (Z > 16384) return TEAL_ERR_SHAPE;  // 16 elements per thread, 32 KB of LDS
             a.x = reinterpret_cast<const uint16_t*>(in->resid_in);
             a.row_index = in->row_index;
             a.slabs = in->slabs;
@@ -429,7 +470,6 @@ int fused_gemv_i4(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z, i
             break;
         default: return TEAL_ERR_ARG;  // TEAL_IN_MASKED: no int4 form
     }
-    if (lds > 2 * (size_t)kI4MaxZ || (lds > 47 * 1024 && !dc->i4_lds_ok)) return TEAL_ERR_SHAPE;  // 16.3 KB static + dynamic <= 64 KB
     const int nunits = Z / 32;
     int split = dc->num_cu / ntiles;
     if (split > 8) split = 8;
@@ -451,7 +491,14 @@ int fused_gemv_i4(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z, i
         }
     }
     const dim3 grid(ntiles, split);
-    const hipError_t e = dtype == TEAL_BF16 ? launch_i4<true>(a, in->mode, grid, lds, st) : launch_i4<false>(a, in->mode, grid, lds, st);
+    hipError_t e;
+    if (g_phase && dtype == TEAL_F16) {  // measurement: the stamping instantiation (fp16 only)
+        a.phase = g_phase + (size_t)g_phase_seq * g_phase_stride;
+        if (g_phase_stride) ++g_phase_seq;
+        e = launch_i4<false, true>(a, in->mode, grid, lds, st);
+    } else {
+        e = dtype == TEAL_BF16 ? launch_i4<true, false>(a, in->mode, grid, lds, st) : launch_i4<false, false>(a, in->mode, grid, lds, st);
+    }
     if (e != hipSuccess) return TEAL_ERR_LAUNCH;
     if (nslabs_out) *nslabs_out = split;
     return TEAL_OK;

@@ -152,7 +152,6 @@ DeviceCtx* device_ctx() {
         return nullptr;
     }
     c->gqa_lds_ok = attention_device_init();
-    c->i4_lds_ok = int4_device_init();
     c->num_cu = cu;
     return c;
 }

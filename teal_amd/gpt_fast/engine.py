@@ -100,8 +100,6 @@ class DecodeEngine:
             for j, lin in enumerate(lins[:-1]):
                 if not int4_kernel_supports(lin.in_features, lin.out_features, lin.groupsize, kvw if j % 5 == 0 else 0):
                     return f"int4 linear {lin.in_features}x{lin.out_features} g{lin.groupsize} is outside the int4 kernel's shape contract"
-            if cfg.intermediate_size > 32768:
-                return "intermediate_size > 32768 (the int4 launch keeps the activation vector in LDS)"
             i8, dt = [False] * len(lins), model.output.weight.dtype
         else:
             i8 = [lin.weight.dtype == torch.int8 for lin in lins]
