@@ -133,12 +133,14 @@ int teal_dense_gemv(const void* x, const void* wT, void* y, int Z, int N, int dt
 /* int4 group-quantised weight-only variant (the reference ships int4-g32/64/128/256 for its dense
  * path only: gpt-fast/quantize.py:58-162 group q-params / quantise / dequantise, :483-526 WeightOnlyInt4Linear over a
  * CUDA-only packed layout).  w[n][m] = (q - 8) * scale[m / G][n] + zero[m / G][n], q in 0..15.
- *   wq               column-gathered nibble image of W^T: row-major [Z][ldb] BYTES (ldb >= N / 2, ldb % 4 == 0), byte j of
- *                    row m = columns 2j (low nibble) and 2j + 1 (high nibble)
+ *   wq               nibble image of W^T by ROW PAIRS: [Z / 2][ldb] BYTES (ldb >= N, ldb % 8 == 0, 8-byte aligned); the
+ *                    32-bit word g of pair-row p holds columns 4g .. 4g+3 of row 2p in its low half (nibble j = column
+ *                    4g + j) and of row 2p + 1 in its high half — two rows of a column unpack into one half2 for a packed
+ *                    dot product; a pair is fetched when either of its rows is kept
  *   scales_and_zeros bf16 [Z / G][N][2] = {scale, zero}, exactly the reference's tensor (quantize.py:79-93)
  * N, N_q, N_kv multiples of 128; Z a multiple of G; x / y fp16 or bf16 (dtype).  N_kv = 0, N_q = N: one threshold.
- * One launch (split-K over groups folded in by arrival tickets); fp32 accumulation, scale / zero applied once per
- * (group, column), one rounding. */
+ * One launch (split-K over 32-row units folded in by arrival tickets); fp32 accumulation, scale / zero applied once per
+ * (unit, column), one rounding. */
 int teal_sparse_qkv_gemv_i4(const void* x, const void* wq, const void* scales_and_zeros, void* y, float tau_q, float tau_k,
                             float tau_v, int Z, int N, int N_q, int N_kv, int ldb, int groupsize, int dtype, void* ws,
                             size_t ws_bytes, void* stream);
@@ -208,7 +210,7 @@ typedef struct teal_gemv_out {
                             * y = round(fp32(sum q*x) * fp32(scale)) — one rounding, where the reference's
                             * F.linear(x, w.to(dtype)) * scales rounds twice */
     const void* scale[3];  /* int8: see above.  int4 (weight_bits = 4, gpt-fast/quantize.py:58-162, 483-526): w[i] = packed image
-                            * of W^T, [Z][ld BYTES], byte j of a row = columns 2j (low nibble) and 2j + 1; scale[i] = the
+                            * of W^T by row pairs, [Z / 2][ld BYTES] (see teal_sparse_qkv_gemv_i4); scale[i] = the
                             * reference's scales_and_zeros tensor of that image, bf16 [Z / groupsize][scale_ld[i]][2]; col0
                             * addresses both.  ncols multiples of 128; in modes PLAIN, RESID_NORM (interleaved slabs, <= 8),
                             * SILU_MUL, ATTN_MERGE; out modes ROUNDED and SLABS */

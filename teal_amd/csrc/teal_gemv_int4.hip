@@ -5,16 +5,23 @@
 // whose forward is a CUDA-only tinygemm op) and lists quantised TEAL as missing (README.md:110).  Semantics restated:
 //     w[n][m] = (q[n][m] - 8) * scale[m / G][n] + zero[m / G][n]        q in 0..15, scale / zero bf16, G = group size
 //     y[n]    = sum over kept m of x[m] * w[n][m]                        kept: float32(|x[m]|) > float32(tau), strict
-// Layout here (ours to choose — the reference's packed layout is tinygemm's): the column-gathered image of W^T,
-// wq[Z][ldb] bytes, byte j of row m = columns 2j (low nibble) and 2j + 1 (high nibble); scales_and_zeros [Z / G][N][2]
-// bf16 exactly as the reference stores them (quantize.py:79-93).
+// scales_and_zeros [Z / G][N][2] bf16 exactly as the reference stores them (quantize.py:79-93).
+//
+// Weight layout (ours to choose — the reference's packed layout is tinygemm's): the image of W^T by ROW PAIRS,
+// wq[Z / 2][ldb] bytes; dword g of pair-row p holds columns 4g .. 4g+3 of row 2p in its low half (nibble j = column 4g+j)
+// and of row 2p+1 in its high half.  One mask-and-or under an fp16 exponent then yields the half2 (1024 + q[2p][c],
+// 1024 + q[2p+1][c]) and one v_dot2_f32_f16 against (x[2p], x[2p+1]) does two multiply-adds in fp32: ~1.2 VALU instructions
+// per multiply-add where a row-per-dword layout needs ~2.6 (unpack, convert, fma) — and this kernel is bound by the VALU,
+// not by HBM: 4 waves per SIMD share it, and at 4 bits a byte of weights carries 4x the arithmetic of fp16.  A pair is
+// fetched when EITHER row is kept (the other row's x enters as 0, which is exact): at 50 % sparsity 75 % of the pairs,
+// i.e. 1.5x the bytes of a row-granular gather — bytes this kernel has to spare.
 //
 // Kernel: one 16-wave workgroup = one 128-column tile x one slice of the 32-row units.  A wave owns units; per unit it
-// ballots the keep mask, compacts the kept rows into its LDS list, deals them to its four 16-lane row groups (a lane = 8
-// columns = one dword of a 64-byte row segment), accumulates A = sum x * (1024 + q) and X = sum x in fp32 and applies
-// scale / zero ONCE per (unit, column):  y += scale * (A - 1032 X) + zero * X  — the group parameters cost 32 bytes per
-// lane and unit instead of per row.  Split-K over units is folded into the one launch by arrival tickets (the last slice
-// of a tile sums the partials in slice order: deterministic, no atomics on the data).  No MFMA on purpose.
+// ballots the keep mask, compacts the kept pairs into its LDS lists, deals them to its four 16-lane groups (a lane = 8
+// columns = 8 bytes of a 128-byte pair-row segment), accumulates A = sum x * (bias + q) and X = sum x in fp32 and applies
+// scale / zero ONCE per (unit, column):  y += scale * (A - (bias + 8) X) + zero * X  — the group parameters cost 32 bytes
+// per lane and unit instead of per row.  Split-K over units is folded into the one launch by arrival tickets (the last
+// slice of a tile sums the partials in slice order: deterministic, no atomics on the data).  No MFMA on purpose.
 //
 // The kernel takes the producers of the fused decode step like the 16-bit one (teal_gemv_fast.h): MODE 1 residual + fp32
 // slabs -> RMSNorm (every workgroup recomputes the vector into LDS: the norm needs all of it), MODE 2 silu(gate) * up and
@@ -28,20 +35,21 @@
 namespace teal {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 constexpr int kPhaseRow = 32;  // uint64 stamps per workgroup (as in teal_gemv_kernel.h)
 
 struct I4Seg {
     const unsigned char* wq;  // first byte of the segment's columns in row 0
     const uint16_t* sz;       // (scale, zero) of the segment's first column in group 0
     uint16_t* y;              // rounded output of the segment (null when the launch leaves slabs)
-    int ldb, szld;            // row stride of wq in bytes; columns per row of sz
+    int ldb, szld;            // pair-row stride of wq in bytes; columns per row of sz
     int tile0;                // first 128-column tile of the segment
     float tau;
 };
 
 struct I4Args {
     I4Seg seg[3];
-    int nseg, Z, G;
+    int nseg, Z, gshift;      // gshift: log2 of the group size
     // producer
     const uint16_t* x;        // MODE 0: x[Z]; MODE 2: gate[Z] | up[Z]; MODE 1: residual (table with row_index)
     const int* row_index;
@@ -59,12 +67,15 @@ struct I4Args {
     unsigned long long* phase;  // PHASE instantiations: kPhaseRow stamps per workgroup (teal_set_phase_buffer)
 };
 
-// A wave handles its 32-row units in PASSES of four; all activations and group parameters of the pass leave first; the
-// ballots compact (row, x) pairs into the wave's LDS list with mbcnt ranks (round 2 dealt the rows through a serial scalar
-// count-trailing-zeros chain: 24 us per 7B launch for 17 MB); then EVERY row load of the pass is issued before the first is
-// consumed.  scale / zero are applied per UNIT with the parameters of the unit's group — y += scale * (A_u - 1032 X_u) +
-// zero * X_u is linear in the units of a group — so units are independent whatever the group size (A carries 1024 + q: two
-// nibbles become two halves by one and_or under the exponent bits, the byte trick of the int8 kernel).
+// A wave handles its 32-row units in PASSES of four: the activations of the pass first; the ballots compact the kept row
+// PAIRS of each unit into the wave's LDS lists (pair index, and the two activations as a half2 with a dropped row's at 0)
+// with mbcnt ranks; then each of the wave's four 16-lane groups takes ONE unit of the pass — its own group parameters, its
+// own accumulators, no cross-lane traffic until the end of the kernel — and EVERY pair-row load of the pass is issued before
+// the first is consumed.  (Four groups sharing the pairs of one unit would each fetch that unit's 32 bytes of parameters
+// per lane: the launch was then bound by the CU's 64 bytes / clock of vector-memory issue, half of it those parameters.)  scale / zero are applied per UNIT with the parameters of the unit's
+// group — y += scale * (A_u - c X_u) + zero * X_u is linear in the units of a group — so units are independent whatever
+// the group size.  fp16 activations: nibbles 1 and 3 of a half are used where they lie, as 1024 + 16 q (no shift); their
+// columns are rescaled at the flush.  bf16 activations: bias 128 (7 mantissa bits), every nibble shifted down.
 // PHASE (measurement builds only): thread 0 stamps [0] entry, [1] arguments in registers, [2] producer done (MODE 1), and for
 // its wave's first pass [3] activations ready, [4] list written, [5] every load issued, [6] first unit consumed, [7] pass
 // done; [8] all passes done, [9] past the reduce barrier, [10] outputs stored.  100 MHz wall clock (scripts/int4_phase.py).
@@ -75,13 +86,14 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
     if constexpr (PHASE) t_entry = wall_clock64();
     extern __shared__ __align__(16) uint16_t xs[];  // MODE 1: the normalised activation vector, Z entries
     __shared__ float red[WAVES * BN];
-    __shared__ uint32_t lists[WAVES][UP * 32];
+    __shared__ __align__(16) uint32_t list_i[WAVES][UP * 16];  // pair index inside the unit, 16 slots per unit, ascending
+    __shared__ __align__(16) uint32_t list_x[WAVES][UP * 16];  // (x[2p], x[2p + 1]) as 16-bit halves, a dropped row's = 0
     __shared__ float wsum[WAVES];
     __shared__ float tflag;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x, slice = blockIdx.y, split = gridDim.y;
-    const int rs = lane >> 4, cl = lane & 15;  // row group of the wave, 4-byte column slot of the tile
+    const int rs = lane >> 4, cl = lane & 15;  // pair slot of the wave, 8-byte column slot of the tile
     const int Z = a.Z;
     bool first_pass = true;
     auto stamp = [&](const int i) {
@@ -94,7 +106,7 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
     // prologue and again in the epilogue
 #define TEAL_I4_SEG_ARGS(g) "s"((g).wq), "s"((g).sz), "s"((g).y), "s"((g).ldb), "s"((g).szld), "s"((g).tile0), "s"((g).tau)
     asm volatile("" ::TEAL_I4_SEG_ARGS(a.seg[0]), TEAL_I4_SEG_ARGS(a.seg[1]), TEAL_I4_SEG_ARGS(a.seg[2]));
-    asm volatile("" ::"s"(a.nseg), "s"(a.Z), "s"(a.G), "s"(a.x), "s"(a.row_index), "s"(a.slabs), "s"(a.nslabs), "s"(a.norm_w),
+    asm volatile("" ::"s"(a.nseg), "s"(a.Z), "s"(a.gshift), "s"(a.x), "s"(a.row_index), "s"(a.slabs), "s"(a.nslabs), "s"(a.norm_w),
                  "s"(a.eps), "s"(a.resid_out), "s"(a.att), "s"(a.att_hd), "s"(a.att_ns), "s"(a.ws), "s"(a.ws_es), "s"(a.ws_ss),
                  "s"(a.ticket));
 #undef TEAL_I4_SEG_ARGS
@@ -106,40 +118,41 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
     // ---- producer -------------------------------------------------------------------------------------------------------
     if constexpr (MODE == 1) {
         // h = resid + round(sum slabs);  x = round(round(h * rstd) * w)          gpt-fast/model.py:158-161, 289-291
+        // KM elements per thread (4: Z <= 4096, 8: Z <= 8192, else 16); every load is unconditional (index clamped) and
+        // leaves in one batch (KM = 16: per block of 4 elements)
         const uint16_t* resid = a.x;
         if (a.row_index) resid += (size_t)a.row_index[0] * (size_t)Z;  // embedding row of the current token
-        const int kmax = (Z + 1023) >> 10;  // <= 16 elements per thread
         const uint32_t stride = (uint32_t)(a.nslabs + 3) & ~3u;
-        uint32_t wb[16];
+        const int nslabs = a.nslabs;
+        const bool writer = a.resid_out && tile == 0 && slice == 0;
+        auto produce = [&](auto km_tag) {
+            constexpr int KM = decltype(km_tag)::value, KB = KM <= 8 ? KM : 4;
+            uint32_t wb[KM];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int m = tid + (k << 10);
-            wb[k] = (k < kmax && m < Z) ? a.norm_w[m] : 0u;
-        }
-        float ss = 0.0f;
+            for (int k = 0; k < KM; ++k) wb[k] = a.norm_w[min(tid + (k << 10), Z - 1)];
+            float ss = 0.0f;
 #pragma unroll
-        for (int k0 = 0; k0 < 16; k0 += 4) {
-            if (k0 < kmax) {
-                uint32_t rb[4];
-                f32x4 v0[4], v1[4];
+            for (int k0 = 0; k0 < KM; k0 += KB) {
+                uint32_t rb[KB];
+                f32x4 v0[KB], v1[KB];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < KB; ++j) {
                     const uint32_t m = (uint32_t)min(tid + ((k0 + j) << 10), Z - 1);
                     rb[j] = resid[m];
-                    if (a.nslabs > 0) v0[j] = *reinterpret_cast<const f32x4*>(a.slabs + m * stride);
-                    if (a.nslabs > 4) v1[j] = *reinterpret_cast<const f32x4*>(a.slabs + m * stride + 4);
+                    if (nslabs > 0) v0[j] = *reinterpret_cast<const f32x4*>(a.slabs + m * stride);
+                    if (nslabs > 4) v1[j] = *reinterpret_cast<const f32x4*>(a.slabs + m * stride + 4);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < KB; ++j) {
                     const int m = tid + ((k0 + j) << 10);
                     float r = bits_to_float(rb[j], BF16);
-                    if (a.nslabs > 0) {  // slab order 0, 1, 2, ... (the order of the ordered reduce); an absent slab adds 0.0f
+                    if (nslabs > 0) {  // slab order 0, 1, 2, ... (the order of the ordered reduce); an absent slab adds 0.0f
                         float sacc = 0.0f;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) sacc += (q < a.nslabs) ? v0[j][q] : 0.0f;
-                        if (a.nslabs > 4) {
+                        for (int q = 0; q < 4; ++q) sacc += (q < nslabs) ? v0[j][q] : 0.0f;
+                        if (nslabs > 4) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) sacc += (4 + q < a.nslabs) ? v1[j][q] : 0.0f;
+                            for (int q = 0; q < 4; ++q) sacc += (4 + q < nslabs) ? v1[j][q] : 0.0f;
                         }
                         const float yv = bits_to_float(float_to_bits<BF16>(sacc), BF16);
                         r = bits_to_float(float_to_bits<BF16>(r + yv), BF16);
@@ -150,24 +163,26 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
                     }
                 }
             }
-        }
-        ss = wave_sum_f(ss);
-        if (lane == 0) wsum[wave] = ss;
-        __syncthreads();
-        float tot = lane < WAVES ? wsum[lane] : 0.0f;
-        tot = wave_sum_f(tot);
-        const float rstd = rsqrtf(tot / (float)Z + a.eps);
-        const bool writer = a.resid_out && tile == 0 && slice == 0;
+            ss = wave_sum_f(ss);
+            if (lane == 0) wsum[wave] = ss;
+            __syncthreads();
+            float tot = lane < WAVES ? wsum[lane] : 0.0f;
+            tot = wave_sum_f(tot);
+            const float rstd = rsqrtf(tot / (float)Z + a.eps);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int m = tid + (k << 10);
-            if (k < kmax && m < Z) {
-                const uint32_t hb = xs[m];  // this thread's own element
-                const float xn = bits_to_float(float_to_bits<BF16>(bits_to_float(hb, BF16) * rstd), BF16);
-                xs[m] = float_to_bits<BF16>(xn * bits_to_float(wb[k], BF16));
-                if (writer) a.resid_out[m] = (uint16_t)hb;
+            for (int k = 0; k < KM; ++k) {
+                const int m = tid + (k << 10);
+                if (m < Z) {
+                    const uint32_t hb = xs[m];  // this thread's own element
+                    const float xn = bits_to_float(float_to_bits<BF16>(bits_to_float(hb, BF16) * rstd), BF16);
+                    xs[m] = float_to_bits<BF16>(xn * bits_to_float(wb[k], BF16));
+                    if (writer) a.resid_out[m] = (uint16_t)hb;
+                }
             }
-        }
+        };
+        if (Z <= 4096) produce(std::integral_constant<int, 4>{});
+        else if (Z <= 8192) produce(std::integral_constant<int, 8>{});
+        else produce(std::integral_constant<int, 16>{});
         __syncthreads();
     }
 
@@ -186,10 +201,17 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
     const float tau = TEAL_I4_SEG(tau);
 #undef TEAL_I4_SEG
     const uint32_t scol = (uint32_t)(tile - seg_tile0) * BN + cl * 8;  // the lane's first column inside the segment
-    const unsigned char* wp = seg_wq + (scol >> 1);
+    const unsigned char* wp = seg_wq + scol;  // a pair-row holds one byte per column
     const uint16_t* szb = seg_sz + (size_t)scol * 2;
     const int nunits = Z >> 5;
-    uint32_t* list = lists[wave];
+    uint32_t* li = list_i[wave];
+    uint32_t* lx = list_x[wave];
+    constexpr uint32_t kBias = BF16 ? 0x43004300u : 0x64006400u;  // half2 (128, 128) bf16 / (1024, 1024) fp16
+    constexpr uint32_t kOnes = BF16 ? 0x3F803F80u : 0x3C003C00u;  // half2 (1, 1)
+    auto dot2 = [](const uint32_t w2, const uint32_t x2, const float acc) {
+        if constexpr (BF16) return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w2), __builtin_bit_cast(bf16x2_t, x2), acc, false);
+        else return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, w2), __builtin_bit_cast(f16x2, x2), acc, false);
+    };
     float total[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) total[k] = 0.0f;
@@ -276,77 +298,100 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
             }
         }
         stamp(3);
-        // ---- 2. ballots -> (row in unit : 16 | x bits : 16) pairs in the wave's list, ascending -------------------------
-        int off[UP + 1];
-        off[0] = 0;
+        // ---- 2. ballots -> kept row pairs of every unit in the wave's lists (16 slots per unit, ascending) -----------------
+        int cnt[UP];  // kept pairs of unit i (wave-uniform)
 #pragma unroll
         for (int i = 0; i < UP; ++i) {
             const float v = bits_to_float(xb[i], BF16);
-            const uint32_t mask = live[i] ? (uint32_t)__ballot(keep_rule(v, tau) || (v != v)) : 0u;  // lanes 32..63 mirror 0..31
-            if (lane < 32 && ((mask >> lane) & 1u))
-                list[off[i] + __builtin_amdgcn_mbcnt_lo(mask, 0u)] = ((uint32_t)lane << 16) | xb[i];
-            off[i + 1] = off[i] + __popc(mask);
+            const bool keep = keep_rule(v, tau) || (v != v);
+            const uint32_t mask = live[i] ? (uint32_t)__ballot(keep) : 0u;  // lanes 32..63 mirror 0..31
+            const uint32_t pm = (mask | (mask >> 1)) & 0x55555555u;          // bit 2p: pair p has a kept row
+            const uint32_t xm = keep ? xb[i] : 0u;
+            const uint32_t xn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)xm, 0xB1, 0xf, 0xf, false);  // lane ^ 1
+            if (lane < 32 && ((pm >> lane) & 1u)) {  // even lanes of kept pairs
+                const uint32_t slot = (uint32_t)i * 16u + __builtin_amdgcn_mbcnt_lo(pm, 0u);
+                li[slot] = (uint32_t)lane >> 1;
+                lx[slot] = xm | (xn << 16);
+            }
+            cnt[i] = __popc(pm);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         stamp(4);
-        // ---- 3. group parameters (wanted at the end of the pass only: requested after the producer has let go of its
-        //         registers) and every row load of the pass (up to 8 steps of 4 rows per unit) --------------------------------
-        u32x4 sz0[UP], sz1[UP];
+        // ---- 3. 16-lane group rs takes unit rs of the pass: its group parameters (32 bytes per lane, once) and every
+        //         pair-row load of its unit, one pair per step, all issued before the first is consumed ----------------------
+        static_assert(UP == 4, "one unit per 16-lane group");
+        const int cntv = rs == 0 ? cnt[0] : (rs == 1 ? cnt[1] : (rs == 2 ? cnt[2] : cnt[3]));
+        const int maxcnt = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));  // wave-uniform step count
+        const int uv = min(u0 + rs * ustride, nunits - 1);                 // (a dead unit has no pairs: any valid address)
+        const u32x4* szp = reinterpret_cast<const u32x4*>(szb + (size_t)((uv << 5) >> a.gshift) * szld * 2);
+        const u32x4 sz0 = szp[0], sz1 = szp[1];
+        const unsigned char* wrow = wp + (size_t)(uv << 4) * ldb;  // first pair-row of the group's unit
+        u32x2 d[16];
+        {
+            u32x4 pidx[4];
 #pragma unroll
-        for (int i = 0; i < UP; ++i) {
-            const int uu = live[i] ? u0 + i * ustride : u0;  // wave-uniform: the group index stays in scalar registers
-            const u32x4* szp = reinterpret_cast<const u32x4*>(szb + (size_t)((uu << 5) / a.G) * szld * 2);
-            sz0[i] = szp[0];
-            sz1[i] = szp[1];
-        }
-        uint32_t d[UP][8];
+            for (int q = 0; q < 4; ++q) pidx[q] = *reinterpret_cast<const u32x4*>(li + rs * 16 + q * 4);
 #pragma unroll
-        for (int i = 0; i < UP; ++i) {
-            const int row0 = (live[i] ? u0 + i * ustride : u0) << 5;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                d[i][r] = 0u;
-                if (off[i] + 4 * r < off[i + 1]) {  // wave-uniform: this step has rows
-                    const int e = off[i] + 4 * r + rs;
-                    if (e < off[i + 1])
-                        d[i][r] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(wp + (size_t)(row0 + (int)(list[e] >> 16)) * ldb));
+            for (int r = 0; r < 16; ++r) {
+                d[r] = u32x2{0u, 0u};
+                if (r < maxcnt) {     // wave-uniform
+                    if (r < cntv)     // (a slot past the count holds a stale index: never dereferenced)
+                        d[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wrow + (size_t)pidx[r >> 2][r & 3] * ldb));
                 }
             }
         }
         stamp(5);
-        // ---- 4. arithmetic, unit by unit; scale / zero once per (unit, column) -------------------------------------------
-#pragma unroll
-        for (int i = 0; i < UP; ++i) {
-            if (i == 1) stamp(6);
+        // ---- 4. arithmetic; scale / zero once per (unit, column) ---------------------------------------------------------------
+        {
             float A[8], X = 0.0f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) A[k] = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                if (off[i] + 4 * r < off[i + 1]) {
-                    const int e = off[i] + 4 * r + rs;
-                    const float xr = e < off[i + 1] ? bits_to_float(list[e] & 0xFFFFu, BF16) : 0.0f;  // a lane without a row adds 0
+            for (int q = 0; q < 4; ++q) {
+                if (q == 1) stamp(6);
+                if (q * 4 < maxcnt) {
+                    const u32x4 xx4 = *reinterpret_cast<const u32x4*>(lx + rs * 16 + q * 4);
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const f16x2 hq = __builtin_bit_cast(f16x2, ((d[i][r] >> (4 * jj)) & 0x000F000Fu) | 0x64006400u);
-                        A[jj] = fmaf((float)hq.x, xr, A[jj]);
-                        A[jj + 4] = fmaf((float)hq.y, xr, A[jj + 4]);
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int r = q * 4 + rr;
+                        if (r < maxcnt) {
+                            const uint32_t x2 = (r < cntv) ? xx4[rr] : 0u;  // a group past its count adds 0
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const uint32_t w = d[r][h];
+                                if constexpr (BF16) {
+#pragma unroll
+                                    for (int jj = 0; jj < 4; ++jj) A[4 * h + jj] = dot2(((w >> (4 * jj)) & 0x000F000Fu) | kBias, x2, A[4 * h + jj]);
+                                } else {
+                                    const uint32_t w8 = w >> 8;
+                                    A[4 * h + 0] = dot2((w & 0x000F000Fu) | kBias, x2, A[4 * h + 0]);
+                                    A[4 * h + 1] = dot2((w & 0x00F000F0u) | kBias, x2, A[4 * h + 1]);  // 1024 + 16 q
+                                    A[4 * h + 2] = dot2((w8 & 0x000F000Fu) | kBias, x2, A[4 * h + 2]);
+                                    A[4 * h + 3] = dot2((w8 & 0x00F000F0u) | kBias, x2, A[4 * h + 3]);  // 1024 + 16 q
+                                }
+                            }
+                            X = dot2(kOnes, x2, X);
+                        }
                     }
-                    X += xr;
                 }
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const uint32_t pr = k < 4 ? sz0[i][k] : sz1[i][k - 4];  // bf16 pair: scale (low half), zero (high half)
+                const uint32_t pr = k < 4 ? sz0[k] : sz1[k - 4];  // bf16 pair: scale (low half), zero (high half)
                 const float sc = __uint_as_float(pr << 16), zr = __uint_as_float(pr & 0xFFFF0000u);
-                total[k] += sc * (A[k] - 1032.0f * X) + zr * X;  // (q - 8) = (1024 + q) - 1032; a dead unit has X = A = 0
+                // sum x (q - 8) from the biased accumulator; a dead unit has X = A = 0
+                float t;
+                if constexpr (BF16) t = A[k] - 136.0f * X;                         // (128 + q) - 136
+                else if (k & 1) t = fmaf(A[k], 0.0625f, -72.0f * X);               // ((1024 + 16 q) - 1024) / 16 - 8
+                else t = A[k] - 1032.0f * X;                                       // (1024 + q) - 1032
+                total[k] += sc * t + zr * X;
             }
         }
         stamp(7);
         first_pass = false;
-        __builtin_amdgcn_wave_barrier();  // the list is rewritten by the next pass
+        __builtin_amdgcn_wave_barrier();  // the lists are rewritten by the next pass
     }
     first_pass = true;
     stamp(8);
@@ -420,16 +465,16 @@ int fused_gemv_i4(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z, i
     DeviceCtx* dc = device_ctx();
     if (!dc) return TEAL_ERR_NO_DEVICE;
     I4Args a = {};
-    a.nseg = out->nseg; a.Z = Z; a.G = G;
+    a.nseg = out->nseg; a.Z = Z; a.gshift = G == 32 ? 5 : (G == 64 ? 6 : (G == 128 ? 7 : 8));
     int ntiles = 0, N = 0;
     for (int i = 0; i < out->nseg; ++i) {
         const int nc = out->ncols[i], c0 = out->col0[i], ldb = out->ld[i], szld = out->scale_ld[i];
         if (!out->w[i] || !out->scale[i] || nc <= 0 || (nc % 128) || c0 < 0 || (c0 & 7)) return TEAL_ERR_SHAPE;
-        if (ldb < (c0 + nc) / 2 || (ldb & 3) || szld < c0 + nc) return TEAL_ERR_SHAPE;
-        if ((reinterpret_cast<uintptr_t>(out->w[i]) & 3u) || !aligned16(out->scale[i])) return TEAL_ERR_ALIGN;
+        if (ldb < c0 + nc || (ldb & 7) || szld < c0 + nc) return TEAL_ERR_SHAPE;  // a pair-row: one byte per column
+        if ((reinterpret_cast<uintptr_t>(out->w[i]) & 7u) || !aligned16(out->scale[i])) return TEAL_ERR_ALIGN;
         if (out->mode == TEAL_OUT_ROUNDED && !out->y[i]) return TEAL_ERR_ARG;
         I4Seg& sg = a.seg[i];
-        sg.wq = reinterpret_cast<const unsigned char*>(out->w[i]) + c0 / 2;
+        sg.wq = reinterpret_cast<const unsigned char*>(out->w[i]) + c0;
         sg.sz = reinterpret_cast<const uint16_t*>(out->scale[i]) + (size_t)c0 * 2;
         sg.y = out->mode == TEAL_OUT_ROUNDED ? reinterpret_cast<uint16_t*>(out->y[i]) : nullptr;
         sg.ldb = ldb; sg.szld = szld; sg.tile0 = ntiles; sg.tau = out->tau[i];
@@ -514,7 +559,7 @@ extern "C" int teal_sparse_qkv_gemv_i4(const void* x, const void* wq, const void
     if (!x || !wq || !scales_and_zeros || !y || Z <= 0 || N <= 0) return TEAL_ERR_ARG;
     if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
     if (groupsize != 32 && groupsize != 64 && groupsize != 128 && groupsize != 256) return TEAL_ERR_ARG;
-    if ((N % 128) || (Z % groupsize) || Z > 65536 || ldb < N / 2 || (ldb & 3)) return TEAL_ERR_SHAPE;
+    if ((N % 128) || (Z % groupsize) || Z > 65536 || ldb < N || (ldb & 7)) return TEAL_ERR_SHAPE;
     if (N_q <= 0 || N_kv < 0 || N_q + 2 * N_kv != N || (N_q % 128) || (N_kv % 128)) return TEAL_ERR_SHAPE;
     teal_gemv_in_t in = {};
     in.mode = TEAL_IN_PLAIN;

@@ -146,16 +146,16 @@ def splitk_sparse_gemv_int8(x: torch.Tensor, weight: torch.Tensor, scales: torch
 
 def qkv_gemv_int4(x: torch.Tensor, weight: torch.Tensor, scales_and_zeros: torch.Tensor, threshold_q: float, threshold_k: float,
                   threshold_v: float, sparsity_bin: int, kv_size: int) -> torch.Tensor:
-    """qkv_gemv on int4 group-quantised weights: weight = packed nibble image of W^T, uint8
-    [Z][N / 2 + pad] (quantize.pack_int4_colmajor); scales_and_zeros bf16 [Z / G][N][2] (the reference's tensor,
+    """qkv_gemv on int4 group-quantised weights: weight = packed nibble image of W^T by row
+    pairs, uint8 [Z / 2][N + pad] (quantize.pack_int4_colmajor); scales_and_zeros bf16 [Z / G][N][2] (the reference's tensor,
     gpt-fast/quantize.py:79-93).  y = sparse(x) @ dequant(W).T, fp32 accumulation, one rounding.  kv_size = 0: one threshold."""
     if not x.is_cuda or not weight.is_cuda or not scales_and_zeros.is_cuda:
         raise RuntimeError("teal_amd sparse GEMV runs on the GPU only (HIP kernels; there is no CPU fallback)")
     if weight.dtype != torch.uint8 or weight.dim() != 2 or weight.stride(1) != 1:
-        raise RuntimeError("int4 weight must be the packed uint8 image [Z][bytes] (quantize.pack_int4_colmajor)")
+        raise RuntimeError("int4 weight must be the packed uint8 image [Z / 2][bytes] (quantize.pack_int4_colmajor)")
     if scales_and_zeros.dtype != torch.bfloat16 or scales_and_zeros.dim() != 3 or scales_and_zeros.shape[2] != 2 or not scales_and_zeros.is_contiguous():
         raise TypeError("scales_and_zeros must be a contiguous bf16 [Z / G][N][2] tensor")
-    Z, N = weight.shape[0], scales_and_zeros.shape[1]
+    Z, N = 2 * weight.shape[0], scales_and_zeros.shape[1]
     G = Z // scales_and_zeros.shape[0]
     assert x.shape[2] == Z and scales_and_zeros.shape[0] * G == Z
     B, S, _ = x.shape
@@ -268,7 +268,7 @@ def _int4_prefill(x: torch.Tensor, weight: torch.Tensor, scales_and_zeros: torch
     # F.linear on the dequantised weight (quantize.WeightOnlyInt4Linear.forward)
     from ..quantize import group_dequantize_tensor, unpack_int4_colmajor
     N = scales_and_zeros.shape[1]
-    G = weight.shape[0] // scales_and_zeros.shape[0]
+    G = 2 * weight.shape[0] // scales_and_zeros.shape[0]  # the image holds row pairs
     w = group_dequantize_tensor(unpack_int4_colmajor(weight, N), scales_and_zeros.float(), 4, G).to(x.dtype)
     return torch.matmul(x, w.T)
 

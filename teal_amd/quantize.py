@@ -133,19 +133,23 @@ def group_dequantize_tensor(q: torch.Tensor, scales_and_zeros: torch.Tensor, n_b
 
 
 def pack_int4_colmajor(q: torch.Tensor, pad_bytes: int = INT4_ROW_PAD_BYTES) -> torch.Tensor:
-    """q int [N, Z] in 0..15 -> uint8 [Z][N / 2 + pad]: byte j of row m = columns 2j (low nibble), 2j + 1 (high nibble)."""
+    """q int [N, Z] in 0..15 -> uint8 [Z / 2][N + pad], the image of W^T by row pairs the kernel reads (include/teal_hip.h,
+    teal_sparse_qkv_gemv_i4): 32-bit word g of pair-row p = columns 4g .. 4g+3 of row 2p in the low half (nibble j = column
+    4g + j) and of row 2p + 1 in the high half, i.e. bytes [2p: c0|c1<<4, 2p: c2|c3<<4, 2p+1: c0|c1<<4, 2p+1: c2|c3<<4]."""
     N, Z = q.shape
-    assert N % 2 == 0
+    assert N % 4 == 0 and Z % 2 == 0
     qt = q.T.contiguous().to(torch.uint8)  # [Z, N]
-    out = torch.zeros(Z, N // 2 + pad_bytes, dtype=torch.uint8, device=q.device)
-    out[:, : N // 2] = qt[:, 0::2] | (qt[:, 1::2] << 4)
+    nib = (qt[:, 0::2] | (qt[:, 1::2] << 4)).view(Z // 2, 2, N // 4, 2)  # [pair, row of the pair, word, byte of the half]
+    out = torch.zeros(Z // 2, N + pad_bytes, dtype=torch.uint8, device=q.device)
+    out[:, :N] = nib.permute(0, 2, 1, 3).reshape(Z // 2, N)
     return out
 
 
 def unpack_int4_colmajor(packed: torch.Tensor, N: int) -> torch.Tensor:
     """inverse of pack_int4_colmajor -> int32 [N, Z]"""
-    b = packed[:, : N // 2]
-    qt = torch.stack((b & 0xF, b >> 4), dim=-1).reshape(b.shape[0], N)
+    P = packed.shape[0]
+    nib = packed[:, :N].reshape(P, N // 4, 2, 2).permute(0, 2, 1, 3).reshape(2 * P, N // 2)  # [Z, N / 2]: byte j = columns 2j, 2j+1
+    qt = torch.stack((nib & 0xF, nib >> 4), dim=-1).reshape(2 * P, N)
     return qt.T.contiguous().to(torch.int32)
 
 
@@ -158,7 +162,7 @@ class WeightOnlyInt4Linear(nn.Module):
         super().__init__()
         assert in_features % groupsize == 0 and out_features % 8 == 0
         self.in_features, self.out_features, self.groupsize = in_features, out_features, groupsize
-        self.register_buffer("weight", torch.zeros((in_features, out_features // 2 + INT4_ROW_PAD_BYTES), dtype=torch.uint8, device=device))
+        self.register_buffer("weight", torch.zeros((in_features // 2, out_features + INT4_ROW_PAD_BYTES), dtype=torch.uint8, device=device))
         self.register_buffer("scales_and_zeros", torch.zeros((in_features // groupsize, out_features, 2), dtype=torch.bfloat16, device=device))
 
     def dequantized(self, dtype) -> torch.Tensor:
@@ -217,7 +221,7 @@ def quantize_model_int4(model: nn.Module, groupsize: int = 32, skip=("output",),
 def convert_for_runtime_int4(model: nn.Module, groupsize: int = 32, skip=("output",), _kv: int = None) -> nn.Module:
     """Replace the projections by EMPTY WeightOnlyInt4Linear modules (role of WeightOnlyInt4QuantHandler.convert_for_runtime,
     quantize.py:417-443): the shape a state dict written by quantize_model_int4(...).state_dict() loads into — packed
-    `weight` uint8 [Z][N / 2 + 64] (column-gathered nibble image) and `scales_and_zeros` bf16 [Z / G][N][2].
+    `weight` uint8 [Z / 2][N + 64] (nibble image of W^T by row pairs) and `scales_and_zeros` bf16 [Z / G][N][2].
     NOT interchangeable with the reference's *int4* checkpoints: those hold the CUDA tinygemm tile layout produced by
     aten._convert_weight_to_int4pack (quantize.py:366-372), which only that kernel reads; scales_and_zeros is the same
     tensor in both."""

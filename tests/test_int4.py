@@ -27,7 +27,7 @@ def test_int4_quantiser_bit_identical_to_reference(tag):
     wdq = group_dequantize_tensor(q, sz.float(), 4, G)
     assert np.array_equal(wdq[:16].float().numpy(), k[f"{tag}_wdq_rows16"])
     packed = pack_int4_colmajor(q)
-    assert packed.shape[0] == Z and packed.dtype == torch.uint8 and torch.equal(unpack_int4_colmajor(packed, N), q)
+    assert packed.shape[0] == Z // 2 and packed.dtype == torch.uint8 and torch.equal(unpack_int4_colmajor(packed, N), q)
 
 
 def _truth(x, q, sz, G, cols):
