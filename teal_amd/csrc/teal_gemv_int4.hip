@@ -79,14 +79,17 @@ struct I4Args {
 // PHASE (measurement builds only): thread 0 stamps [0] entry, [1] arguments in registers, [2] producer done (MODE 1), and for
 // its wave's first pass [3] activations ready, [4] list written, [5] every load issued, [6] first unit consumed, [7] pass
 // done; [8] all passes done, [9] past the reduce barrier, [10] outputs stored.  100 MHz wall clock (scripts/int4_phase.py).
-template <bool BF16, int MODE, bool PHASE = false>
+// SHARE: launches that leave a wave one or two units (the 7B wo projection over 256 workgroups: one) — the four lane groups
+// SHARE each unit, pairs dealt round-robin, instead of three of them idling while one walks 12 pairs on its own.
+template <bool BF16, int MODE, bool SHARE, bool PHASE = false>
 __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) {
-    constexpr int WAVES = 16, BN = 128, UP = 4;  // UP: units per pass
+    constexpr int WAVES = 16, BN = 128, UP = SHARE ? 2 : 4;  // UP: units per pass
     unsigned long long t_entry = 0;
     if constexpr (PHASE) t_entry = wall_clock64();
     extern __shared__ __align__(16) uint16_t xs[];  // MODE 1: the normalised activation vector, Z entries
     __shared__ float red[WAVES * BN];
-    __shared__ __align__(16) uint32_t list_i[WAVES][UP * 16];  // pair index inside the unit, 16 slots per unit, ascending
+    // 16 slots per unit: ascending; SHARE: rank k at slot (k & 3) * 4 + (k >> 2), a lane group's four entries contiguous
+    __shared__ __align__(16) uint32_t list_i[WAVES][UP * 16];  // pair index inside the unit
     __shared__ __align__(16) uint32_t list_x[WAVES][UP * 16];  // (x[2p], x[2p + 1]) as 16-bit halves, a dropped row's = 0
     __shared__ float wsum[WAVES];
     __shared__ float tflag;
@@ -215,6 +218,37 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
     float total[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) total[k] = 0.0f;
+    // 16 multiply-adds of a lane: 8 columns x the two rows of a pair
+    auto mac16 = [&](const u32x2 dd, const uint32_t x2, float (&A)[8], float& X) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t w = dd[h];
+            if constexpr (BF16) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) A[4 * h + jj] = dot2(((w >> (4 * jj)) & 0x000F000Fu) | kBias, x2, A[4 * h + jj]);
+            } else {
+                const uint32_t w8 = w >> 8;
+                A[4 * h + 0] = dot2((w & 0x000F000Fu) | kBias, x2, A[4 * h + 0]);
+                A[4 * h + 1] = dot2((w & 0x00F000F0u) | kBias, x2, A[4 * h + 1]);  // 1024 + 16 q
+                A[4 * h + 2] = dot2((w8 & 0x000F000Fu) | kBias, x2, A[4 * h + 2]);
+                A[4 * h + 3] = dot2((w8 & 0x00F000F0u) | kBias, x2, A[4 * h + 3]);  // 1024 + 16 q
+            }
+        }
+        X = dot2(kOnes, x2, X);
+    };
+    // scale / zero of one unit: sum x (q - 8) from the biased accumulators; a dead unit has X = A = 0
+    auto flush = [&](const float (&A)[8], const float X, const u32x4 s0, const u32x4 s1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t pr = k < 4 ? s0[k] : s1[k - 4];  // bf16 pair: scale (low half), zero (high half)
+            const float sc = __uint_as_float(pr << 16), zr = __uint_as_float(pr & 0xFFFF0000u);
+            float t;
+            if constexpr (BF16) t = A[k] - 136.0f * X;                         // (128 + q) - 136
+            else if (k & 1) t = fmaf(A[k], 0.0625f, -72.0f * X);               // ((1024 + 16 q) - 1024) / 16 - 8
+            else t = A[k] - 1032.0f * X;                                       // (1024 + q) - 1032
+            total[k] += sc * t + zr * X;
+        }
+    };
     // unit u belongs to slice u % split, and inside the slice to wave (u / split) % 16
     const int ustride = split * WAVES;
     for (int u0 = slice + split * wave; u0 < nunits; u0 += ustride * UP) {
@@ -292,9 +326,9 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
             using I = std::integral_constant<int, 0>;
             if (a.att_ns == 8) {  // 24 registers of partials per unit: two units at a time
                 merge(std::integral_constant<int, 8>{}, I{}, std::integral_constant<int, 2>{});
-                merge(std::integral_constant<int, 8>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+                if constexpr (UP == 4) merge(std::integral_constant<int, 8>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
             } else {
-                merge(std::integral_constant<int, 4>{}, I{}, std::integral_constant<int, 4>{});
+                merge(std::integral_constant<int, 4>{}, I{}, std::integral_constant<int, UP>{});
             }
         }
         stamp(3);
@@ -309,7 +343,8 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
             const uint32_t xm = keep ? xb[i] : 0u;
             const uint32_t xn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)xm, 0xB1, 0xf, 0xf, false);  // lane ^ 1
             if (lane < 32 && ((pm >> lane) & 1u)) {  // even lanes of kept pairs
-                const uint32_t slot = (uint32_t)i * 16u + __builtin_amdgcn_mbcnt_lo(pm, 0u);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_lo(pm, 0u);
+                const uint32_t slot = (uint32_t)i * 16u + (SHARE ? (rank & 3u) * 4u + (rank >> 2) : rank);
                 li[slot] = (uint32_t)lane >> 1;
                 lx[slot] = xm | (xn << 16);
             }
@@ -319,74 +354,94 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         stamp(4);
-        // ---- 3. 16-lane group rs takes unit rs of the pass: its group parameters (32 bytes per lane, once) and every
-        //         pair-row load of its unit, one pair per step, all issued before the first is consumed ----------------------
-        static_assert(UP == 4, "one unit per 16-lane group");
-        const int cntv = rs == 0 ? cnt[0] : (rs == 1 ? cnt[1] : (rs == 2 ? cnt[2] : cnt[3]));
-        const int maxcnt = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));  // wave-uniform step count
-        const int uv = min(u0 + rs * ustride, nunits - 1);                 // (a dead unit has no pairs: any valid address)
-        const u32x4* szp = reinterpret_cast<const u32x4*>(szb + (size_t)((uv << 5) >> a.gshift) * szld * 2);
-        const u32x4 sz0 = szp[0], sz1 = szp[1];
-        const unsigned char* wrow = wp + (size_t)(uv << 4) * ldb;  // first pair-row of the group's unit
-        u32x2 d[16];
-        {
-            u32x4 pidx[4];
+        if constexpr (SHARE) {
+            // ---- 3s. the four lane groups share each unit: group rs takes the pairs of rank rs, rs + 4, ... (<= 4 steps per unit)
+            u32x4 sz0[UP], sz1[UP];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pidx[q] = *reinterpret_cast<const u32x4*>(li + rs * 16 + q * 4);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                d[r] = u32x2{0u, 0u};
-                if (r < maxcnt) {     // wave-uniform
-                    if (r < cntv)     // (a slot past the count holds a stale index: never dereferenced)
-                        d[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wrow + (size_t)pidx[r >> 2][r & 3] * ldb));
-                }
+            for (int i = 0; i < UP; ++i) {
+                const int uu = live[i] ? u0 + i * ustride : u0;  // wave-uniform
+                const u32x4* szp = reinterpret_cast<const u32x4*>(szb + (size_t)((uu << 5) >> a.gshift) * szld * 2);
+                sz0[i] = szp[0];
+                sz1[i] = szp[1];
             }
-        }
-        stamp(5);
-        // ---- 4. arithmetic; scale / zero once per (unit, column) ---------------------------------------------------------------
-        {
-            float A[8], X = 0.0f;
+            u32x2 d[UP][4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) A[k] = 0.0f;
+            for (int i = 0; i < UP; ++i) {
+                const u32x4 pidx = *reinterpret_cast<const u32x4*>(li + i * 16 + rs * 4);
+                const unsigned char* wrow = wp + (size_t)((live[i] ? u0 + i * ustride : u0) << 4) * ldb;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q == 1) stamp(6);
-                if (q * 4 < maxcnt) {
-                    const u32x4 xx4 = *reinterpret_cast<const u32x4*>(lx + rs * 16 + q * 4);
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int r = q * 4 + rr;
-                        if (r < maxcnt) {
-                            const uint32_t x2 = (r < cntv) ? xx4[rr] : 0u;  // a group past its count adds 0
-#pragma unroll
-                            for (int h = 0; h < 2; ++h) {
-                                const uint32_t w = d[r][h];
-                                if constexpr (BF16) {
-#pragma unroll
-                                    for (int jj = 0; jj < 4; ++jj) A[4 * h + jj] = dot2(((w >> (4 * jj)) & 0x000F000Fu) | kBias, x2, A[4 * h + jj]);
-                                } else {
-                                    const uint32_t w8 = w >> 8;
-                                    A[4 * h + 0] = dot2((w & 0x000F000Fu) | kBias, x2, A[4 * h + 0]);
-                                    A[4 * h + 1] = dot2((w & 0x00F000F0u) | kBias, x2, A[4 * h + 1]);  // 1024 + 16 q
-                                    A[4 * h + 2] = dot2((w8 & 0x000F000Fu) | kBias, x2, A[4 * h + 2]);
-                                    A[4 * h + 3] = dot2((w8 & 0x00F000F0u) | kBias, x2, A[4 * h + 3]);  // 1024 + 16 q
-                                }
-                            }
-                            X = dot2(kOnes, x2, X);
-                        }
+                for (int r = 0; r < 4; ++r) {
+                    d[i][r] = u32x2{0u, 0u};
+                    if (4 * r < cnt[i]) {          // wave-uniform: this step has pairs
+                        if (4 * r + rs < cnt[i])   // (a slot past the count holds a stale index: never dereferenced)
+                            d[i][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wrow + (size_t)pidx[r] * ldb));
                     }
                 }
             }
+            stamp(5);
+            // ---- 4s. arithmetic, unit by unit; scale / zero once per (unit, column) — linear, so every group applies them to
+            //          its own share and the shares meet in the reduce at the end of the kernel
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t pr = k < 4 ? sz0[k] : sz1[k - 4];  // bf16 pair: scale (low half), zero (high half)
-                const float sc = __uint_as_float(pr << 16), zr = __uint_as_float(pr & 0xFFFF0000u);
-                // sum x (q - 8) from the biased accumulator; a dead unit has X = A = 0
-                float t;
-                if constexpr (BF16) t = A[k] - 136.0f * X;                         // (128 + q) - 136
-                else if (k & 1) t = fmaf(A[k], 0.0625f, -72.0f * X);               // ((1024 + 16 q) - 1024) / 16 - 8
-                else t = A[k] - 1032.0f * X;                                       // (1024 + q) - 1032
-                total[k] += sc * t + zr * X;
+            for (int i = 0; i < UP; ++i) {
+                if (i == 1) stamp(6);
+                float A[8], X = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) A[k] = 0.0f;
+                const u32x4 xx4 = *reinterpret_cast<const u32x4*>(lx + i * 16 + rs * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (4 * r < cnt[i]) {
+                        const uint32_t x2 = (4 * r + rs < cnt[i]) ? xx4[r] : 0u;  // a group without a pair adds 0
+                        mac16(d[i][r], x2, A, X);
+                    }
+                }
+                flush(A, X, sz0[i], sz1[i]);
+            }
+        } else {
+            // ---- 3. 16-lane group rs takes unit rs of the pass: its group parameters (32 bytes per lane, once) and every
+            //         pair-row load of its unit, one pair per step, all issued before the first is consumed ----------------------
+            const int cntv = rs == 0 ? cnt[0] : (rs == 1 ? cnt[1] : (rs == 2 ? cnt[2] : cnt[3]));
+            const int maxcnt = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3]));  // wave-uniform step count
+            const int uv = min(u0 + rs * ustride, nunits - 1);                 // (a dead unit has no pairs: any valid address)
+            const u32x4* szp = reinterpret_cast<const u32x4*>(szb + (size_t)((uv << 5) >> a.gshift) * szld * 2);
+            const u32x4 sz0 = szp[0], sz1 = szp[1];
+            const unsigned char* wrow = wp + (size_t)(uv << 4) * ldb;  // first pair-row of the group's unit
+            u32x2 d[16];
+            {
+                u32x4 pidx[4];
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) pidx[q] = *reinterpret_cast<const u32x4*>(li + rs * 16 + q * 4);
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    d[r] = u32x2{0u, 0u};
+                    if (r < maxcnt) {     // wave-uniform
+                        if (r < cntv)     // (a slot past the count holds a stale index: never dereferenced)
+                            d[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wrow + (size_t)pidx[r >> 2][r & 3] * ldb));
+                    }
+                }
+            }
+            stamp(5);
+            // ---- 4. arithmetic; scale / zero once per (unit, column) ---------------------------------------------------------------
+            {
+                float A[8], X = 0.0f;
+    #pragma unroll
+                for (int k = 0; k < 8; ++k) A[k] = 0.0f;
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q == 1) stamp(6);
+                    if (q * 4 < maxcnt) {
+                        const u32x4 xx4 = *reinterpret_cast<const u32x4*>(lx + rs * 16 + q * 4);
+    #pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int r = q * 4 + rr;
+                            if (r < maxcnt) {
+                                const uint32_t x2 = (r < cntv) ? xx4[rr] : 0u;  // a group past its count adds 0
+                                    mac16(d[r], x2, A, X);
+                            }
+                        }
+                    }
+                }
+                    flush(A, X, sz0, sz1);
             }
         }
         stamp(7);
@@ -439,14 +494,14 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
     }
 }
 
-template <bool BF16, bool PHASE>
+template <bool BF16, bool SHARE, bool PHASE>
 static hipError_t launch_i4(const I4Args& a, int mode, dim3 grid, size_t lds, hipStream_t st) {
     const dim3 block(1024);
     switch (mode) {
-        case TEAL_IN_PLAIN: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 0, PHASE>), grid, block, 0, st, a); break;
-        case TEAL_IN_RESID_NORM: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 1, PHASE>), grid, block, lds, st, a); break;
-        case TEAL_IN_SILU_MUL: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 2, PHASE>), grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 4, PHASE>), grid, block, 0, st, a); break;
+        case TEAL_IN_PLAIN: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 0, SHARE, PHASE>), grid, block, 0, st, a); break;
+        case TEAL_IN_RESID_NORM: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 1, SHARE, PHASE>), grid, block, lds, st, a); break;
+        case TEAL_IN_SILU_MUL: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 2, SHARE, PHASE>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 4, SHARE, PHASE>), grid, block, 0, st, a); break;
     }
     return hipGetLastError();
 }
@@ -536,13 +591,17 @@ int fused_gemv_i4(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z, i
         }
     }
     const dim3 grid(ntiles, split);
+    // a wave's units: up to two -> its lane groups share each unit; more -> one unit per lane group
+    const bool share = (nunits + split * 16 - 1) / (split * 16) <= 2;
     hipError_t e;
     if (g_phase && dtype == TEAL_F16) {  // measurement: the stamping instantiation (fp16 only)
         a.phase = g_phase + (size_t)g_phase_seq * g_phase_stride;
         if (g_phase_stride) ++g_phase_seq;
-        e = launch_i4<false, true>(a, in->mode, grid, lds, st);
+        e = share ? launch_i4<false, true, true>(a, in->mode, grid, lds, st) : launch_i4<false, false, true>(a, in->mode, grid, lds, st);
+    } else if (dtype == TEAL_BF16) {
+        e = share ? launch_i4<true, true, false>(a, in->mode, grid, lds, st) : launch_i4<true, false, false>(a, in->mode, grid, lds, st);
     } else {
-        e = dtype == TEAL_BF16 ? launch_i4<true, false>(a, in->mode, grid, lds, st) : launch_i4<false, false>(a, in->mode, grid, lds, st);
+        e = share ? launch_i4<false, true, false>(a, in->mode, grid, lds, st) : launch_i4<false, false, false>(a, in->mode, grid, lds, st);
     }
     if (e != hipSuccess) return TEAL_ERR_LAUNCH;
     if (nslabs_out) *nslabs_out = split;

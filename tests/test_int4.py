@@ -178,7 +178,8 @@ def _gap_tau(xabs: torch.Tensor, frac: float) -> float:
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_int4_fused_producers_and_slabs(dtype):
     """teal_fused_gemv with weight_bits = 4 (include/teal_hip.h): each producer (RESID_NORM over interleaved slabs, SILU_MUL,
-    ATTN_MERGE at 4 and 8 splits) against the PLAIN int4 launch on the torch restatement of the activation vector, with the
+    ATTN_MERGE at 4 and 8 splits; each at a narrow output, where a wave's lane groups share its one or two units, and at a
+    wide one, where each lane group takes a unit of its own) against the PLAIN int4 launch on the torch restatement of the activation vector, with the
     thresholds placed in gaps of |x|; resid_out bit-exact; the SLABS output summed in slice order equals the ROUNDED one
     bit for bit (same partials, same order)."""
     import ctypes
@@ -218,7 +219,7 @@ def test_int4_fused_producers_and_slabs(dtype):
             y, n = run(gin, Z, N, G, packed, sz, taus, TEAL_OUT_ROUNDED, ws)
             plain = GemvIn(mode=TEAL_IN_PLAIN, x=x_ref.data_ptr())
             y_ref, n_ref = run(plain, Z, N, G, packed, sz, taus, TEAL_OUT_ROUNDED, ws)
-            assert n == n_ref and n > 1, "split-K through the arrival tickets"
+            assert n == n_ref and (n > 1 or N > 8192), "split-K through the arrival tickets (narrow outputs)"
             assert torch.allclose(y.float(), y_ref.float(), atol=tol, rtol=tol), (frac, float((y.float() - y_ref.float()).abs().max()))
             slabs = torch.full((N, (n + 3) & ~3), float("nan"), device=DEV, dtype=torch.float32)
             _, n2 = run(gin, Z, N, G, packed, sz, taus, TEAL_OUT_SLABS, ws, slabs)
@@ -245,6 +246,7 @@ def test_int4_fused_producers_and_slabs(dtype):
                  norm_weight=nw.data_ptr(), eps=1e-5, resid_out=rout.data_ptr())
     check(gin, x_ref, Z, N, G, tol)
     assert torch.equal(rout.view(torch.int16), h.view(torch.int16)), "updated residual, bit-exact"
+    check(gin, x_ref, Z, 12288, G, tol)  # 96 tiles x 2 slices: four units per wave, one per 16-lane group
     # embedding lookup form (layer 0): row_index, no slabs
     table = torch.randn(7, Z, generator=g).to(dtype).to(DEV)
     idx = torch.tensor([5], device=DEV, dtype=torch.int32)
@@ -259,6 +261,7 @@ def test_int4_fused_producers_and_slabs(dtype):
     gu = torch.randn(2 * Z, generator=g).to(dtype).to(DEV)
     x_ref = (torch.nn.functional.silu(gu[:Z].float()).to(dtype).float() * gu[Z:].float()).to(dtype)
     check(GemvIn(mode=TEAL_IN_SILU_MUL, x=gu.data_ptr()), x_ref, Z, N, G, tol)
+    check(GemvIn(mode=TEAL_IN_SILU_MUL, x=gu.data_ptr()), x_ref, Z, 11008, G, tol)  # 86 tiles x 2 slices: two passes, the second ragged
     # ATTN_MERGE: partials {max, sum, o[hd]} per (head, split)
     for ns, hd in ((4, 128), (8, 64)):
         Z, N, G = 2048, 512, 128
@@ -273,6 +276,7 @@ def test_int4_fused_producers_and_slabs(dtype):
         f = torch.where(l > 0, torch.exp(m - m.max(dim=1, keepdim=True).values), torch.zeros_like(m))
         x_ref = ((o * (f / (l * f).sum(1, keepdim=True))[:, :, None]).sum(1)).reshape(-1).to(dtype)
         check(GemvIn(mode=TEAL_IN_ATTN_MERGE, x=p.data_ptr(), att_head_dim=hd, att_nsplit=ns), x_ref, Z, N, G, tol)
+        check(GemvIn(mode=TEAL_IN_ATTN_MERGE, x=p.data_ptr(), att_head_dim=hd, att_nsplit=ns), x_ref, Z, 16640, G, tol)  # 130 tiles, no split
     # contract: planar / more than 8 input slabs and the paired output have no int4 form
     packed, sz = linear(4096, 256, 32)
     ws = runtime.new_workspace(4096, 256)
