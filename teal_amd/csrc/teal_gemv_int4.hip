@@ -79,17 +79,25 @@ struct I4Args {
 // PHASE (measurement builds only): thread 0 stamps [0] entry, [1] arguments in registers, [2] producer done (MODE 1), and for
 // its wave's first pass [3] activations ready, [4] list written, [5] every load issued, [6] first unit consumed, [7] pass
 // done; [8] all passes done, [9] past the reduce barrier, [10] outputs stored.  100 MHz wall clock (scripts/int4_phase.py).
-// SHARE: launches that leave a wave one or two units (the 7B wo projection over 256 workgroups: one) — the four lane groups
-// SHARE each unit, pairs dealt round-robin, instead of three of them idling while one walks 12 pairs on its own.
-template <bool BF16, int MODE, bool SHARE, bool PHASE = false>
+// KIND, by the units a launch leaves a wave (host: fused_gemv_i4):
+//   1 SHARE  one or two (the 7B wo projection over 256 workgroups: one) — the four lane groups SHARE each unit, pairs dealt
+//            round-robin, instead of three of them idling while one walks 12 pairs on its own;
+//   0 GROUP  more: passes of four units, one unit per lane group, loads issued only for the pairs that exist.
+// (A software-pipelined form of GROUP — pass p + 1's loads in flight while pass p is consumed, every lane issuing exactly 16
+// loads and running 16 steps per pass so that the loop body is straight-line and the compiler's vmcnt waits exact — measured
+// SLOWER: 494 against 537 tok/s on Llama-2-7B, 66.4 against 89.1 on Llama-2-70B, int4-g32 @ 50 %; 128 VGPRs with spills,
+// 17 % more loads and steps than the pairs that exist.  Not kept)
+constexpr int kI4Group = 0, kI4Share = 1;
+template <bool BF16, int MODE, int KIND, bool PHASE = false>
 __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) {
+    constexpr bool SHARE = KIND == kI4Share;
     constexpr int WAVES = 16, BN = 128, UP = SHARE ? 2 : 4;  // UP: units per pass
     unsigned long long t_entry = 0;
     if constexpr (PHASE) t_entry = wall_clock64();
     extern __shared__ __align__(16) uint16_t xs[];  // MODE 1: the normalised activation vector, Z entries
     __shared__ float red[WAVES * BN];
     // 16 slots per unit: ascending; SHARE: rank k at slot (k & 3) * 4 + (k >> 2), a lane group's four entries contiguous
-    __shared__ __align__(16) uint32_t list_i[WAVES][UP * 16];  // pair index inside the unit
+    __shared__ __align__(16) uint8_t list_i[WAVES][UP * 16];   // pair index inside the unit (one byte: a lane's 16 in one read)
     __shared__ __align__(16) uint32_t list_x[WAVES][UP * 16];  // (x[2p], x[2p + 1]) as 16-bit halves, a dropped row's = 0
     __shared__ float wsum[WAVES];
     __shared__ float tflag;
@@ -204,10 +212,14 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
     const float tau = TEAL_I4_SEG(tau);
 #undef TEAL_I4_SEG
     const uint32_t scol = (uint32_t)(tile - seg_tile0) * BN + cl * 8;  // the lane's first column inside the segment
-    const unsigned char* wp = seg_wq + scol;  // a pair-row holds one byte per column
+    // a pair-row holds one byte per column.  Addresses = workgroup-uniform base (scalar registers) + a 32-bit lane offset:
+    // one VGPR and one multiply-add per load instead of a 64-bit pointer each (the host bounds the image below 4 GB)
+    const unsigned char* wtile = seg_wq + (uint32_t)(tile - seg_tile0) * BN;
+    const uint32_t lane_off = (uint32_t)cl * 8u;
+    const uint32_t uldb = (uint32_t)ldb;
     const uint16_t* szb = seg_sz + (size_t)scol * 2;
     const int nunits = Z >> 5;
-    uint32_t* li = list_i[wave];
+    uint8_t* li = list_i[wave];
     uint32_t* lx = list_x[wave];
     constexpr uint32_t kBias = BF16 ? 0x43004300u : 0x64006400u;  // half2 (128, 128) bf16 / (1024, 1024) fp16
     constexpr uint32_t kOnes = BF16 ? 0x3F803F80u : 0x3C003C00u;  // half2 (1, 1)
@@ -251,12 +263,12 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
     };
     // unit u belongs to slice u % split, and inside the slice to wave (u / split) % 16
     const int ustride = split * WAVES;
-    for (int u0 = slice + split * wave; u0 < nunits; u0 += ustride * UP) {
+    // phases 1 and 2 of a pass whose first unit is u0: activations, ballots, the wave's lists (li, lx); cnt[i] = kept pairs
+    auto front = [&](const int u0, uint8_t* li, uint32_t* lx, int (&cnt)[UP], bool (&live)[UP]) {
         // ---- 1. activations of the pass ----------------------------------------------------------------------------------------
         // The element-wise producers (MODE 2, MODE 4) run HERE, per unit, in the registers of the wave that owns the unit:
         // a workgroup touches only its own slice of gate | up (of the attention partials), not the whole vector.
         uint32_t xb[UP];
-        bool live[UP];
         uint32_t m_el[UP];  // the lane's element of unit i (lanes 32..63 mirror 0..31)
 #pragma unroll
         for (int i = 0; i < UP; ++i) {
@@ -333,7 +345,6 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
         }
         stamp(3);
         // ---- 2. ballots -> kept row pairs of every unit in the wave's lists (16 slots per unit, ascending) -----------------
-        int cnt[UP];  // kept pairs of unit i (wave-uniform)
 #pragma unroll
         for (int i = 0; i < UP; ++i) {
             const float v = bits_to_float(xb[i], BF16);
@@ -345,7 +356,7 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
             if (lane < 32 && ((pm >> lane) & 1u)) {  // even lanes of kept pairs
                 const uint32_t rank = __builtin_amdgcn_mbcnt_lo(pm, 0u);
                 const uint32_t slot = (uint32_t)i * 16u + (SHARE ? (rank & 3u) * 4u + (rank >> 2) : rank);
-                li[slot] = (uint32_t)lane >> 1;
+                li[slot] = (uint8_t)(lane >> 1);
                 lx[slot] = xm | (xn << 16);
             }
             cnt[i] = __popc(pm);
@@ -353,6 +364,11 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for (int u0 = slice + split * wave; u0 < nunits; u0 += ustride * UP) {
+        int cnt[UP];  // kept pairs of unit i (wave-uniform)
+        bool live[UP];
+        front(u0, li, lx, cnt, live);
         stamp(4);
         if constexpr (SHARE) {
             // ---- 3s. the four lane groups share each unit: group rs takes the pairs of rank rs, rs + 4, ... (<= 4 steps per unit)
@@ -367,14 +383,14 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
             u32x2 d[UP][4];
 #pragma unroll
             for (int i = 0; i < UP; ++i) {
-                const u32x4 pidx = *reinterpret_cast<const u32x4*>(li + i * 16 + rs * 4);
-                const unsigned char* wrow = wp + (size_t)((live[i] ? u0 + i * ustride : u0) << 4) * ldb;
+                const uint32_t pidx = *reinterpret_cast<const uint32_t*>(li + i * 16 + rs * 4);  // the group's four pair indices
+                const uint32_t row_off = (uint32_t)((live[i] ? u0 + i * ustride : u0) << 4) * uldb + lane_off;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     d[i][r] = u32x2{0u, 0u};
                     if (4 * r < cnt[i]) {          // wave-uniform: this step has pairs
                         if (4 * r + rs < cnt[i])   // (a slot past the count holds a stale index: never dereferenced)
-                            d[i][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wrow + (size_t)pidx[r] * ldb));
+                            d[i][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wtile + (row_off + ((pidx >> (8 * r)) & 0xFFu) * uldb)));
                     }
                 }
             }
@@ -405,18 +421,16 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
             const int uv = min(u0 + rs * ustride, nunits - 1);                 // (a dead unit has no pairs: any valid address)
             const u32x4* szp = reinterpret_cast<const u32x4*>(szb + (size_t)((uv << 5) >> a.gshift) * szld * 2);
             const u32x4 sz0 = szp[0], sz1 = szp[1];
-            const unsigned char* wrow = wp + (size_t)(uv << 4) * ldb;  // first pair-row of the group's unit
+            const uint32_t row_off = (uint32_t)(uv << 4) * uldb + lane_off;  // first pair-row of the group's unit
             u32x2 d[16];
             {
-                u32x4 pidx[4];
-    #pragma unroll
-                for (int q = 0; q < 4; ++q) pidx[q] = *reinterpret_cast<const u32x4*>(li + rs * 16 + q * 4);
-    #pragma unroll
+                const u32x4 pidx = *reinterpret_cast<const u32x4*>(li + rs * 16);  // the group's 16 pair indices
+#pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     d[r] = u32x2{0u, 0u};
                     if (r < maxcnt) {     // wave-uniform
                         if (r < cntv)     // (a slot past the count holds a stale index: never dereferenced)
-                            d[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wrow + (size_t)pidx[r >> 2][r & 3] * ldb));
+                            d[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wtile + (row_off + ((pidx[r >> 2] >> (8 * (r & 3))) & 0xFFu) * uldb)));
                     }
                 }
             }
@@ -424,14 +438,14 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
             // ---- 4. arithmetic; scale / zero once per (unit, column) ---------------------------------------------------------------
             {
                 float A[8], X = 0.0f;
-    #pragma unroll
+#pragma unroll
                 for (int k = 0; k < 8; ++k) A[k] = 0.0f;
-    #pragma unroll
+#pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (q == 1) stamp(6);
                     if (q * 4 < maxcnt) {
                         const u32x4 xx4 = *reinterpret_cast<const u32x4*>(lx + rs * 16 + q * 4);
-    #pragma unroll
+#pragma unroll
                         for (int rr = 0; rr < 4; ++rr) {
                             const int r = q * 4 + rr;
                             if (r < maxcnt) {
@@ -494,14 +508,14 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
     }
 }
 
-template <bool BF16, bool SHARE, bool PHASE>
+template <bool BF16, int KIND, bool PHASE>
 static hipError_t launch_i4(const I4Args& a, int mode, dim3 grid, size_t lds, hipStream_t st) {
     const dim3 block(1024);
     switch (mode) {
-        case TEAL_IN_PLAIN: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 0, SHARE, PHASE>), grid, block, 0, st, a); break;
-        case TEAL_IN_RESID_NORM: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 1, SHARE, PHASE>), grid, block, lds, st, a); break;
-        case TEAL_IN_SILU_MUL: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 2, SHARE, PHASE>), grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 4, SHARE, PHASE>), grid, block, 0, st, a); break;
+        case TEAL_IN_PLAIN: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 0, KIND, PHASE>), grid, block, 0, st, a); break;
+        case TEAL_IN_RESID_NORM: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 1, KIND, PHASE>), grid, block, lds, st, a); break;
+        case TEAL_IN_SILU_MUL: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 2, KIND, PHASE>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((sparse_gemv_int4_kernel<BF16, 4, KIND, PHASE>), grid, block, 0, st, a); break;
     }
     return hipGetLastError();
 }
@@ -526,6 +540,7 @@ int fused_gemv_i4(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z, i
         const int nc = out->ncols[i], c0 = out->col0[i], ldb = out->ld[i], szld = out->scale_ld[i];
         if (!out->w[i] || !out->scale[i] || nc <= 0 || (nc % 128) || c0 < 0 || (c0 & 7)) return TEAL_ERR_SHAPE;
         if (ldb < c0 + nc || (ldb & 7) || szld < c0 + nc) return TEAL_ERR_SHAPE;  // a pair-row: one byte per column
+        if ((size_t)(Z / 2) * (size_t)ldb >= ((size_t)1 << 32)) return TEAL_ERR_SHAPE;  // 32-bit offsets inside an image
         if ((reinterpret_cast<uintptr_t>(out->w[i]) & 7u) || !aligned16(out->scale[i])) return TEAL_ERR_ALIGN;
         if (out->mode == TEAL_OUT_ROUNDED && !out->y[i]) return TEAL_ERR_ARG;
         I4Seg& sg = a.seg[i];
@@ -591,18 +606,22 @@ int fused_gemv_i4(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z, i
         }
     }
     const dim3 grid(ntiles, split);
-    // a wave's units: up to two -> its lane groups share each unit; more -> one unit per lane group
-    const bool share = (nunits + split * 16 - 1) / (split * 16) <= 2;
+    // a wave's units: up to two -> its lane groups share each unit; more -> passes of four, a unit per lane group
+    const int upw = (nunits + split * 16 - 1) / (split * 16);
+    const int kind = upw <= 2 ? kI4Share : kI4Group;
     hipError_t e;
+#define TEAL_I4_LAUNCH(BF, PH) \
+    (kind == kI4Share ? launch_i4<BF, kI4Share, PH>(a, in->mode, grid, lds, st) : launch_i4<BF, kI4Group, PH>(a, in->mode, grid, lds, st))
     if (g_phase && dtype == TEAL_F16) {  // measurement: the stamping instantiation (fp16 only)
         a.phase = g_phase + (size_t)g_phase_seq * g_phase_stride;
         if (g_phase_stride) ++g_phase_seq;
-        e = share ? launch_i4<false, true, true>(a, in->mode, grid, lds, st) : launch_i4<false, false, true>(a, in->mode, grid, lds, st);
+        e = TEAL_I4_LAUNCH(false, true);
     } else if (dtype == TEAL_BF16) {
-        e = share ? launch_i4<true, true, false>(a, in->mode, grid, lds, st) : launch_i4<true, false, false>(a, in->mode, grid, lds, st);
+        e = TEAL_I4_LAUNCH(true, false);
     } else {
-        e = share ? launch_i4<false, true, false>(a, in->mode, grid, lds, st) : launch_i4<false, false, false>(a, in->mode, grid, lds, st);
+        e = TEAL_I4_LAUNCH(false, false);
     }
+#undef TEAL_I4_LAUNCH
     if (e != hipSuccess) return TEAL_ERR_LAUNCH;
     if (nslabs_out) *nslabs_out = split;
     return TEAL_OK;
