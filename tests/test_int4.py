@@ -250,6 +250,24 @@ def test_int4_fused_producers_and_slabs(dtype):
     check(gin, x_ref, Z, N, G, tol)
     assert torch.equal(rout.view(torch.int16), h.view(torch.int16)), "updated residual, bit-exact"
     check(gin, x_ref, Z, 12288, G, tol)  # 96 tiles x 2 slices: four units per wave, one per 16-lane group
+    # other widths of the producer: 5120 (8 elements per thread, the last block ragged; 8 slabs = two 16-byte loads per element)
+    # and 9216 (16 per thread, in blocks of four; one slab)
+    for Zw, ns in ((5120, 8), (9216, 1)):
+        r2 = torch.randn(Zw, generator=g).to(dtype).to(DEV)
+        s2 = torch.zeros(Zw, (ns + 3) & ~3, dtype=torch.float32)
+        s2[:, :ns] = torch.randn(Zw, ns, generator=g) * 0.2
+        s2 = s2.to(DEV)
+        w2 = (1.0 + 0.1 * torch.randn(Zw, generator=g)).to(dtype).to(DEV)
+        ro2 = torch.zeros(Zw, device=DEV, dtype=dtype)
+        acc = torch.zeros(Zw, device=DEV, dtype=torch.float32)
+        for j in range(ns):
+            acc = acc + s2[:, j]
+        h2 = (r2.float() + acc.to(dtype).float()).to(dtype)
+        x2 = ((h2.float() * torch.rsqrt(h2.float().pow(2).mean() + 1e-5)).to(dtype).float() * w2.float()).to(dtype)
+        gin2 = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=r2.data_ptr(), slabs=s2.data_ptr(), nslabs=ns, slabs_interleaved=1,
+                      norm_weight=w2.data_ptr(), eps=1e-5, resid_out=ro2.data_ptr())
+        check(gin2, x2, Zw, 256, 64, tol)
+        assert torch.equal(ro2.view(torch.int16), h2.view(torch.int16)), Zw
     # embedding lookup form (layer 0): row_index, no slabs
     table = torch.randn(7, Z, generator=g).to(dtype).to(DEV)
     idx = torch.tensor([5], device=DEV, dtype=torch.int32)
