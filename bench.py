@@ -473,7 +473,7 @@ def main():
             out["prefill_ms"] = t_pf * 1e3
     if rank == 0 and world == 1:
         if a.weights == "int4":
-            out["roofline"] = None  # (the roofline object describes the 16-bit / int8 engine's dominant launch)
+            out["roofline"] = None  # (the roofline object describes the 16-bit / int8 engine's dominant launch; int4: DESIGN.md 3.2b)
         else:
             out["roofline"] = roofline_engine_gateup(info["engine"], a) if mode == "engine" else roofline_dominant_kernel(model, a)
         if not a.no_dense:
@@ -503,7 +503,7 @@ def main():
                 out["speedup_vs_reference_dense_path"] = tps / (nref / tr)
                 del rmodel, rstep
                 torch.cuda.empty_cache()
-        if mode == "engine" and not a.no_context_sweep and a.prompt_tokens < 500 and a.weights != "int4":
+        if mode == "engine" and not a.no_context_sweep and a.prompt_tokens < 500:
             # The headline decodes at the reference's default prompt (6 tokens): cache positions 6..~230, the short-context
             # best case of the attention launch.  Same model, same thresholds law, longer contexts (a prefill of that many
             # random tokens through the module path, thresholds re-taken on the timed decode positions):
