@@ -232,8 +232,9 @@ def roofline_engine_gateup(eng, a):
         nnz_g = int((x > k4_out.tau[0]).sum())
         nnz_u = int((x > k4_out.tau[1]).sum())
         out_bytes = (N * 2 + N // 8) if eng.pair else 2 * N * 2  # h (+ keep masks) vs gate|up
-        wbytes = 1 if eng.int8 else 2  # int8 weight-only: 1 byte per weight + the two scale vectors
-        total_bytes += (nnz_g + nnz_u) * N * wbytes + (2 * N * 2 if eng.int8 else 0) + Z * 2 + ns * Z * 4 + Z * 2 + out_bytes
+        wbytes = 0.5 if eng.int4 else (1 if eng.int8 else 2)  # int8: + the two scale vectors; int4: + the group parameters
+        qbytes = 2 * N * 2 if eng.int8 else (2 * (Z // m.layers[i].feed_forward.w1.groupsize) * N * 4 if eng.int4 else 0)
+        total_bytes += int((nnz_g + nnz_u) * N * wbytes) + qbytes + Z * 2 + ns * Z * 4 + Z * 2 + out_bytes
         gin = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=B.data_ptr(), slabs=eng.s_wo.data_ptr(), nslabs=ns, slabs_interleaved=1,
                      norm_weight=m.layers[i].ffn_norm.weight.data_ptr(), eps=eng.eps, resid_out=None)
         launches.append((gin, k4_out))
@@ -270,7 +271,9 @@ def roofline_engine_gateup(eng, a):
             "frac": total_bytes / t / 1e9 / HBM_PEAK_GBS, "frac_of_measured_ceiling": total_bytes / t / 1e9 / HBM_MEASURED_CEILING_GBS,
             "measured_ceiling": HBM_MEASURED_CEILING_GBS, "traffic": traffic, "traffic_source": tsrc,
             "traffic_measured_in_this_run": False,
-            "kernel": kname + f" (fused RMSNorm -> mask -> gate|up GEMV{' -> silu*mul' if eng.pair else ''}, Z={Z}, N=2x{N})",
+            "kernel": kname + f" (fused RMSNorm -> mask -> gate|up GEMV{' -> silu*mul' if eng.pair else ''}, Z={Z}, N=2x{N}"
+                      + ("; int4: algorithmic bytes count kept ROWS at half a byte per weight + the dense group parameters — the kernel "
+                         "fetches row PAIRS, 1.5x those weight bytes at 50 %" if eng.int4 else "") + ")",
             "algorithmic_bytes": total_bytes / n, "us_per_launch": t / n * 1e6, "launches_timed": n,
             "timing": "HIP events (launch stream) around a hipGraph of one launch per layer with that layer's weights; "
                       "per-launch time includes the same-stream launch boundary, like rocprofv3's per-dispatch duration"}
@@ -472,10 +475,7 @@ def main():
             out["tokens_per_sec_reference_definition"] = 200.0 / (t_pf + 200.0 * t / a.steps)
             out["prefill_ms"] = t_pf * 1e3
     if rank == 0 and world == 1:
-        if a.weights == "int4":
-            out["roofline"] = None  # (the roofline object describes the 16-bit / int8 engine's dominant launch; int4: DESIGN.md 3.2b)
-        else:
-            out["roofline"] = roofline_engine_gateup(info["engine"], a) if mode == "engine" else roofline_dominant_kernel(model, a)
+        out["roofline"] = roofline_engine_gateup(info["engine"], a) if mode == "engine" else roofline_dominant_kernel(model, a)
         if not a.no_dense:
             # dense comparator on the same harness: same kernels with every row kept (threshold < 0)
             a_d = argparse.Namespace(**vars(a))

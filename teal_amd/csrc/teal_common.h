@@ -104,6 +104,7 @@ extern int g_phase_seq;
 extern int g_swizzle;
 extern int g_wave_local;
 extern int g_exp;
+extern char g_last_desc[160];  // template instantiation + grid of the most recent GEMV launch (teal_last_launch_desc)
 
 // ---- caller-owned workspace --------------------------------------------------------------------------------------
 // A workspace prepared by teal_workspace_init() starts with a header the library owns (zeroed once by that call, re-armed

@@ -31,6 +31,7 @@
 #include "teal_common.h"
 
 #include <limits.h>
+#include <stdio.h>
 
 namespace teal {
 
@@ -625,6 +626,8 @@ int fused_gemv_i4(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z, i
     }
 #undef TEAL_I4_LAUNCH
     if (e != hipSuccess) return TEAL_ERR_LAUNCH;
+    snprintf(g_last_desc, sizeof(g_last_desc), "sparse_gemv_int4_kernel<%s,%d,%d,false> grid (%d,%d) x 1024", dtype == TEAL_BF16 ? "true" : "false",
+             in->mode, kind, ntiles, split);
     if (nslabs_out) *nslabs_out = split;
     return TEAL_OK;
 }
