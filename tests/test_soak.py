@@ -215,3 +215,51 @@ def test_workspace_init_contract():
     assert L.teal_fused_gemv(ctypes.byref(gin), ctypes.byref(gout), Z, 0, None, 0, None, st) == -1
     assert L.teal_workspace_release(buf.data_ptr()) == 0 and L.teal_workspace_release(buf.data_ptr()) == -1
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_int4_graph_replay_soak(dtype):
+    """The same contract for the int4 group-quantised step (teal_gemv_int4.hip: LDS pair lists, packed dot products, slab and
+    ticketed split-K): a 12-layer Llama-2-7B-width model, int4-g32 @ 50 %, captured in a hipGraph and replayed; every
+    hand-over buffer that survives a step and the logits equal the first replay bit for bit."""
+    from teal_amd.gpt_fast import generate as G
+    from teal_amd.gpt_fast.engine import DecodeEngine
+    from teal_amd.quantize import quantize_model_int4
+    n_layer, NP = 12, 120
+    model = quantize_model_int4(G.build_synthetic_model("7B", DEV, dtype, seed=31, n_layer=n_layer), 32)
+    ths = G.apply_sparsity(model, sparsity=0.5, hist_path=None, greedy_lookup=None, synthetic=True)
+    prompt = torch.randint(0, model.config.vocab_size, (NP,), device=DEV, dtype=torch.int, generator=torch.Generator(device=DEV).manual_seed(5))
+    try:
+        with torch.no_grad():
+            model.max_seq_length = -1
+            model.setup_caches(1, NP + 8)
+            model(prompt.view(1, -1), torch.arange(NP, device=DEV))
+            eng = DecodeEngine(model, ths)
+            assert eng.int4
+            tok = torch.tensor([[23]], device=DEV, dtype=torch.int)
+            pos = torch.tensor([NP], device=DEV, dtype=torch.int)
+            eng(tok, pos)
+            torch.cuda.synchronize()
+            kept = eng.kept_fractions(tok, pos)
+            assert all(0.3 < v < 0.7 for v in kept.values()), kept
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                eng(tok, pos)
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                eng(tok, pos)
+            g.replay()
+            ref = [_bytes(b).clone() for b in _live(eng)] + [_bytes(eng.logits).clone()]
+            assert bool(torch.isfinite(eng.logits.float()).all())
+            bad = torch.zeros(len(ref), dtype=torch.int64, device=DEV)
+            for _ in range(max(200, PLAIN // 4)):
+                g.replay()
+                cur = [_bytes(b) for b in _live(eng)] + [_bytes(eng.logits)]
+                bad += torch.stack([(c != r).any() for c, r in zip(cur, ref)]).to(torch.int64)
+            torch.cuda.synchronize()
+            assert int(bad.sum()) == 0, dict(zip(NAMES + ("logits",), bad.tolist()))
+    finally:
+        del model
+        torch.cuda.empty_cache()
