@@ -33,8 +33,11 @@ def find_multiple(n: int, k: int) -> int:
 # name -> architecture (gpt-fast/model.py:66-79); matched case-insensitively as a substring of
 # the checkpoint directory name, longest match wins.
 transformer_configs = {
+    "CodeLlama-7b-Python-hf": dict(block_size=16384, vocab_size=32000, n_layer=32, dim=4096, rope_base=1000000),
     "7B": dict(n_layer=32, n_head=32, dim=4096),
     "13B": dict(n_layer=40, n_head=40, dim=5120),
+    "30B": dict(n_layer=60, n_head=52, dim=6656),
+    "34B": dict(n_layer=48, n_head=64, dim=8192, vocab_size=32000, n_local_heads=8, intermediate_size=22016, rope_base=1000000),
     "70B": dict(n_layer=80, n_head=64, dim=8192, n_local_heads=8, intermediate_size=28672),
     "Mistral-7B": dict(n_layer=32, n_head=32, n_local_heads=8, dim=4096, intermediate_size=14336, vocab_size=32000),
     "llama-3-8b": dict(block_size=8192, n_layer=32, n_head=32, n_local_heads=8, dim=4096, intermediate_size=14336,
@@ -42,6 +45,7 @@ transformer_configs = {
     "llama-3-70b": dict(block_size=8192, n_layer=80, n_head=64, n_local_heads=8, dim=8192, intermediate_size=28672,
                         vocab_size=128256, rope_base=500000),
     "stories15M": dict(n_layer=6, n_head=6, dim=288),
+    "stories110M": dict(n_layer=12, n_head=12, dim=768),
     "tiny-test": dict(n_layer=2, n_head=4, n_local_heads=2, dim=256, intermediate_size=512, vocab_size=512, block_size=128),
     "tiny-gqa-test": dict(n_layer=2, n_head=8, n_local_heads=2, dim=512, intermediate_size=1024, vocab_size=512, block_size=128),
 }

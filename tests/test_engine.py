@@ -337,6 +337,54 @@ def test_engine_matches_module_path_full_width(name, dtype, n_layer, int8):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("name,dtype,n_layer,fmt", [("13B", torch.float16, 1, "w16"), ("13B", torch.bfloat16, 1, "int4"), ("30B", torch.bfloat16, 1, "w16"),
+                                                    ("30B", torch.float16, 1, "int8"), ("34B", torch.float16, 1, "int8"), ("34B", torch.float16, 1, "int4"),
+                                                    ("stories110M", torch.float16, 2, "w16"), ("Mistral-7B", torch.bfloat16, 1, "int4"),
+                                                    ("70B", torch.float16, 1, "int4")])
+def test_engine_matches_module_path_other_architectures(name, dtype, n_layer, fmt):
+    """The other architectures of the reference's table (gpt-fast/model.py:66-79: 13B 5120 / 13824, 30B 6656 / 17920 with 52
+    heads, 34B GQA 8192 / 22016, stories110M head_dim 64, Mistral-7B) and the three weight formats: the fused engine against the
+    op-by-op module path with every row kept (no threshold can flip) over a few tokens, then a step at 50 % (thresholds
+    taken on the decode activations)."""
+    from teal_amd.gpt_fast import generate as G
+    from teal_amd.gpt_fast.engine import DecodeEngine, pick_engine
+    from teal_amd.quantize import quantize_model_int4, quantize_model_int8
+    quant = {"w16": lambda m: m, "int8": quantize_model_int8, "int4": lambda m: quantize_model_int4(m, 32)}[fmt]
+    ref = quant(G.build_synthetic_model(name, DEV, dtype, seed=5, n_layer=n_layer))
+    ref.fused_decode = False
+    eng_m = quant(G.build_synthetic_model(name, DEV, dtype, seed=5, n_layer=n_layer))
+    ths = G.apply_sparsity(ref, sparsity=0.0, hist_path=None, greedy_lookup=None, synthetic=True)
+    G.apply_sparsity(eng_m, sparsity=0.0, hist_path=None, greedy_lookup=None, synthetic=True)
+    V = ref.config.vocab_size
+    prompt = torch.randint(0, V, (6,), device=DEV, dtype=torch.int, generator=torch.Generator(device=DEV).manual_seed(2))
+    with torch.no_grad():
+        for m in (ref, eng_m):
+            m.max_seq_length = -1
+            m.setup_caches(1, 32)
+            m(prompt.view(1, -1), torch.arange(6, device=DEV))
+        assert pick_engine(eng_m) == (DecodeEngine, None)
+        eng = DecodeEngine(eng_m, ths)
+        assert eng.int4 == (fmt == "int4") and eng.int8 == (fmt == "int8")
+        tok = torch.tensor([[17]], device=DEV, dtype=torch.int)
+        for step in range(3):
+            pos = torch.tensor([6 + step], device=DEV, dtype=torch.int)
+            a = ref(tok, pos).float().view(-1)
+            b = eng(tok, pos).float().view(-1)
+            scale = float(a.abs().max())
+            tol = (4e-3 if dtype == torch.float16 else 4e-2) * max(1.0, scale) * (1.0 if fmt == "w16" else 2.0)
+            assert float((a - b).abs().max()) <= tol, (step, float((a - b).abs().max()), scale)
+            tok = a.argmax().view(1, 1).to(torch.int)
+        # 50 %: thresholds from the decode activations themselves; the step keeps about half of every projection's rows
+        sp = {p: [0.5] * n_layer for p in eng.SITE}
+        eng.calibrate_on_decode(sp, torch.tensor([17], device=DEV, dtype=torch.int), 9, 6, n_samples=3, rounds=2)
+        tok, pos = torch.tensor([[17]], device=DEV, dtype=torch.int), torch.tensor([12], device=DEV, dtype=torch.int)
+        kept = eng.kept_fractions(tok, pos)
+        assert all(0.3 < v < 0.7 for v in kept.values()), kept
+        assert bool(torch.isfinite(eng(tok, pos).float()).all())
+    del ref, eng_m, eng
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_decode_attention_split_long_context(dtype):
     """flash-decoding form: same result as the single-workgroup kernel and as torch, at thousands of positions"""
