@@ -411,6 +411,11 @@ def generate(model: Transformer, prompt: torch.Tensor, max_new_tokens: int, deco
 def main(args) -> Dict:
     device = args.device
     assert "cuda" in device, "the sparse decode path is GPU-only (HIP kernels, no CPU fallback)"
+    if getattr(args, "draft_checkpoint_path", None) is not None:
+        raise SystemExit("--draft_checkpoint_path: speculative decoding is not part of this build (the reference lists it as "
+                         "untested with TEAL); run without a draft model")
+    if getattr(args, "interactive", False) and args.synthetic:
+        raise SystemExit("--interactive needs a tokenizer (a checkpoint directory), not --synthetic")
     dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[args.precision]
     from teal_amd import runtime
     runtime.init()
@@ -463,6 +468,11 @@ def main(args) -> Dict:
     tps, seqs = [], []
     start = -1 if args.compile else 0
     for i in range(start, args.num_samples):
+        if getattr(args, "interactive", False) and i >= 0:
+            text = input("What is your prompt? ")
+            if "chat" in str(args.checkpoint_path):
+                text = f"[INST] {text.strip()} [/INST]"
+            prompt = torch.tensor([tokenizer.bos_id()] + tokenizer.encode(text), dtype=torch.int, device=device)
         torch.cuda.synchronize()
         prof = contextlib.nullcontext()
         if args.profile and i == args.num_samples - 1:
@@ -502,6 +512,8 @@ def main(args) -> Dict:
 def build_parser() -> argparse.ArgumentParser:
     p = argparse.ArgumentParser(description="TEAL decode harness (MI355X / HIP)")
     p.add_argument("--prompt", type=str, default="Hello, my name is")
+    p.add_argument("--interactive", action="store_true", help="ask for a prompt before every sample (needs a tokenizer: not with "
+                   "--synthetic); chat checkpoints get the reference's [INST] wrapping (generate.py:440-446)")
     p.add_argument("--num_samples", type=int, default=5)
     p.add_argument("--max_new_tokens", type=int, default=200)
     p.add_argument("--top_k", type=int, default=200)
@@ -511,6 +523,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--compile_prefill", action="store_true", help="capture the prompt pass into a hipGraph too "
                    "(the reference's flag of the same name, generate.py:540)")
     p.add_argument("--profile", type=Path, default=None)
+    p.add_argument("--speculate_k", type=int, default=5, help="accepted for command-line compatibility; only read with a draft model")
+    p.add_argument("--draft_checkpoint_path", type=Path, default=None, help="speculative decoding is outside this build (the "
+                   "reference marks it untested with TEAL: README.md:111, generate.py:393): giving a draft model is an error")
     p.add_argument("--device", type=str, default=default_device)
     # monkeypatch (reference flags)
     p.add_argument("--hist_path", type=str, default=None)

@@ -81,6 +81,17 @@ def test_cli_flags_match_reference_surface():
     assert a.hist_path == "H" and a.sparsity == 0.5 and a.compile and a.max_new_tokens == 10
     d = p.parse_args([])
     assert d.max_new_tokens == 200 and d.num_samples == 5 and d.top_k == 200 and d.temperature == 0.8 and d.sparsity == 0.0
+    # every flag of the reference's parser (gpt-fast/generate.py:532-548) is accepted with its default
+    assert d.prompt == "Hello, my name is" and not d.interactive and d.speculate_k == 5 and d.draft_checkpoint_path is None
+    assert not d.compile_prefill and d.profile is None and str(d.checkpoint_path).endswith("Llama-2-7b-chat-hf/model.pth")
+    full = p.parse_args(["--prompt", "x", "--interactive", "--num_samples", "1", "--max_new_tokens", "3", "--top_k", "5", "--temperature", "0.5",
+                         "--checkpoint_path", "a/model.pth", "--compile", "--compile_prefill", "--profile", "t", "--speculate_k", "4",
+                         "--draft_checkpoint_path", "d/model.pth", "--device", "cuda", "--hist_path", "H", "--sparsity", "0.4"])
+    assert full.interactive and full.speculate_k == 4
+    with pytest.raises(SystemExit, match="speculative decoding"):  # named, not silently ignored
+        G.main(full)
+    with pytest.raises(SystemExit, match="tokenizer"):
+        G.main(p.parse_args(["--synthetic", "tiny-test", "--interactive", "--device", "cuda"]))
 
 
 def test_decode_engine_supports_names_ineligible_models():
