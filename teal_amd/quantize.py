@@ -243,3 +243,53 @@ def convert_for_runtime_int4(model: nn.Module, groupsize: int = 32, skip=("outpu
 
 def is_int4(lin: nn.Module) -> bool:
     return isinstance(lin, WeightOnlyInt4Linear)
+
+
+def quantize(checkpoint_path, mode: str = "int8", groupsize: int = 32, label: str = "", device: str = "cpu"):
+    """Write the weight-only quantised checkpoint next to `checkpoint_path` — the command-line role of the reference's
+    gpt-fast/quantize.py:528-600: model.pth -> model{label}int8.pth / model{label}int4.g{G}.pth, the names the loader's
+    branches key on (teal_amd/gpt_fast/generate.py load_checkpoint_model; gpt-fast/generate.py:236-243).  int8 state dicts are
+    the reference's (`weight` int8 [N, Z], `scales`); int4 ones hold this build's row-pair image (convert_for_runtime_int4).
+    mode 'int4-gptq' (calibration on lm-eval tasks) is outside this build."""
+    import time
+    from pathlib import Path
+
+    from .gpt_fast.model import Transformer
+    checkpoint_path = Path(checkpoint_path)
+    assert checkpoint_path.is_file(), checkpoint_path
+    if mode not in ("int8", "int4"):
+        raise ValueError(f"Invalid quantization mode {mode}: this build writes int8 and int4 (int4-gptq needs the lm-eval calibration "
+                         "harness, out of scope)")
+    t0 = time.time()
+    with torch.device("meta"):
+        model = Transformer.from_name(checkpoint_path.parent.name)
+    ckpt = torch.load(str(checkpoint_path), mmap=True, weights_only=True)
+    model.load_state_dict(ckpt, assign=True)
+    model = model.to(dtype=torch.bfloat16, device=device)  # the reference quantises from bf16 (quantize.py:546)
+    if mode == "int8":
+        print("Quantizing model weights for int8 weight-only symmetric per-channel quantization")
+        sd = quantize_model_int8(model).state_dict()
+        name = checkpoint_path.name.replace(".pth", f"{label}int8.pth")
+    else:
+        print("Quantizing model weights for int4 weight-only affine per-channel groupwise quantization")
+        sd = quantize_model_int4(model, groupsize).state_dict()
+        name = checkpoint_path.name.replace(".pth", f"{label}int4.g{groupsize}.pth")
+    out = checkpoint_path.parent / name
+    print(f"Writing quantized weights to {out}")
+    out.unlink(missing_ok=True)
+    torch.save(sd, out)
+    print(f"Quantization complete took {time.time() - t0:.02f} seconds")
+    return out
+
+
+if __name__ == "__main__":
+    import argparse
+    from pathlib import Path
+    ap = argparse.ArgumentParser(description="Quantize a model (weight-only int8 / int4 group-wise).")
+    ap.add_argument("--checkpoint_path", type=Path, default=Path("checkpoints/meta-llama/Llama-2-7b-chat-hf/model.pth"))
+    ap.add_argument("--mode", "-q", type=str, default="int8", choices=["int8", "int4", "int4-gptq"])
+    ap.add_argument("--groupsize", type=int, default=32, help="Group size for int4 quantization.")
+    ap.add_argument("--label", type=str, default="_", help="label to add to output filename")
+    ap.add_argument("--device", type=str, default="cpu", help="where to run the quantiser (cpu works; cuda is faster)")
+    a = ap.parse_args()
+    quantize(a.checkpoint_path, a.mode, a.groupsize, a.label, a.device)

@@ -360,3 +360,33 @@ def test_int4_engine_matches_int4_module_path(dtype, sparsity):
         # a single-token call of the patched model takes the same engine
         eng_m(torch.tensor([[7]], device=DEV, dtype=torch.int), torch.tensor([15], device=DEV))
         assert isinstance(eng_m._eng, DecodeEngine) and eng_m._eng.int4
+
+
+def test_quantize_cli_writes_the_checkpoints_the_loader_branches_on(tmp_path):
+    """teal_amd.quantize.quantize (the role of gpt-fast/quantize.py:528-600): model.pth -> model_int8.pth and
+    model_int4.g32.pth next to it, under the names load_checkpoint_model keys on; the state dicts load into the
+    convert_for_runtime_* shells and reproduce the quantiser's own tensors (CPU only)."""
+    from teal_amd.gpt_fast import generate as G
+    from teal_amd.gpt_fast.model import Transformer
+    from teal_amd.quantize import (convert_for_runtime_int4, convert_for_runtime_int8, quantize, quantize_model_int4,
+                                   quantize_model_int8)
+    ck = tmp_path / "tiny-test"
+    ck.mkdir()
+    torch.save(G.build_synthetic_model("tiny-test", "cpu", torch.bfloat16, seed=9, std=0.05).state_dict(), ck / "model.pth")
+    p8 = quantize(ck / "model.pth", "int8", label="_")
+    p4 = quantize(ck / "model.pth", "int4", groupsize=32, label="_")
+    assert p8.name == "model_int8.pth" and p4.name == "model_int4.g32.pth"
+    with pytest.raises(ValueError, match="int4-gptq"):
+        quantize(ck / "model.pth", "int4-gptq")
+    base = lambda: G.build_synthetic_model("tiny-test", "cpu", torch.bfloat16, seed=9, std=0.05)  # noqa: E731
+    for path, conv, ref in ((p8, lambda m: convert_for_runtime_int8(m, torch.bfloat16), quantize_model_int8(base())),
+                            (p4, lambda m: convert_for_runtime_int4(m, 32), quantize_model_int4(base(), 32))):
+        with torch.device("meta"):
+            m = Transformer.from_name("tiny-test")
+        conv(m)
+        m.load_state_dict(torch.load(str(path), weights_only=True), assign=True)
+        want = ref.state_dict()
+        got = m.state_dict()
+        assert set(got) == set(want)
+        for k in want:
+            assert torch.equal(got[k].cpu(), want[k].cpu()), k
