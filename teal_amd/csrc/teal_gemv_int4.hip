@@ -73,10 +73,11 @@ struct I4Args {
 // with mbcnt ranks; then each of the wave's four 16-lane groups takes ONE unit of the pass — its own group parameters, its
 // own accumulators, no cross-lane traffic until the end of the kernel — and EVERY pair-row load of the pass is issued before
 // the first is consumed.  (Four groups sharing the pairs of one unit would each fetch that unit's 32 bytes of parameters
-// per lane: the launch was then bound by the CU's 64 bytes / clock of vector-memory issue, half of it those parameters.)  scale / zero are applied per UNIT with the parameters of the unit's
-// group — y += scale * (A_u - c X_u) + zero * X_u is linear in the units of a group — so units are independent whatever
-// the group size.  fp16 activations: nibbles 1 and 3 of a half are used where they lie, as 1024 + 16 q (no shift); their
-// columns are rescaled at the flush.  bf16 activations: bias 128 (7 mantissa bits), every nibble shifted down.
+// per lane: the launch was then bound by the CU's 64 bytes / clock of vector-memory issue, half of it those parameters.)
+// scale / zero are applied per UNIT with the parameters of the unit's group — y += scale * (A_u - c X_u) + zero * X_u is
+// linear in the units of a group — so units are independent whatever the group size.  fp16 activations: nibbles 1 and 3 of
+// a half are used where they lie, as 1024 + 16 q (no shift); their columns are rescaled at the flush.  bf16 activations:
+// bias 128 (7 mantissa bits), every nibble shifted down.
 // PHASE (measurement builds only): thread 0 stamps [0] entry, [1] arguments in registers, [2] producer done (MODE 1), and for
 // its wave's first pass [3] activations ready, [4] list written, [5] every load issued, [6] first unit consumed, [7] pass
 // done; [8] all passes done, [9] past the reduce barrier, [10] outputs stored.  100 MHz wall clock (scripts/int4_phase.py).
