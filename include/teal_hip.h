@@ -133,7 +133,8 @@ int teal_dense_gemv(const void* x, const void* wT, void* y, int Z, int N, int dt
 /* int4 group-quantised weight-only variant (the reference ships int4-g32/64/128/256 for its dense
  * path only: gpt-fast/quantize.py:58-162 group q-params / quantise / dequantise, :483-526 WeightOnlyInt4Linear over a
  * CUDA-only packed layout).  w[n][m] = (q - 8) * scale[m / G][n] + zero[m / G][n], q in 0..15.
- *   wq               nibble image of W^T by ROW PAIRS: [Z / 2][ldb] BYTES (ldb >= N, ldb % 8 == 0, 8-byte aligned); the
+ *   wq               nibble image of W^T by ROW PAIRS: [Z / 2][ldb] BYTES (ldb >= N, ldb % 8 == 0, 8-byte aligned; for speed
+ *                    ldb % 128 == 0 and a 128-byte aligned base, so that a tile's 128-byte segment is ONE memory line); the
  *                    32-bit word g of pair-row p holds columns 4g .. 4g+3 of row 2p in its low half (nibble j = column
  *                    4g + j) and of row 2p + 1 in its high half — two rows of a column unpack into one half2 for a packed
  *                    dot product; a pair is fetched when either of its rows is kept

@@ -89,8 +89,10 @@ struct I4Args {
 // loads and running 16 steps per pass so that the loop body is straight-line and the compiler's vmcnt waits exact — measured
 // SLOWER: 494 against 537 tok/s on Llama-2-7B, 66.4 against 89.1 on Llama-2-70B, int4-g32 @ 50 %; 128 VGPRs with spills,
 // 17 % more loads and steps than the pairs that exist.  Starting the odd waves half a pass late, so that one half of the
-// chip's waves loads while the other computes: 88.1 / 86.2 against 89.4 tok/s (70B), 533 / 523 against 539 (7B).  Neither is
-// kept: the passes are not the bound, the 128-byte row segments are.)
+// chip's waves loads while the other computes: 88.1 / 86.2 against 89.4 tok/s (70B), 533 / 523 against 539 (7B).  A ring of 8
+// loads per lane that never drains between passes, the next pass's lists built while the current one streams (ISA checked:
+// exact progressive vmcnt waits): 561 against 578, 97.4 against 102.9.  None is kept: overlap inside a wave is not what
+// bounds the launch — padding every unit to 16 steps costs more than the overlap returns.)
 constexpr int kI4Group = 0, kI4Share = 1;
 template <bool BF16, int MODE, int KIND, bool PHASE = false>
 __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) {
