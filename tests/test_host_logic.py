@@ -280,6 +280,17 @@ def test_to_column_major_int8_pads_128_bytes():
     assert lin.weight.stride() == (1, 40 + 64)
 
 
+def test_weight_images_keep_rows_on_128_byte_lines():
+    """Every weight image the kernels gather from pads its rows by a multiple of 128 bytes at the real layer widths, so that a
+    column tile's 128- / 256-byte row segment never straddles an extra memory line (the int4 image's first padding, 64 bytes,
+    cost 7 % at 7B widths and 15 % at 70B)."""
+    from teal_amd.monkeypatch import ROW_PAD, UP_SHIFT_BYTES
+    from teal_amd.quantize import INT4_ROW_PAD_BYTES
+    assert (ROW_PAD * 2) % 128 == 0 and UP_SHIFT_BYTES % 128 == 0 and INT4_ROW_PAD_BYTES % 128 == 0
+    for N in (4096, 6144, 10240, 12288, 11008, 14336, 28672, 13824, 17920, 22016, 32000, 128256):
+        assert ((N + ROW_PAD) * 2) % 128 == 0 and (N + 128) % 128 == 0 and (N + INT4_ROW_PAD_BYTES) % 128 == 0, N
+
+
 def test_engine_grouped_query_split_choice_mirrors_the_launcher():
     """engine.py picks the split count of the grouped-query attention launch from the same LDS formula and limits as
     attention_split_impl (teal_attention.hip); a drift would silently fall back to the per-query-head kernel."""

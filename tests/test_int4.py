@@ -28,6 +28,7 @@ def test_int4_quantiser_bit_identical_to_reference(tag):
     assert np.array_equal(wdq[:16].float().numpy(), k[f"{tag}_wdq_rows16"])
     packed = pack_int4_colmajor(q)
     assert packed.shape[0] == Z // 2 and packed.dtype == torch.uint8 and torch.equal(unpack_int4_colmajor(packed, N), q)
+    assert packed.stride(0) % 128 == 0, "pair-rows start on 128-byte lines: a tile's 128-byte segment must not straddle two"
 
 
 def _truth(x, q, sz, G, cols):
