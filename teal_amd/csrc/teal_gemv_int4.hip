@@ -91,7 +91,8 @@ struct I4Args {
 // 17 % more loads and steps than the pairs that exist.  Starting the odd waves half a pass late, so that one half of the
 // chip's waves loads while the other computes: 88.1 / 86.2 against 89.4 tok/s (70B), 533 / 523 against 539 (7B).  A ring of 8
 // loads per lane that never drains between passes, the next pass's lists built while the current one streams (ISA checked:
-// exact progressive vmcnt waits): 561 against 578, 97.4 against 102.9.  None is kept: overlap inside a wave is not what
+// exact progressive vmcnt waits): 561 against 578, 97.4 against 102.9.  Passes of eight units, two per lane group (32 loads in
+// flight per lane, the 7B gate|up launch in one pass): 567 against 578, 99.4 against 102.8.  None is kept: overlap inside a wave is not what
 // bounds the launch — padding every unit to 16 steps costs more than the overlap returns.)
 constexpr int kI4Group = 0, kI4Share = 1;
 template <bool BF16, int MODE, int KIND, bool PHASE = false>
