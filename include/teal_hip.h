@@ -333,8 +333,9 @@ int teal_set_swizzle(int on);
  *   [0] kernel entry, [1] kernel arguments in registers, [2] activation ready, [3] row list ready, [4] first weight
  *   batch consumed (wave 0), [5] wave 0 done streaming, [6] past the reduce barrier, [7] done,
  *   [12] hardware id << 32 | XCC id, [13] waves << 32 | workgroups, [16 + w] end of stream of wave w (w < 16).
- * The attention and sampler launches stamp rows of the same width with their own phase meanings (scripts/attn_phase.py,
- * scripts/sampler_phase.py).  NULL (default) disables.  Process-global. */
+ * The attention, sampler and int4 launches (the latter with fp16 activations only) stamp rows of the same width with their own
+ * phase meanings (scripts/attn_phase.py, scripts/sampler_phase.py, scripts/int4_phase.py).  NULL (default) disables.
+ * Process-global. */
 int teal_set_phase_buffer(void* dev_u64);
 /* > 0: consecutive GEMV / attention launches stamp consecutive regions of `u64_per_launch` uint64 of the phase buffer
  * (so that a chain of launches can be timed against each other): u64_per_launch >= 32 * the largest launch's
