@@ -15,6 +15,7 @@
 
 #include <limits.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <vector>
@@ -131,7 +132,9 @@ int g_phase_seq = 0;
 int g_swizzle = 0;
 int g_wave_local = 1;
 int g_fast = 1;  // lean kernel (teal_gemv_fast.h) where the shape qualifies
-int g_exp = 0;   // experiment switches handed to the lean kernel (teal_set_experiment)
+// experiment switches handed to the lean kernel (teal_set_experiment); TEAL_EXPERIMENT=<mask> presets them for a whole
+// process (running the test suite under an experiment)
+int g_exp = getenv("TEAL_EXPERIMENT") ? atoi(getenv("TEAL_EXPERIMENT")) : 0;
 
 // ---- per-device properties (immutable once cached) ---------------------------------------------------------------
 constexpr int kMaxDevices = 64;
