@@ -169,6 +169,12 @@ int teal_sparse_gateup_silu(const void* x, const void* w1T, const void* w3T, voi
                               * att_nsplit = nsplit (0 means 4); Z <= 16384 (nsplit 4) / 8192 (nsplit 8) */
 #define TEAL_OUT_ROUNDED 0   /* y rounded to dtype (runs the ordered slab reduce when split-K is used) */
 #define TEAL_OUT_SLABS 1     /* leave the fp32 split-K slabs for the next launch's RESID_NORM producer */
+#define TEAL_OUT_QKV_ROPE 3  /* nseg == 3 = q | k | v of ONE fused wqkv image, RESID_NORM input: when the launch needs no
+                              * split-K (and the lean kernel takes it: *nslabs_out = 0), its epilogue applies RoPE to q and
+                              * to the new k row and appends k, v to the caches (gpt-fast/model.py:170-178): y[0] = rotated
+                              * q [ncols[0]], rounded exactly as teal_decode_attention* would have; follow it with
+                              * teal_decode_attention_split_roped.  Otherwise (*nslabs_out >= 1) the launch behaved as
+                              * TEAL_OUT_SLABS (slabs required) and teal_decode_attention_split_slabs finishes the job */
 #define TEAL_OUT_PAIR_SILU 2 /* nseg == 2 (gate, up of equal shape): every workgroup streams the same column tile
                               * of both matrices and stores h = silu(gate) * up to y[0] (model.py:258-259); optional
                               * mask_out[ncols/64] = keep masks of h against mask_tau for a TEAL_IN_MASKED consumer */
@@ -217,6 +223,13 @@ typedef struct teal_gemv_out {
                             * SILU_MUL, ATTN_MERGE; out modes ROUNDED and SLABS */
     int scale_ld[3];       /* int4 only: columns per group row of scale[i] (the image's N) */
     int groupsize;         /* int4 only: 32, 64, 128 or 256 rows per quantisation group; Z a multiple */
+    /* TEAL_OUT_QKV_ROPE only (zero otherwise): */
+    const void* rope;          /* (cos, sin) table [rope_max_seq][rope_head_dim / 2][2], activation dtype */
+    const int32_t* rope_pos;   /* device int32: position of the token being decoded (clamped to the cache) */
+    void* k_cache;             /* [ncols[1] / rope_head_dim][rope_max_seq][rope_head_dim] */
+    void* v_cache;
+    int rope_head_dim;         /* 64 or 128 */
+    int rope_max_seq;
 } teal_gemv_out_t;
 
 /* One launch: [fused producer] -> mask + compaction -> gathered GEMV over every segment.
@@ -266,6 +279,13 @@ int teal_decode_attention_split_ws(const void* qkv, const float* qkv_slabs, int 
                                    const int32_t* pos, void* k_cache, void* v_cache, void* y, void* mask_out,
                                    float mask_tau, int n_head, int n_kv_head, int head_dim, int max_seq, int nsplit,
                                    void* partials, size_t partials_bytes, int dtype, void* ws, size_t ws_bytes, void* stream);
+/* After a TEAL_OUT_QKV_ROPE projection that reported *nslabs_out = 0: q = the rotated, rounded query [n_head * head_dim];
+ * the token's k / v rows are already in the caches.  Always the per-query-head split kernel (no grouped-query form); same
+ * partials, merge and results as teal_decode_attention_split_ws. */
+int teal_decode_attention_split_roped(const void* q, const int32_t* pos, const void* k_cache, const void* v_cache, void* y,
+                                      void* mask_out, float mask_tau, int n_head, int n_kv_head, int head_dim, int max_seq,
+                                      int nsplit, void* partials, size_t partials_bytes, int dtype, void* ws, size_t ws_bytes,
+                                      void* stream);
 /* y == NULL: only the partials are written (no merge launch); with nsplit 4 or 8 a TEAL_IN_ATTN_MERGE wo
  * projection merges them in its own prologue (nsplit 4 or 8) — one launch less per layer, and 4 CUs per head pull the KV
  * cache instead of one (a single CU sustains ~50 GB/s, which bounds the one-workgroup-per-head kernel). */

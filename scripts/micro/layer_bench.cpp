@@ -83,6 +83,7 @@ struct Layer {
 
 int main(int argc, char** argv) {
     int n_layer = 32, steps = 100, pos0 = 64, warm = 5, att_split = 0, pair = 1;
+    int use_rope = getenv("LB_ROPE") ? atoi(getenv("LB_ROPE")) : 1;  // RoPE + KV append in the qkv launch's epilogue (TEAL_OUT_QKV_ROPE)
     float sparsity = 0.5f;
     bool phase = false, dense = false, bf = false;
     std::string model = "7b";
@@ -170,6 +171,7 @@ int main(int argc, char** argv) {
     uint16_t* A = (uint16_t*)allocz(dim * 2); uint16_t* B = (uint16_t*)allocz(dim * 2);
     uint16_t* y_attn = (uint16_t*)allocz(dim * 2); uint16_t* h_mlp = (uint16_t*)allocz(inter * 2);
     uint16_t* gu = (uint16_t*)allocz((size_t)2 * inter * 2);
+    uint16_t* q_rot = (uint16_t*)allocz((size_t)nqkv * 2);
     unsigned long long* y_mask = (unsigned long long*)allocz(((dim + 63) / 64) * 8);
     unsigned long long* h_mask = (unsigned long long*)allocz(((inter + 63) / 64) * 8);
     const size_t slab_floats = (size_t)32 * std::max(dim, nqkv);
@@ -209,12 +211,20 @@ int main(int argc, char** argv) {
         const int nc[3] = {dim, kv, kv}; const float tau[3] = {tq, tq, tq};
         teal_gemv_out_t o = mk_out(3, w, ld, c0, nc, tau, nullptr, TEAL_OUT_SLABS, s_qkv);
         o.slabs_bytes = (size_t)8 * nqkv * 4;
+        if (use_rope) {
+            o.mode = TEAL_OUT_QKV_ROPE; o.y[0] = q_rot; o.rope = rope; o.rope_pos = pos; o.k_cache = l.kc; o.v_cache = l.vc;
+            o.rope_head_dim = hd; o.rope_max_seq = max_seq;
+        }
         apply_tune("qkv");
         TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, &n_qkv, ls));
     };
     auto k_attn = [&](int i, bool to_y, float tau_o) {
         Layer& l = Ls[i];
         apply_tune("attn");
+        if (n_qkv == 0)
+            TK(teal_decode_attention_split_roped(q_rot, pos, l.kc, l.vc, to_y ? y_attn : nullptr, y_mask, tau_o, S.n_head, S.n_kv, hd, max_seq,
+                                                 att_split, att_ws, att_bytes, dt, nullptr, 0, ls));
+        else
         TK(teal_decode_attention_split_slabs(s_qkv, n_qkv, rope, pos, l.kc, l.vc, to_y ? y_attn : nullptr, y_mask, tau_o, S.n_head, S.n_kv,
                                              hd, max_seq, att_split, att_ws, att_bytes, dt, ls));
     };
@@ -462,6 +472,47 @@ int main(int argc, char** argv) {
             const double ta = time_graph(g1, steps, true), tb = time_graph(ge2, steps, true);
             printf("  two-queue bound round %d: one stream %.1f us (%.2f/layer)   two streams, no dependencies %.1f us (%.2f/layer)\n", r, ta, ta / n_layer, tb, tb / n_layer);
         }
+        return 0;
+    }
+    if (getenv("LB_ROPEAB")) {
+        // A/B inside one process: RoPE + KV append in the qkv epilogue (+ the attention launch that starts from finished rows)
+        // against the slab hand-over (attention sums the slabs, rotates, appends)
+        const int r0 = use_rope;
+        {   // same bits either way: split-KV partials of the attention launch and the cache rows of the token
+            auto snap = [&](const void* d, size_t bytes) { std::vector<unsigned char> h(bytes); CK(hipStreamSynchronize(st)); CK(hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost)); return h; };
+            int32_t pcur = 0; CK(hipMemcpy(&pcur, pos, 4, hipMemcpyDeviceToHost));
+            int bad = 0;
+            for (int i : {0, 1, n_layer - 1}) {
+                Layer& l = Ls[i];
+                use_rope = 0;
+                for (int e = 0; e < i; ++e) { Layer& q = Ls[e]; k_qkv(e, q.tq); k_attn(e, !fused_merge, q.to); k_wo(e, q.to); k_gu(e, q.tg, q.td); k_down(e, q.td); }
+                const size_t rowb = (size_t)hd * 2, cache_b = (size_t)S.n_kv * max_seq * hd * 2;
+                CK(hipMemsetAsync(l.kc + (size_t)pcur * hd, 0, rowb, st)); CK(hipMemsetAsync(l.vc + (size_t)pcur * hd, 0, rowb, st));
+                k_qkv(i, l.tq); k_attn(i, !fused_merge, l.to);
+                auto a0 = snap(att_ws, att_bytes); auto k0 = snap(l.kc, cache_b); auto v0 = snap(l.vc, cache_b);
+                use_rope = 1;
+                CK(hipMemsetAsync(l.kc + (size_t)pcur * hd, 0, rowb, st)); CK(hipMemsetAsync(l.vc + (size_t)pcur * hd, 0, rowb, st));
+                k_qkv(i, l.tq); k_attn(i, !fused_merge, l.to);
+                auto a1 = snap(att_ws, att_bytes); auto k1 = snap(l.kc, cache_b); auto v1 = snap(l.vc, cache_b);
+                const bool ok = a0 == a1 && k0 == k1 && v0 == v1;
+                printf("  rope verify layer %d (pos %d, n_qkv %d): partials %s, K cache %s, V cache %s\n", i, pcur, n_qkv, a0 == a1 ? "same" : "DIFF",
+                       k0 == k1 ? "same" : "DIFF", v0 == v1 ? "same" : "DIFF");
+                bad += !ok;
+            }
+            const bool forced = getenv("LB_EXP") && (atoi(getenv("LB_EXP")) & 1024);  // another geometry than the slab hand-over: other fp32 sums
+            if (bad && !forced) { printf("rope verify FAILED\n"); return 3; }
+        }
+        use_rope = 0; token_step(); CK(hipStreamSynchronize(st)); hipGraphExec_t ga = capture(token_step);
+        use_rope = 1; token_step(); CK(hipStreamSynchronize(st)); hipGraphExec_t gb = capture(token_step);
+        use_rope = r0;
+        double sa = 0, sb = 0; const int rounds = 6;
+        for (int r = 0; r < rounds; ++r) {
+            const double ta = time_graph(ga, steps, true), tb = time_graph(gb, steps, true);
+            printf("  rope A/B round %d: attention rotates %.1f us  qkv epilogue rotates %.1f us\n", r, ta, tb);
+            if (r) { sa += ta; sb += tb; }
+        }
+        printf("rope A/B mean (rounds 1..): attention rotates %.1f us/token, qkv epilogue rotates %.1f us/token  -> %+.2f %%\n", sa / (rounds - 1),
+               sb / (rounds - 1), (sb / sa - 1.0) * 100.0);
         return 0;
     }
     if (getenv("LB_PAIRAB")) {

@@ -34,6 +34,7 @@ EXPORTS = (
     "teal_sparse_gemv", "teal_sparse_qkv_gemv", "teal_dense_gemv", "teal_sparse_gateup_silu",
     "teal_set_tuning", "teal_get_config", "teal_set_phase_buffer", "teal_fused_gemv", "teal_decode_attention", "teal_sample_topk", "teal_set_swizzle", "teal_set_wave_local", "teal_sparse_qkv_gemv_ld", "teal_decode_attention_masked", "teal_decode_attention_split", "teal_sparse_qkv_gemv_i8", "teal_decode_attention_split_slabs", "teal_set_phase_stride", "teal_set_fast", "teal_last_launch_desc", "teal_sparse_qkv_gemv_i4", "teal_set_experiment",
     "teal_workspace_init", "teal_workspace_release", "teal_sample_topk_ws", "teal_decode_attention_split_ws", "teal_cmp_flag_gemv",
+    "teal_decode_attention_split_roped",
 )
 
 _lib = None
@@ -129,6 +130,7 @@ def load() -> ctypes.CDLL:
     L.teal_decode_attention_split_slabs.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, ci, vp, sz, ci, vp]
     L.teal_decode_attention_split_ws.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, ci, vp, sz, ci, vp, sz, vp]
     L.teal_cmp_flag_gemv.argtypes = [vp, vp, ci, vp, vp, cf, ci, ci, ci, vp]
+    L.teal_decode_attention_split_roped.argtypes = [vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, ci, vp, sz, ci, vp, sz, vp]
     L.teal_decode_attention.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
     L.teal_get_config.argtypes = [ci, ci, ci, ctypes.POINTER(ci)]
     for name in EXPORTS:

@@ -71,8 +71,8 @@ __global__ __launch_bounds__(NT) void decode_attention_kernel(
         const float sn = bits_to_float(rope[((size_t)pos * (hd / 2) + tid) * 2 + 1], BF16);
         const float q0 = bits_to_float(qh[2 * tid], BF16), q1 = bits_to_float(qh[2 * tid + 1], BF16);
         const float k0 = bits_to_float(kh[2 * tid], BF16), k1 = bits_to_float(kh[2 * tid + 1], BF16);
-        const uint16_t qa = float_to_bits<BF16>(q0 * c - q1 * sn), qb = float_to_bits<BF16>(q1 * c + q0 * sn);
-        const uint16_t ka = float_to_bits<BF16>(k0 * c - k1 * sn), kb = float_to_bits<BF16>(k1 * c + k0 * sn);
+        const uint16_t qa = float_to_bits<BF16>(rope_even(q0, q1, c, sn)), qb = float_to_bits<BF16>(rope_odd(q0, q1, c, sn));
+        const uint16_t ka = float_to_bits<BF16>(rope_even(k0, k1, c, sn)), kb = float_to_bits<BF16>(rope_odd(k0, k1, c, sn));
         qs[2 * tid] = bits_to_float(qa, BF16);
         qs[2 * tid + 1] = bits_to_float(qb, BF16);
         kn[2 * tid] = bits_to_float(ka, BF16);
@@ -291,7 +291,7 @@ __device__ __forceinline__ void fold_merge(unsigned* __restrict__ ticket, const 
 // Each workgroup writes an un-normalised partial {running max m, sum l, o[hd]}; the wo projection's merge producer
 // (or the merge kernel) rescales and sums them and rounds once.
 // ------------------------------------------------------------------------------------------------
-template <bool BF16, int HD, int NT>
+template <bool BF16, int HD, int NT, bool ROPED = false>
 __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
     const int* __restrict__ pos_ptr, const float* __restrict__ qkv_slabs, uint16_t* __restrict__ k_cache,
     uint16_t* __restrict__ v_cache, const uint16_t* __restrict__ qkv, float* __restrict__ partials,
@@ -352,7 +352,10 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
     };
     f32x4 la[4], lb[4];
     uint16_t lr[4] = {0, 0, 0, 0};
-    const bool rot = tid < hd / 2, vld = tid >= 128 && tid < 128 + hd;
+    // ROPED (after a TEAL_OUT_QKV_ROPE projection): qkv = the rotated, rounded query; the token's k / v rows are in the caches
+    u32x4 qraw = {0u, 0u, 0u, 0u};
+    if constexpr (ROPED) qraw = *reinterpret_cast<const u32x4*>(qkv + (size_t)h * hd + ds * 8);
+    const bool rot = !ROPED && tid < hd / 2, vld = !ROPED && tid >= 128 && tid < 128 + hd;
     if (rot) {
         raw_at(h * hd + 2 * tid, la[0], lb[0], lr[0]);
         raw_at(h * hd + 2 * tid + 1, la[1], lb[1], lr[1]);
@@ -372,16 +375,16 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
         return;
     }
     const int nsteps = ((n + STEP - 1) / STEP - sp + nsplit - 1) / nsplit;  // local steps with a row in range
-    const bool has_new = ((pos / STEP) % nsplit) == sp;  // this workgroup's rows include the token being decoded
+    const bool has_new = !ROPED && ((pos / STEP) % nsplit) == sp;  // this workgroup's rows include the token being decoded
     if (rot) {
         const float c = bits_to_float(rope[((size_t)pos * (hd / 2) + tid) * 2], BF16);
         const float sn = bits_to_float(rope[((size_t)pos * (hd / 2) + tid) * 2 + 1], BF16);
         const float q0 = fin_at(la[0], lb[0], lr[0]), q1 = fin_at(la[1], lb[1], lr[1]);
-        qs[2 * tid] = bits_to_float(float_to_bits<BF16>(q0 * c - q1 * sn), BF16);
-        qs[2 * tid + 1] = bits_to_float(float_to_bits<BF16>(q1 * c + q0 * sn), BF16);
+        qs[2 * tid] = bits_to_float(float_to_bits<BF16>(rope_even(q0, q1, c, sn)), BF16);
+        qs[2 * tid + 1] = bits_to_float(float_to_bits<BF16>(rope_odd(q0, q1, c, sn)), BF16);
         if (has_new) {
             const float k0 = fin_at(la[2], lb[2], lr[2]), k1 = fin_at(la[3], lb[3], lr[3]);
-            const uint16_t ka = float_to_bits<BF16>(k0 * c - k1 * sn), kb = float_to_bits<BF16>(k1 * c + k0 * sn);
+            const uint16_t ka = float_to_bits<BF16>(rope_even(k0, k1, c, sn)), kb = float_to_bits<BF16>(rope_odd(k0, k1, c, sn));
             kn[2 * tid] = bits_to_float(ka, BF16);
             kn[2 * tid + 1] = bits_to_float(kb, BF16);
             if (h % rep == 0) {
@@ -395,16 +398,24 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
         vn[d] = vf;
         if (h % rep == 0) vc[(size_t)pos * hd + d] = float_to_bits<BF16>(vf);
     }
-    __syncthreads();
+    if constexpr (!ROPED) __syncthreads();
     stamp_p(2);
     float qv[8];
+    if constexpr (ROPED) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) qv[j] = qs[ds * 8 + j];
+        for (int j = 0; j < 4; ++j) {
+            qv[2 * j] = bits_to_float(qraw[j] & 0xFFFFu, BF16);
+            qv[2 * j + 1] = bits_to_float(qraw[j] >> 16, BF16);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[j] = qs[ds * 8 + j];
+    }
     float lmax = -INFINITY;
     auto score_row = [&](const int i, const u32x4 w) {
         const int t = row_of(i);
         float a = 0.0f;
-        if (t == pos) {
+        if (!ROPED && t == pos) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) a += qv[j] * kn[ds * 8 + j];
         } else {
@@ -462,7 +473,7 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
         const int t = row_of(i);
         if (t >= n) return;
         const float pr = sc[i * STEP + rbase];
-        if (t == pos) {
+        if (!ROPED && t == pos) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += pr * vn[ds * 8 + j];
         } else {
@@ -666,7 +677,7 @@ __global__ __launch_bounds__(NT) void decode_attention_gqa_kernel(
             const int pr = it % (hd / 2);
             const float c = bits_to_float(rope[((size_t)pos * (hd / 2) + pr) * 2], BF16);
             const float sn = bits_to_float(rope[((size_t)pos * (hd / 2) + pr) * 2 + 1], BF16);
-            const uint32_t rr = (uint32_t)float_to_bits<BF16>(a0 * c - a1 * sn) | ((uint32_t)float_to_bits<BF16>(a1 * c + a0 * sn) << 16);
+            const uint32_t rr = (uint32_t)float_to_bits<BF16>(rope_even(a0, a1, c, sn)) | ((uint32_t)float_to_bits<BF16>(rope_odd(a0, a1, c, sn)) << 16);
             if (it < REP * (hd / 2)) {
                 qsb[it] = rr;
             } else if (has_new) {
@@ -1474,8 +1485,9 @@ int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_
 static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv_nslabs, const void* rope, const int32_t* pos,
                                 void* k_cache, void* v_cache, void* y, void* mask_out, float mask_tau, int n_head,
                                 int n_kv_head, int head_dim, int max_seq, int nsplit, void* partials, size_t partials_bytes,
-                                int dtype, void* ws, size_t ws_bytes, void* stream) {
-    if ((!qkv && !qkv_slabs) || !rope || !pos || !k_cache || !v_cache || !partials) return TEAL_ERR_ARG;
+                                int dtype, void* ws, size_t ws_bytes, void* stream, bool roped = false) {
+    if ((!qkv && !qkv_slabs) || (!rope && !roped) || !pos || !k_cache || !v_cache || !partials) return TEAL_ERR_ARG;
+    if (roped && (!qkv || !aligned16(qkv))) return TEAL_ERR_ARG;
     if (qkv_slabs && (qkv_nslabs < 1 || qkv_nslabs > 8 || !aligned16(qkv_slabs))) return TEAL_ERR_ARG;
     if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
     if ((head_dim != 64 && head_dim != 128) || n_head <= 0 || n_kv_head <= 0 || n_head % n_kv_head || max_seq <= 0 ||
@@ -1505,7 +1517,7 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
     // grouped-query models at long contexts: one workgroup per (KV head, split) serves all the query heads of the group
     // (the per-query-head kernel is 2-3 us faster below ~2 k positions: scripts/attention_context_sweep.py)
     const int rep = n_head / n_kv_head;
-    bool gqa = ((rep == 8 && max_seq >= kGqaMinSeq8) || (rep == 4 && max_seq >= kGqaMinSeq)) && !(g_exp & 8);
+    bool gqa = ((rep == 8 && max_seq >= kGqaMinSeq8) || (rep == 4 && max_seq >= kGqaMinSeq)) && !(g_exp & 8) && !roped;
     // y requested (the consumer does not merge): the merge can be FOLDED into the split launch — the last workgroup of a head
     // (or KV-head group) to arrive merges it (prepared workspace) — instead of a merge launch.  MEASURED, NOT FASTER
     // (profiles/r03_attention_context_sweep.txt): equal at 4-8 splits, 1-7 us slower at 16-32 (the last arriver's drain,
@@ -1533,12 +1545,14 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
     }
     if (!gqa) {
         if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
-#define TEAL_ATTS(BF, HDV, NTV) hipLaunchKernelGGL((decode_attention_split_kernel<BF, HDV, NTV>), grid, block, lds, st, pos, qkv_slabs, kc, vc, q, pw, r, n_head, n_kv_head, max_seq, nsplit, scale, qkv_nslabs, ph, g_exp, tk, yo, mo, mask_tau)
+#define TEAL_ATTS_R(BF, HDV, NTV, RP) hipLaunchKernelGGL((decode_attention_split_kernel<BF, HDV, NTV, RP>), grid, block, lds, st, pos, qkv_slabs, kc, vc, q, pw, r, n_head, n_kv_head, max_seq, nsplit, scale, qkv_nslabs, ph, g_exp, tk, yo, mo, mask_tau)
+#define TEAL_ATTS(BF, HDV, NTV) do { if (roped) TEAL_ATTS_R(BF, HDV, NTV, true); else TEAL_ATTS_R(BF, HDV, NTV, false); } while (0)
 #define TEAL_ATTS_NT(BF, HDV) do { if (nt == 1024) TEAL_ATTS(BF, HDV, 1024); else TEAL_ATTS(BF, HDV, 256); } while (0)
     if (dtype == TEAL_BF16) { if (head_dim == 128) TEAL_ATTS_NT(true, 128); else TEAL_ATTS_NT(true, 64); }
     else { if (head_dim == 128) TEAL_ATTS_NT(false, 128); else TEAL_ATTS_NT(false, 64); }
 #undef TEAL_ATTS_NT
 #undef TEAL_ATTS
+#undef TEAL_ATTS_R
     }
     if (hipGetLastError() != hipSuccess) return TEAL_ERR_LAUNCH;
     if (!y || tk) return TEAL_OK;  // partials only: the consumer merges (TEAL_IN_ATTN_MERGE) — or merged inside the launch
@@ -1573,6 +1587,15 @@ int teal_decode_attention_split_ws(const void* qkv, const float* qkv_slabs, int 
     if ((qkv != nullptr) == (qkv_slabs != nullptr)) return TEAL_ERR_ARG;  // exactly one form of the projection
     return attention_split_impl(qkv, qkv_slabs, qkv_nslabs, rope, pos, k_cache, v_cache, y, mask_out, mask_tau, n_head,
                                 n_kv_head, head_dim, max_seq, nsplit, partials, partials_bytes, dtype, ws, ws_bytes, stream);
+}
+
+int teal_decode_attention_split_roped(const void* q, const int32_t* pos, const void* k_cache, const void* v_cache, void* y,
+                                      void* mask_out, float mask_tau, int n_head, int n_kv_head, int head_dim, int max_seq,
+                                      int nsplit, void* partials, size_t partials_bytes, int dtype, void* ws, size_t ws_bytes,
+                                      void* stream) {
+    return attention_split_impl(q, nullptr, 0, nullptr, pos, const_cast<void*>(k_cache), const_cast<void*>(v_cache), y, mask_out,
+                                mask_tau, n_head, n_kv_head, head_dim, max_seq, nsplit, partials, partials_bytes, dtype, ws,
+                                ws_bytes, stream, true);
 }
 
 int teal_decode_attention(const void* qkv, const void* rope, const int32_t* pos, void* k_cache, void* v_cache,

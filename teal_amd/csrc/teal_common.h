@@ -72,6 +72,9 @@ struct Params {
     float mask_tau;
     unsigned long long* phase;  // optional: per-workgroup phase timestamps (teal_set_phase_buffer)
     unsigned* tickets;          // host side: arrival counters of the caller's prepared workspace (or null)
+    // TEAL_OUT_QKV_ROPE (lean kernel, split == 1): RoPE + KV-cache append in the epilogue; rope == nullptr otherwise
+    const uint16_t* rope; const int* rope_pos; uint16_t* kc; uint16_t* vc;
+    int rope_hd, rope_max_seq;
     Seg seg[kMaxSeg];
 };
 
@@ -150,6 +153,12 @@ __device__ __forceinline__ uint16_t float_to_bits(float f) {
     _Float16 h = (_Float16)f;  // v_cvt_f16_f32, round-to-nearest-even
     return __builtin_bit_cast(uint16_t, h);
 }
+
+// RoPE of one (even, odd) pair (gpt-fast/model.py:apply_rotary_emb: x0 * cos - x1 * sin, x1 * cos + x0 * sin), written with
+// explicit fused multiply-adds so that every translation unit — whatever its -ffp-contract setting — rounds the same way:
+// the qkv projection's epilogue (teal_gemv_fast.h, ROPE) and the attention launches must agree bit for bit.
+__device__ __forceinline__ float rope_even(float x0, float x1, float c, float s) { return fmaf(x0, c, -(x1 * s)); }
+__device__ __forceinline__ float rope_odd(float x0, float x1, float c, float s) { return fmaf(x1, c, x0 * s); }
 
 // keep rule of the reference kernel: float32(|x|) > float32(tau)  (kernels/sparse_gemv.py:75)
 __device__ __forceinline__ bool keep_rule(float v, float tau) { return fabsf(v) > tau; }

@@ -40,11 +40,12 @@ namespace teal {
 //   masks (in0 x, in1 masks); 4 split-KV attention partials (in0).  Element-wise modes (0, 2, 3, 4) cache the rounds of
 //   the workgroup's own slice only: register k <-> round slice + k * split.
 //   EXACT (MODE 1): Z == 1024 * KR, every cached chunk exists — no clamps, no guards.
-template <bool BF16, int MODE, bool PAIR, int LPR, int KR, bool EXACT, bool PHASE, int U = 4, bool W8 = false>
+template <bool BF16, int MODE, bool PAIR, int LPR, int KR, bool EXACT, bool PHASE, int U = 4, bool W8 = false, bool ROPE = false>
 __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const void* in1, const void* in2,
                                                          const int* row_index, const int Z, const int nslabs,
                                                          const float eps, const FastArgs a) {
     static_assert(!(W8 && PAIR), "int8 gate|up runs unpaired (two images of 128-byte row segments)");
+    static_assert(!ROPE || (MODE == 1 && !PAIR && !W8), "the RoPE / KV-append epilogue belongs to the fused wqkv projection");
     constexpr int WAVES = 16;
     constexpr int RPW = 64 / LPR;
     // a lane owns 8 columns: 16 bytes of 16-bit weights, 8 bytes of int8 weights (the same lane <-> row mapping, hence the
@@ -73,6 +74,8 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
     bool own[KR];    // chunk exists and its rows belong to this workgroup (wave-uniform)
     int cidx[KR];
     float sumsq_part = 0.0f;
+    int rope_p = 0;            // ROPE: clamped position of the token
+    uint32_t rope_cs = 0u;     // ROPE: (cos | sin << 16) of this thread's column pair
     float rv[MODE == 1 ? KR : 1];
     uint32_t wb[MODE == 1 ? KR : 1];
     unsigned long long mk[MODE == 3 ? KR : 1];
@@ -112,6 +115,16 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
             for (int k = 0; k < KR; ++k) v1[k] = *reinterpret_cast<const f32x4*>(slabs + mel[k] * stride + 4);
         }
         TEAL_FAST_ARGS_BATCH(a);
+        if constexpr (ROPE) {
+            // position and the (cos, sin) pair of this thread's output column: requested now, used in the epilogue.  Issued by
+            // EVERY thread (unconditional: the compiler's vmcnt bookkeeping stays exact), the same 4 bytes per column pair
+            asm volatile("" ::"s"(a.rope), "s"(a.rope_pos), "s"(a.kc), "s"(a.vc), "s"(a.rope_hd), "s"(a.rope_dim), "s"(a.rope_kv),
+                         "s"(a.rope_max_seq));
+            rope_p = min(max(a.rope_pos[0], 0), a.rope_max_seq - 1);
+            const uint32_t cc = (uint32_t)tile * BN + (uint32_t)(tid & (BN - 1));
+            const uint32_t jj = (cc & (uint32_t)(a.rope_hd - 1)) >> 1;  // head_dim is 64 or 128
+            rope_cs = *reinterpret_cast<const uint32_t*>(a.rope + ((size_t)rope_p * (size_t)(a.rope_hd >> 1) + jj) * 2);
+        }
         stamp(1);
         // slab order 0, 1, 2, ... (the order of the ordered reduce launch); adding an absent slab as 0.0f is exact
         float ysum[KR];
@@ -459,7 +472,27 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
             const unsigned long long mko = __ballot(keep_rule(hv, a.mask_tau) || (hv != hv));
             if (a.mask_out && lane == 0) a.mask_out[c >> 6] = mko;
         } else if (a.ws_stride == 0) {
-            reinterpret_cast<uint16_t*>(a.y)[c] = float_to_bits<BF16>(gs);
+            if constexpr (ROPE) {
+                // gpt-fast/model.py:170-178: q and the new k row are rotated (pairs of adjacent columns: lane ^ 1 holds the
+                // partner), k and v go straight into their cache rows; the roundings are those of the unfused sequence
+                // (projection rounded, rotation in fp32, rounded again — what the attention launch did with the same helpers)
+                const uint16_t b16 = float_to_bits<BF16>(gs);
+                const float f = bits_to_float(b16, BF16);
+                const float pr = __shfl_xor(f, 1);
+                const float cs = bits_to_float(rope_cs & 0xFFFFu, BF16), sn = bits_to_float(rope_cs >> 16, BF16);
+                const uint16_t rb = float_to_bits<BF16>((tid & 1) ? rope_odd(pr, f, cs, sn) : rope_even(f, pr, cs, sn));
+                const uint32_t dimq = (uint32_t)a.rope_dim, kvw = (uint32_t)a.rope_kv, hdm = (uint32_t)a.rope_hd;
+                if (c < dimq) {
+                    reinterpret_cast<uint16_t*>(a.y)[c] = rb;
+                } else {
+                    const bool isk = c < dimq + kvw;
+                    const uint32_t cc = c - dimq - (isk ? 0u : kvw);
+                    const uint32_t kvh = cc / hdm, d = cc & (hdm - 1u);
+                    (isk ? a.kc : a.vc)[((size_t)kvh * (size_t)a.rope_max_seq + (size_t)rope_p) * hdm + d] = isk ? rb : b16;
+                }
+            } else {
+                reinterpret_cast<uint16_t*>(a.y)[c] = float_to_bits<BF16>(gs);
+            }
         } else if (!a.ticket) {
             a.ws[c * (uint32_t)a.ws_stride + slice] = gs;
         } else {
@@ -515,6 +548,13 @@ hipError_t launch_fast_e(const FastLaunch& f, hipStream_t st) {
                                    f.in2, f.row_index, f.Z, f.nslabs, f.eps, f.a);
                 return hipGetLastError();
             }
+        }
+    }
+    if constexpr (MODE == 1 && !PAIR && !W8) {
+        if (f.a.rope) {  // fused wqkv projection, split == 1: RoPE + KV-cache append in the epilogue
+            hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, false, 4, W8, true>), grid, block, f.lds, st, f.in0, f.in1,
+                               f.in2, f.row_index, f.Z, f.nslabs, f.eps, f.a);
+            return hipGetLastError();
         }
     }
     hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, false, 4, W8>), grid, block, f.lds, st, f.in0, f.in1, f.in2,

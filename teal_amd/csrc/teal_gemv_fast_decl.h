@@ -25,6 +25,13 @@ struct FastArgs {
     const uint16_t* scale1;
     int w1_tile;                    // not PAIR: first tile that streams the second image w1 / ld1 (INT_MAX: one image)
     int exp;                        // experiment switches (teal_set_experiment; 0 in production): A/B inside one process
+    // ROPE instantiations (TEAL_OUT_QKV_ROPE: the fused wqkv projection with split == 1): RoPE of q and of the new k row and
+    // the KV-cache append happen in the epilogue (gpt-fast/model.py:170-178), so the attention launch starts from finished rows
+    const uint16_t* rope;           // (cos, sin) table [max_seq][head_dim / 2][2]
+    const int* rope_pos;            // device int32: position of the token being decoded
+    uint16_t* kc;                   // K cache [n_kv_head][max_seq][head_dim]
+    uint16_t* vc;                   // V cache
+    int rope_hd, rope_dim, rope_kv, rope_max_seq;  // head_dim, n_head * head_dim, n_kv_head * head_dim, cache rows
 };
 
 // Launch description filled by run_gemv when the shape qualifies (teal_kernels.hip: fast_eligible)

@@ -132,6 +132,7 @@ int g_phase_seq = 0;
 int g_swizzle = 0;
 int g_wave_local = 1;
 int g_fast = 1;  // lean kernel (teal_gemv_fast.h) where the shape qualifies
+static bool g_rope_taken = false;  // the most recent run_gemv launched a ROPE instantiation (TEAL_OUT_QKV_ROPE bookkeeping)
 // experiment switches handed to the lean kernel (teal_set_experiment); TEAL_EXPERIMENT=<mask> presets them for a whole
 // process (running the test suite under an experiment)
 int g_exp = getenv("TEAL_EXPERIMENT") ? atoi(getenv("TEAL_EXPERIMENT")) : 0;
@@ -327,6 +328,13 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
     f.a.exp = g_exp;
     f.a.ws_stride = (to_ws || ticketed) ? ((c.split + 3) & ~3) : 0;
     f.a.ticket = ticketed ? p.tickets : nullptr;
+    if (p.rope) {  // RoPE + KV append epilogue: one rounded q|k|v vector, no split-K, tiles inside one head
+        if (mode != 1 || p.pair || p.w8 || to_ws || c.split != 1 || p.nseg != 3 || (p.rope_hd != 64 && p.rope_hd != 128) ||
+            p.rope_hd % bn || p.seg[1].ncols != p.seg[2].ncols || p.seg[0].ncols % p.rope_hd || p.seg[1].ncols % p.rope_hd)
+            return false;
+        f.a.rope = p.rope; f.a.rope_pos = p.rope_pos; f.a.kc = p.kc; f.a.vc = p.vc;
+        f.a.rope_hd = p.rope_hd; f.a.rope_dim = p.seg[0].ncols; f.a.rope_kv = p.seg[1].ncols; f.a.rope_max_seq = p.rope_max_seq;
+    }
     return true;
 }
 
@@ -483,7 +491,10 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
     if (used) *used = c;
     {
         FastLaunch f;
-        if (fast_eligible(p, c, to_ws, ws_bytes, f)) {
+        const bool lean = fast_eligible(p, c, to_ws, ws_bytes, f);
+        if (p.rope && !lean) return TEAL_ERR_CONFIG;  // the RoPE epilogue exists in the lean kernel only: never fall through unrotated
+        if (lean) {
+            g_rope_taken = f.a.rope != nullptr;
             snprintf(g_last_desc, sizeof g_last_desc, "gemv_fast_kernel<%s,%d,%s,%d,%d,%s,false%s> grid (%d,%d) x 1024",
                      dtype == TEAL_BF16 ? "true" : "false", f.mode, f.pair ? "true" : "false", f.lpr, f.kr,
                      (f.mode == 1 && f.Z == 1024 * f.kr) ? "true" : "false", f.w8 ? ",4,true" : ",4,false", f.ntiles, f.split);
@@ -838,6 +849,39 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
         if (rc == TEAL_OK && out->slabs_interleaved && !p.ws_il) return TEAL_ERR_CONFIG;  // > 8 slices cannot interleave
     } else if (out->mode == TEAL_OUT_ROUNDED) {
         rc = run_gemv(p, dtype, ws, ws_bytes, false, st, &used, false);
+    } else if (out->mode == TEAL_OUT_QKV_ROPE) {
+        if (out->nseg != 3 || in->mode != TEAL_IN_RESID_NORM || !out->y[0] || !out->rope || !out->rope_pos || !out->k_cache ||
+            !out->v_cache || out->rope_max_seq <= 0 || !nslabs_out)
+            return TEAL_ERR_ARG;
+        // the fused epilogue exists in the lean kernel for a launch without split-K; decide before launching
+        int total_cols = 0;
+        for (int i = 0; i < 3; ++i) total_cols += out->ncols[i];
+        Params q = p;
+        q.rope = reinterpret_cast<const uint16_t*>(out->rope);
+        q.rope_pos = out->rope_pos;
+        q.kc = reinterpret_cast<uint16_t*>(out->k_cache);
+        q.vc = reinterpret_cast<uint16_t*>(out->v_cache);
+        q.rope_hd = out->rope_head_dim;
+        q.rope_max_seq = out->rope_max_seq;
+        q.seg[1].y = reinterpret_cast<uint16_t*>(out->y[0]) + out->ncols[0];                   // (k, v land in the caches; the
+        q.seg[2].y = reinterpret_cast<uint16_t*>(out->y[0]) + out->ncols[0] + out->ncols[1];   //  lean kernel wants one vector)
+        const Config c0 = pick_config(Z, total_cols, 3);
+        bool fused = false;
+        // (a 70B-class projection hands over row-sliced slabs of 128-column tiles instead — run_gemv's wide_sliced geometry,
+        //  measured faster there; experiment bit 10 takes the epilogue anyway, for A/B)
+        const bool sliced = (size_t)Z * total_cols >= (size_t)8192 * 8192 && !(g_exp & 1024);
+        if (c0.split == 1 && !sliced && g_fast && !g_override.split && !g_override.lpr) {
+            g_rope_taken = false;
+            rc = run_gemv(q, dtype, ws, ws_bytes, false, st, &used, false);
+            if (rc != TEAL_OK && rc != TEAL_ERR_CONFIG) return rc;  // TEAL_ERR_CONFIG: not a lean-kernel shape, nothing was launched
+            fused = rc == TEAL_OK && g_rope_taken;
+            if (rc == TEAL_OK && !fused) return TEAL_ERR_LAUNCH;    // (unreachable: run_gemv refuses to launch a rope request unrotated)
+        }
+        if (fused) { *nslabs_out = 0; return TEAL_OK; }
+        if (!out->slabs) return TEAL_ERR_ARG;
+        if (ws_prepared(out->slabs, out->slabs_bytes)) return TEAL_ERR_ARG;
+        rc = run_gemv(p, dtype, out->slabs, out->slabs_bytes, true, st, &used, true, out->slabs_interleaved != 0, false);
+        if (rc == TEAL_OK && out->slabs_interleaved && !p.ws_il) return TEAL_ERR_CONFIG;
     } else {
         return TEAL_ERR_ARG;
     }

@@ -7,7 +7,8 @@ prologue (every workgroup recomputes the tiny vector work from L2; nothing round
 separate kernel):
 
   1. qkv     [h = resid + round(sum down-slabs); x = RMSNorm(h) * w] -> mask(tau_q|k|v) -> GEMV -> q|k|v
-  2. attn    RoPE(q, k), KV-cache append, softmax(q K^T / sqrt(d)) V                         -> y
+             (no split-K, 16-bit weights: RoPE(q, k) and the KV-cache append happen in this launch's epilogue)
+  2. attn    [RoPE(q, k), KV-cache append unless done by 1.] softmax(q K^T / sqrt(d)) V     -> y
   3. wo      mask(tau_o) -> GEMV                                                            -> fp32 slabs
   4. gate|up [h = resid + round(sum wo-slabs); x = RMSNorm(h) * w] -> mask(tau_gate|up)      -> gate|up
   5. down    [x = silu(gate) * up] -> mask(tau_down) -> GEMV                                -> fp32 slabs
@@ -29,7 +30,7 @@ from ..monkeypatch import UP_SHIFT_BYTES, to_column_major
 from .model import Transformer
 
 TEAL_IN_PLAIN, TEAL_IN_RESID_NORM, TEAL_IN_SILU_MUL, TEAL_IN_MASKED, TEAL_IN_ATTN_MERGE = 0, 1, 2, 3, 4
-TEAL_OUT_ROUNDED, TEAL_OUT_SLABS, TEAL_OUT_PAIR_SILU = 0, 1, 2
+TEAL_OUT_ROUNDED, TEAL_OUT_SLABS, TEAL_OUT_PAIR_SILU, TEAL_OUT_QKV_ROPE = 0, 1, 2, 3
 MAX_SLABS = 32
 
 
@@ -47,7 +48,9 @@ class GemvOut(ctypes.Structure):  # teal_gemv_out_t
                 ("y", ctypes.c_void_p * 3), ("mode", ctypes.c_int), ("slabs", ctypes.c_void_p),
                 ("slabs_bytes", ctypes.c_size_t), ("mask_out", ctypes.c_void_p), ("mask_tau", ctypes.c_float),
                 ("slabs_interleaved", ctypes.c_int), ("weight_bits", ctypes.c_int), ("scale", ctypes.c_void_p * 3),
-                ("scale_ld", ctypes.c_int * 3), ("groupsize", ctypes.c_int)]
+                ("scale_ld", ctypes.c_int * 3), ("groupsize", ctypes.c_int),
+                ("rope", ctypes.c_void_p), ("rope_pos", ctypes.c_void_p), ("k_cache", ctypes.c_void_p), ("v_cache", ctypes.c_void_p),
+                ("rope_head_dim", ctypes.c_int), ("rope_max_seq", ctypes.c_int)]
 
 
 def _out(segs, mode, slabs: Optional[torch.Tensor] = None) -> GemvOut:
@@ -204,6 +207,11 @@ class DecodeEngine:
         else:
             self.att_split = min(16, max(2, (256 + cfg.n_head - 1) // cfg.n_head, (self.max_seq + 2047) // 2048))
         self.att_fused_merge = (self.att_split == 4 and dim <= 16384) or (self.att_split == 8 and dim <= 8192)
+        # RoPE + KV-cache append in the epilogue of the wqkv launch (TEAL_OUT_QKV_ROPE: -1.3 % per token on Llama-2-7B @ 50 %,
+        # profiles/r04_layer_experiments.txt) wherever that launch runs without split-K (the library reports which way it
+        # went) and the per-query-head attention kernel follows (the grouped-query kernel of long contexts rotates itself)
+        gqa_kernel = (rep == 8 and self.max_seq >= 2048) or (rep == 4 and self.max_seq >= 4096)
+        self.rope_epilogue = bool(self.att_split) and not (self.int8 or self.int4) and not gqa_kernel
         self.att_ws = e(cfg.n_head * max(1, self.att_split) * (hd + 2), dtype=torch.float32)
         self.eps = float(cfg.norm_eps)
         self.n_wo = ctypes.c_int(0)
@@ -248,6 +256,12 @@ class DecodeEngine:
             # split attention: the projection writes fp32 slabs that the attention launch sums itself, so a narrow
             # (GQA) wqkv is row-sliced over all CUs without a reduce launch in between
             k1_out = _out(k1_segs, TEAL_OUT_SLABS, self.s_qkv) if self.att_split else _out(k1_segs, TEAL_OUT_ROUNDED)
+            if self.rope_epilogue:
+                kc0, vc0 = at.kv_cache.k_cache, at.kv_cache.v_cache
+                k1_out.mode = TEAL_OUT_QKV_ROPE  # y[0] = rotated q; falls back to the slabs when the launch needs split-K
+                k1_out.rope, k1_out.rope_pos = self.rope.data_ptr(), None  # (position pointer: per call, see _layer)
+                k1_out.k_cache, k1_out.v_cache = kc0.data_ptr(), vc0.data_ptr()
+                k1_out.rope_head_dim, k1_out.rope_max_seq = hd_, self.max_seq
             if self.att_fused_merge:
                 k3_in = GemvIn(mode=TEAL_IN_ATTN_MERGE, x=self.att_ws.data_ptr(), att_head_dim=hd_, att_nsplit=self.att_split)
             elif self.pair:
@@ -318,12 +332,21 @@ class DecodeEngine:
             k1_in.row_index = tok_ptr
         else:
             k1_in.nslabs = self.n_down.value
+        if self.rope_epilogue:
+            k1_out.rope_pos = pos_ptr
         cb("before", "qkv", i)
         self._gemv(k1_in, k1_out, self.dim, self.n_qkv if self.att_split else None)
         cb("after", "qkv", i)
         ymask = self.y_mask.data_ptr() if self.pair else None
         cb("before", "attn", i)
-        if self.att_split:
+        if self.att_split and self.rope_epilogue and self.n_qkv.value == 0:
+            # the projection's epilogue rotated q (self.qkv[:dim]) and appended the token's k / v rows
+            rc = self.L.teal_decode_attention_split_roped(self.qkv.data_ptr(), pos_ptr, kc.data_ptr(), vc.data_ptr(),
+                                                          None if self.att_fused_merge else self.y_attn.data_ptr(), ymask, tau_o,
+                                                          cfg.n_head, cfg.n_local_heads, cfg.head_dim, self.max_seq,
+                                                          self.att_split, self.att_ws.data_ptr(), self.att_ws.numel() * 4,
+                                                          self.code, self.ws.data_ptr(), self.ws.numel() * 4, self._stream)
+        elif self.att_split:
             # (with y requested — long contexts / grouped-query shapes — the merge is folded into the split launch through the
             # arrival counters of the engine's workspace: no merge launch)
             rc = self.L.teal_decode_attention_split_ws(None, self.s_qkv.data_ptr(), self.n_qkv.value, self.rope.data_ptr(), pos_ptr,

@@ -624,3 +624,47 @@ def test_sampler_window_and_radix_kernels_pick_the_same_tokens(dtype, V, law):
             assert len(tied) >= 40 and set(outs[0]) <= tied and len(set(outs[0])) > 10
         if law == "spike" and top_k in (1, 20, 200):
             assert set(outs[0]) == {777}
+
+
+@pytest.mark.parametrize("name,dtype", [("7B", torch.float16), ("7B", torch.bfloat16), ("70B", torch.float16)])
+def test_rope_epilogue_equals_attention_side_rope(name, dtype):
+    """TEAL_OUT_QKV_ROPE (RoPE of q / the new k row and the KV-cache append in the wqkv launch's epilogue, then
+    teal_decode_attention_split_roped) against the slab hand-over (the attention launch sums, rotates and appends,
+    gpt-fast/model.py:170-178): the same bits in the cache rows of the token, the split-KV partials and the logits."""
+    from teal_amd.gpt_fast import generate as G
+    from teal_amd.gpt_fast.engine import DecodeEngine
+    model = G.build_synthetic_model(name, DEV, dtype, seed=31, n_layer=2)
+    ths = G.apply_sparsity(model, sparsity=0.5, hist_path=None, greedy_lookup=None, synthetic=True)
+    prompt = torch.randint(0, model.config.vocab_size, (9,), device=DEV, dtype=torch.int, generator=torch.Generator(device=DEV).manual_seed(6))
+    try:
+        with torch.no_grad():
+            model.max_seq_length = -1
+            model.setup_caches(1, 32)
+            model(prompt.view(1, -1), torch.arange(9, device=DEV))
+            eng = DecodeEngine(model, ths)
+            assert eng.rope_epilogue
+            tok = torch.tensor([[41]], device=DEV, dtype=torch.int)
+            pos = torch.tensor([9], device=DEV, dtype=torch.int)
+            caches = [(l.attention.kv_cache.k_cache, l.attention.kv_cache.v_cache) for l in model.layers]
+
+            def run(rope_epilogue):
+                eng.rope_epilogue = rope_epilogue
+                eng._build(ths)
+                for kc, vc in caches:  # the row of this token must be written by the step itself
+                    kc[:, :, 9].zero_()
+                    vc[:, :, 9].zero_()
+                logits = eng(tok, pos).clone()
+                return [logits, eng.att_ws.clone()] + [c[:, :, 9].clone() for kv in caches for c in kv], eng.n_qkv.value
+
+            a, na = run(True)
+            b, nb = run(False)
+            if name == "70B":  # 70B-class projections keep the row-sliced slab hand-over (faster there): the request falls back
+                assert na == nb and nb > 1, (na, nb)
+            else:
+                assert na == 0 and nb == 1, (na, nb)  # the epilogue ran / one slab was handed over: the same fp32 sums
+            for i, (x, y) in enumerate(zip(a, b)):
+                assert torch.equal(x.view(torch.uint8), y.view(torch.uint8)), i
+            assert float(a[2].float().abs().max()) > 0  # the cache row was really written
+    finally:
+        del model
+        torch.cuda.empty_cache()

@@ -198,11 +198,37 @@ def test_engine_launches_vs_oracle_under_sparsity(oracle, name, tdt, sparsity, n
                 k1_out.tau[0], k1_out.tau[1], k1_out.tau[2] = seen["tq"], seen["tk"], seen["tv"]
             elif when == "after" and stage == "qkv":
                 assert np.array_equal(bits_from_torch(B), seen["h1"]), "residual written by the qkv launch"
-                acc, _ = _slab_sum(O, np32(eng.s_qkv.view(-1)), eng.n_qkv.value, nqkv, dtype)
                 truth = O.truth64(seen["x1"], W["qkv"], dim, nqkv, seen["tq"], seen["tk"], seen["tv"], dim, kv, dtype)
-                got = O.from_bits(O.to_bits(acc, dtype), dtype)
-                err = np.abs(got - truth)
-                assert (err <= tolerance(O, truth, dtype)).all(), ("qkv", float(err.max()))
+                if eng.n_qkv.value == 0:
+                    # TEAL_OUT_QKV_ROPE: the launch's epilogue rotated q and the token's k row (gpt-fast/model.py:170-178) and
+                    # appended k, v to the caches — compare against the rotated truth with the tolerance carried through the
+                    # rotation (|cos| tol(x0) + |sin| tol(x1)) plus the second rounding
+                    assert eng.rope_epilogue and fast == 1
+                    P = int(pos.item())
+                    cs = np32(eng.rope[P])  # [hd / 2][2]
+                    c_, s_ = np.repeat(cs[:, 0], 2).astype(np.float64), np.repeat(cs[:, 1], 2).astype(np.float64)
+                    tol = tolerance(O, truth, dtype)
+
+                    def rot(v, t):
+                        v, t = v.reshape(-1, hd), t.reshape(-1, hd)
+                        sw = np.empty_like(v); sw[:, 0::2] = -v[:, 1::2]; sw[:, 1::2] = v[:, 0::2]
+                        tsw = np.empty_like(t); tsw[:, 0::2] = t[:, 1::2]; tsw[:, 1::2] = t[:, 0::2]
+                        r = v * c_ + sw * s_
+                        return r.reshape(-1), (np.abs(c_) * t + np.abs(s_) * tsw).reshape(-1) + O.ulp16(r.reshape(-1), dtype)
+
+                    tq, tolq = rot(truth[:dim], tol[:dim])
+                    tk, tolk = rot(truth[dim:dim + kv], tol[dim:dim + kv])
+                    gq = O.from_bits(bits_from_torch(eng.qkv[:dim]), dtype)
+                    gk = O.from_bits(bits_from_torch(kc[0, :, P, :].reshape(-1)), dtype)
+                    gv = O.from_bits(bits_from_torch(vc[0, :, P, :].reshape(-1)), dtype)
+                    assert (np.abs(gq - tq) <= tolq).all(), ("q rotated", float(np.abs(gq - tq).max()))
+                    assert (np.abs(gk - tk) <= tolk).all(), ("k rotated", float(np.abs(gk - tk).max()))
+                    assert (np.abs(gv - truth[dim + kv:]) <= tol[dim + kv:]).all(), ("v appended", float(np.abs(gv - truth[dim + kv:]).max()))
+                else:
+                    acc, _ = _slab_sum(O, np32(eng.s_qkv.view(-1)), eng.n_qkv.value, nqkv, dtype)
+                    got = O.from_bits(O.to_bits(acc, dtype), dtype)
+                    err = np.abs(got - truth)
+                    assert (err <= tolerance(O, truth, dtype)).all(), ("qkv", float(err.max()))
                 seen["qkv_kept"] = float((np.abs(O.from_bits(seen["x1"], dtype)) > seen["tq"]).mean())
             elif when == "before" and stage == "wo":
                 ns = eng.att_split
@@ -300,13 +326,13 @@ def test_engine_step_bit_reproducible_at_real_width(fast):
             eng = DecodeEngine(model, ths)
             tok = torch.tensor([[23]], device=DEV, dtype=torch.int)
             pos = torch.tensor([6], device=DEV, dtype=torch.int)
-            bufs = lambda: [b.clone() for b in (eng.s_qkv, eng.att_ws, eng.s_wo, eng.h_mlp, eng.h_mask, eng.s_down, eng.resid[0], eng.resid[1], eng.logits)]  # noqa: E731
+            bufs = lambda: [b.clone() for b in (eng.s_qkv, eng.qkv, eng.att_ws, eng.s_wo, eng.h_mlp, eng.h_mask, eng.s_down, eng.resid[0], eng.resid[1], eng.logits)]  # noqa: E731
             eng(tok, pos)
             ref = bufs()
             for it in range(60):
                 eng(tok, pos)
                 cur = bufs()
-                for name, a, b in zip(("s_qkv", "att_ws", "s_wo", "h_mlp", "h_mask", "s_down", "resid A", "resid B", "logits"), ref, cur):
+                for name, a, b in zip(("s_qkv", "q (rotated)", "att_ws", "s_wo", "h_mlp", "h_mask", "s_down", "resid A", "resid B", "logits"), ref, cur):
                     assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), (it, name)
     finally:
         L.teal_set_fast(1)

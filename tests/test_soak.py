@@ -32,7 +32,9 @@ def _live(eng):
     """the meaningful part of every hand-over buffer, as flat byte views (slab buffers are allocated for 32 slices)"""
     dim, inter, nq = eng.dim, eng.inter, eng.nqkv
     st = lambda n: (n + 3) & ~3  # noqa: E731
-    return [eng.s_qkv.view(-1)[: nq * st(eng.n_qkv.value)], eng.att_ws.view(-1), eng.s_wo.view(-1)[: dim * st(eng.n_wo.value)],
+    # (s_qkv: written by the general kernel only — the lean wqkv launch rotates q and appends k / v in its epilogue,
+    #  TEAL_OUT_QKV_ROPE, n_qkv == 0; both paths meet again, bit for bit, in the attention partials att_ws)
+    return [eng.s_qkv.view(-1)[: nq * st(max(1, eng.n_qkv.value))], eng.att_ws.view(-1), eng.s_wo.view(-1)[: dim * st(eng.n_wo.value)],
             eng.h_mlp, eng.h_mask, eng.s_down.view(-1)[: dim * st(eng.n_down.value)], eng.resid[0], eng.resid[1], eng.gu]
     # (paired gate|up writes h_mlp / h_mask, unpaired writes the rounded gate|up vector; the other one stays constant)
 
@@ -96,8 +98,13 @@ def test_full_depth_graph_replay_soak():
             sgraphs = {"lean": capture(1, snap_hook), "general": capture(0, snap_hook)}
 
             # ---- plain graphs: everything that survives a step, against the first lean replay ---------------------
+            # (buffer 0, s_qkv, is written by the general kernel only — the lean wqkv launch rotates and appends in its
+            #  epilogue — so it is held against the general graph's own first replay; every other buffer against the lean one)
+            graphs["general"].replay()
+            gref0 = _bytes(_live(eng)[0]).clone()
             graphs["lean"].replay()
             ref = [_bytes(b).clone() for b in _live(eng)] + [_bytes(eng.logits).clone()]
+            ref[0] = gref0
             bad = torch.zeros(2, nbuf + 1, dtype=torch.int64, device=DEV)       # [graph][buffer] replays that differed
             first = torch.full((2,), -1, dtype=torch.int64, device=DEV)          # first differing replay per graph
             for it in range(PLAIN):
@@ -111,8 +118,11 @@ def test_full_depth_graph_replay_soak():
             plain_bad, plain_first = bad.cpu(), first.cpu()
 
             # ---- snapshot graphs: every layer's buffers, against the first lean snapshot replay ---------------------
+            sgraphs["general"].replay()
+            sref0 = snap[0].clone()
             sgraphs["lean"].replay()
             sref = [s.clone() for s in snap]
+            sref[0] = sref0
             sbad = torch.zeros(2, nbuf, n_layer, dtype=torch.int64, device=DEV)
             for it in range(SNAP):
                 for gi, name in enumerate(("lean", "general")):
@@ -127,6 +137,8 @@ def test_full_depth_graph_replay_soak():
                 if int(plain_bad[gi, j]):
                     report.append(f"{name} graph: {bn} differed in {int(plain_bad[gi, j])} of {PLAIN} replays (first at replay {int(plain_first[gi])})")
             for j, bn in enumerate(NAMES):
+                if name == "lean" and j == 0:
+                    continue  # the lean step never writes s_qkv (RoPE / KV append in the wqkv epilogue): nothing per layer to hold
                 layers = torch.nonzero(sbad[gi, j]).view(-1).tolist()
                 if layers:
                     report.append(f"{name} snapshot graph: {bn} differed first at layer {layers[0]} ({int(sbad[gi, j, layers[0]])} of {SNAP} replays; layers {layers[:8]})")
