@@ -194,6 +194,10 @@ typedef struct teal_gemv_in {
     int att_nsplit;           /* ATTN_MERGE: partials per head, 4 or 8 (0 = 4) */
     int slabs_interleaved;    /* RESID_NORM: slabs are [Z][(nslabs+3)&~3] (as written by a producer with
                                * slabs_interleaved = 1) instead of planar [nslabs][Z]; nslabs <= 8 */
+    int gate_activated;       /* SILU_MUL: the gate half already holds round(silu(gate)) — written by a launch with
+                               * act_seg0 = 1 — so x = round(gate * up): the same roundings as the unfused sequence
+                               * (model.py:258-259), the activation computed once per column instead of in every consumer
+                               * workgroup's prologue.  16-bit and int8 weights (not the int4 kernel) */
 } teal_gemv_in_t;
 
 typedef struct teal_gemv_out {
@@ -230,6 +234,9 @@ typedef struct teal_gemv_out {
     void* v_cache;
     int rope_head_dim;         /* 64 or 128 */
     int rope_max_seq;
+    int act_seg0;              /* TEAL_OUT_ROUNDED: y[0] = round(silu(round(sum))) for segment 0 (the gate projection of an
+                                * unpaired gate | up launch, model.py:258); the other segments are stored as usual.  16-bit
+                                * and int8 weights (not the int4 kernel) */
 } teal_gemv_out_t;
 
 /* One launch: [fused producer] -> mask + compaction -> gathered GEMV over every segment.

@@ -83,6 +83,7 @@ struct Layer {
 
 int main(int argc, char** argv) {
     int n_layer = 32, steps = 100, pos0 = 64, warm = 5, att_split = 0, pair = 1;
+    int gate_act = getenv("LB_GATEACT") ? atoi(getenv("LB_GATEACT")) : 1;  // silu in the gate tiles' epilogue (act_seg0)
     int use_rope = getenv("LB_ROPE") ? atoi(getenv("LB_ROPE")) : 1;  // RoPE + KV append in the qkv launch's epilogue (TEAL_OUT_QKV_ROPE)
     float sparsity = 0.5f;
     bool phase = false, dense = false, bf = false;
@@ -254,6 +255,7 @@ int main(int argc, char** argv) {
         } else {
             void* y[2] = {gu, gu + inter};
             teal_gemv_out_t o = mk_out(2, w, ld, c0, nc, tau, y, TEAL_OUT_ROUNDED, nullptr);
+            o.act_seg0 = gate_act;  // the gate tiles store silu(gate); down's producer only multiplies
             TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, nullptr, ls));
         }
     };
@@ -261,7 +263,7 @@ int main(int argc, char** argv) {
         Layer& l = Ls[i];
         teal_gemv_in_t in; memset(&in, 0, sizeof in);
         if (pair) { in.mode = TEAL_IN_MASKED; in.x = h_mlp; in.masks = h_mask; }
-        else { in.mode = TEAL_IN_SILU_MUL; in.x = gu; }
+        else { in.mode = TEAL_IN_SILU_MUL; in.x = gu; in.gate_activated = gate_act; }
         const void* w[1] = {l.w2}; const int ld[1] = {ldd}; const int c0[1] = {0}; const int nc[1] = {dim}; const float tau[1] = {td};
         teal_gemv_out_t o = mk_out(1, w, ld, c0, nc, tau, nullptr, TEAL_OUT_SLABS, s_down);
         apply_tune("down");
@@ -321,7 +323,7 @@ int main(int argc, char** argv) {
         } else {
             auto g = fetch16(gu, 2 * inter);
             std::vector<float> h(inter);
-            for (int j = 0; j < inter; ++j) { const float s = h2f(f2h(g[j] / (1.0f + expf(-g[j])), bf), bf); h[j] = h2f(f2h(s * g[inter + j], bf), bf); }
+            for (int j = 0; j < inter; ++j) { const float s = gate_act ? g[j] : h2f(f2h(g[j] / (1.0f + expf(-g[j])), bf), bf); h[j] = h2f(f2h(s * g[inter + j], bf), bf); }
             l.td = quantile_abs(h, sparsity);
         }
         k_down(i, l.td);
@@ -354,8 +356,9 @@ int main(int argc, char** argv) {
             k_attn(i, !fused_merge, l.to);
             TK(teal_set_fast(0)); k_wo(i, l.to); auto w0 = snap(s_wo, (size_t)((n_wo + 3) & ~3) * dim * 4);
             TK(teal_set_fast(1)); k_wo(i, l.to); cmp("wo slabs", w0, snap(s_wo, (size_t)((n_wo + 3) & ~3) * dim * 4));
-            TK(teal_set_fast(0)); k_gu(i, l.tg, l.td); auto h0 = snap(h_mlp, inter * 2); auto m0 = snap(h_mask, ((inter + 63) / 64) * 8); auto a0 = snap(A, dim * 2);
+            TK(teal_set_fast(0)); k_gu(i, l.tg, l.td); auto h0 = snap(h_mlp, inter * 2); auto m0 = snap(h_mask, ((inter + 63) / 64) * 8); auto a0 = snap(A, dim * 2); auto u0 = snap(gu, (size_t)2 * inter * 2);
             TK(teal_set_fast(1)); k_gu(i, l.tg, l.td); cmp("gate|up h", h0, snap(h_mlp, inter * 2)); cmp("gate|up masks", m0, snap(h_mask, ((inter + 63) / 64) * 8)); cmp("gate|up resid_out", a0, snap(A, dim * 2));
+            cmp("gate|up rounded (unpaired)", u0, snap(gu, (size_t)2 * inter * 2));
             TK(teal_set_fast(0)); k_down(i, l.td); auto d0 = snap(s_down, (size_t)((n_down + 3) & ~3) * dim * 4);
             TK(teal_set_fast(1)); k_down(i, l.td); cmp("down slabs", d0, snap(s_down, (size_t)((n_down + 3) & ~3) * dim * 4));
         }

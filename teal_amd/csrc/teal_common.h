@@ -48,6 +48,7 @@ struct InSpec {
     int slabs_il;              // mode 1: slabs are interleaved [Z][(nslabs + 3) & ~3] (one 16-byte load per element)
     const unsigned long long* masks;  // mode 3: keep masks (one per 64 activations) emitted by the producer
     float eps;
+    int gate_act;              // mode 2: the gate half already holds round(silu(gate)): x = round(gate * up)
 };
 
 struct Params {
@@ -75,6 +76,7 @@ struct Params {
     // TEAL_OUT_QKV_ROPE (lean kernel, split == 1): RoPE + KV-cache append in the epilogue; rope == nullptr otherwise
     const uint16_t* rope; const int* rope_pos; uint16_t* kc; uint16_t* vc;
     int rope_hd, rope_max_seq;
+    int act0;                   // rounded output of segment 0 goes through silu (and is rounded again)
     Seg seg[kMaxSeg];
 };
 
@@ -159,6 +161,13 @@ __device__ __forceinline__ uint16_t float_to_bits(float f) {
 // the qkv projection's epilogue (teal_gemv_fast.h, ROPE) and the attention launches must agree bit for bit.
 __device__ __forceinline__ float rope_even(float x0, float x1, float c, float s) { return fmaf(x0, c, -(x1 * s)); }
 __device__ __forceinline__ float rope_odd(float x0, float x1, float c, float s) { return fmaf(x1, c, x0 * s); }
+
+// round(silu(round(sum))): the gate projection's output with the activation applied where it is computed (model.py:258)
+template <bool BF16>
+__device__ __forceinline__ uint16_t silu_bits(const float sum) {
+    const float g16 = bits_to_float(float_to_bits<BF16>(sum), BF16);
+    return float_to_bits<BF16>(g16 / (1.0f + expf(-g16)));
+}
 
 // keep rule of the reference kernel: float32(|x|) > float32(tau)  (kernels/sparse_gemv.py:75)
 __device__ __forceinline__ bool keep_rule(float v, float tau) { return fabsf(v) > tau; }

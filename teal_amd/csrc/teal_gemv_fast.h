@@ -229,11 +229,17 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
         }
         TEAL_FAST_ARGS_BATCH(a);
         stamp(1);
+        if (a.gate_act) {  // the gate half went through silu in the gate | up launch's epilogue (act_seg0): once per column there,
+                           // instead of ~30 instructions per element in the prologue of every one of this launch's workgroups
+#pragma unroll
+            for (int k = 0; k < KR; ++k) xr[k] = float_to_bits<BF16>(bits_to_float(gb[k], BF16) * bits_to_float(ub[k], BF16));
+        } else {
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
             const float gt = bits_to_float(gb[k], BF16);
             const float sl = bits_to_float(float_to_bits<BF16>(gt / (1.0f + expf(-gt))), BF16);
             xr[k] = float_to_bits<BF16>(sl * bits_to_float(ub[k], BF16));
+        }
         }
     } else {
 #pragma unroll
@@ -490,6 +496,8 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
                     const uint32_t kvh = cc / hdm, d = cc & (hdm - 1u);
                     (isk ? a.kc : a.vc)[((size_t)kvh * (size_t)a.rope_max_seq + (size_t)rope_p) * hdm + d] = isk ? rb : b16;
                 }
+            } else if (a.act0 && s == 0) {  // the gate tiles of gate | up: activation applied here (model.py:258)
+                reinterpret_cast<uint16_t*>(a.y)[c] = silu_bits<BF16>(gs);
             } else {
                 reinterpret_cast<uint16_t*>(a.y)[c] = float_to_bits<BF16>(gs);
             }
@@ -519,7 +527,7 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
                 float sum = 0.0f;
                 for (int sl = 0; sl < split; ++sl)
                     sum += __hip_atomic_load(&a.ws[c * (uint32_t)a.ws_stride + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                reinterpret_cast<uint16_t*>(a.y)[c] = float_to_bits<BF16>(sum);
+                reinterpret_cast<uint16_t*>(a.y)[c] = (a.act0 && s == 0) ? silu_bits<BF16>(sum) : float_to_bits<BF16>(sum);
                 if (tid == 0) __hip_atomic_store(&a.ticket[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }

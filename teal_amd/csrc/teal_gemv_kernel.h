@@ -163,6 +163,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
             // silu(gate) * up with the roundings of the unfused fp16/bf16 sequence (model.py:258-259)
             const float gt = bits_to_float(x[m], BF16);
             const float up = bits_to_float(x[Z + m], BF16);
+            if (p.in.gate_act) return float_to_bits<BF16>(gt * up);  // the producer applied silu (act_seg0)
             const float sl = bits_to_float(float_to_bits<BF16>(gt / (1.0f + expf(-gt))), BF16);
             return float_to_bits<BF16>(sl * up);
         } else {
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         for (int k = 0; k < KR; ++k) {
             const int m = (chunk_of(k) << 6) + lane;
             const float gt = bits_to_float(gb[k], BF16);
-            const float sl = bits_to_float(float_to_bits<BF16>(gt / (1.0f + expf(-gt))), BF16);
+            const float sl = p.in.gate_act ? gt : bits_to_float(float_to_bits<BF16>(gt / (1.0f + expf(-gt))), BF16);
             xr[k] = (m < Z) ? (uint32_t)float_to_bits<BF16>(sl * bits_to_float(ub[k], BF16)) : 0u;
         }
     } else {
@@ -663,7 +664,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
             for (int wv = 0; wv < WAVES; ++wv) sum += red[wv * BN + t];
             if constexpr (W8) sum = (sum - bias) * bits_to_float(scb, BF16);  // t == tid: BN <= T, one pass
             if (p.split == 1 && !p.to_ws) {
-                reinterpret_cast<uint16_t*>(sg.y)[c] = float_to_bits<BF16>(sum);
+                reinterpret_cast<uint16_t*>(sg.y)[c] = (p.act0 && s == 0) ? silu_bits<BF16>(sum) : float_to_bits<BF16>(sum);
             } else if (p.ws_il) {
                 p.ws[(size_t)(sg.ws_off + c) * ((p.split + 3) & ~3) + slice] = sum;
             } else {

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Params p) {
     if (p.nseg > 2 && n >= p.seg[2].ws_off) s = 2;
     float sum = 0.0f;
     for (int k = 0; k < p.split; ++k) sum += p.ws[(size_t)k * p.ws_ld + n];
-    reinterpret_cast<uint16_t*>(p.seg[s].y)[n - p.seg[s].ws_off] = float_to_bits<BF16>(sum);
+    reinterpret_cast<uint16_t*>(p.seg[s].y)[n - p.seg[s].ws_off] = (p.act0 && s == 0) ? silu_bits<BF16>(sum) : float_to_bits<BF16>(sum);
 }
 
 // h[n] = silu(gate[n]) * up[n] from the fp32 slabs of a 2-segment (gate | up) GEMV.
@@ -326,6 +326,8 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
     f.a.seg_tile1 = (!p.pair && p.nseg > 1) ? p.seg[1].tile0 : INT_MAX;
     f.a.seg_tile2 = (!p.pair && p.nseg > 2) ? p.seg[2].tile0 : INT_MAX;
     f.a.exp = g_exp;
+    f.a.act0 = p.act0;
+    f.a.gate_act = p.in.gate_act;
     f.a.ws_stride = (to_ws || ticketed) ? ((c.split + 3) & ~3) : 0;
     f.a.ticket = ticketed ? p.tickets : nullptr;
     if (p.rope) {  // RoPE + KV append epilogue: one rounded q|k|v vector, no split-K, tiles inside one head
@@ -776,7 +778,11 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
     if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
     if (Z > 65536) return TEAL_ERR_SHAPE;
     if (!device_ctx()) return TEAL_ERR_NO_DEVICE;
-    if (out->weight_bits == 4) return fused_gemv_i4(in, out, Z, dtype, ws, ws_bytes, nslabs_out, reinterpret_cast<hipStream_t>(stream));
+    if (out->act_seg0 && out->mode != TEAL_OUT_ROUNDED) return TEAL_ERR_ARG;
+    if (out->weight_bits == 4) {
+        if (out->act_seg0 || in->gate_activated || out->mode == TEAL_OUT_QKV_ROPE) return TEAL_ERR_ARG;  // 16-bit / int8 launches only
+        return fused_gemv_i4(in, out, Z, dtype, ws, ws_bytes, nslabs_out, reinterpret_cast<hipStream_t>(stream));
+    }
     Params p = {};
     p.Z = Z;
     p.in.mode = in->mode;
@@ -785,6 +791,7 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
         case TEAL_IN_SILU_MUL:
             if (!in->x) return TEAL_ERR_ARG;
             p.x = in->x;
+            p.in.gate_act = (in->mode == TEAL_IN_SILU_MUL && in->gate_activated) ? 1 : 0;
             break;
         case TEAL_IN_ATTN_MERGE:
             if (!in->x || (in->att_head_dim != 64 && in->att_head_dim != 128) || Z % in->att_head_dim ||
@@ -848,6 +855,7 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
         rc = run_gemv(p, dtype, out->slabs, out->slabs_bytes, true, st, &used, true, out->slabs_interleaved != 0, false);
         if (rc == TEAL_OK && out->slabs_interleaved && !p.ws_il) return TEAL_ERR_CONFIG;  // > 8 slices cannot interleave
     } else if (out->mode == TEAL_OUT_ROUNDED) {
+        p.act0 = out->act_seg0 ? 1 : 0;
         rc = run_gemv(p, dtype, ws, ws_bytes, false, st, &used, false);
     } else if (out->mode == TEAL_OUT_QKV_ROPE) {
         if (out->nseg != 3 || in->mode != TEAL_IN_RESID_NORM || !out->y[0] || !out->rope || !out->rope_pos || !out->k_cache ||

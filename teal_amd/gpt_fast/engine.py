@@ -39,7 +39,7 @@ class GemvIn(ctypes.Structure):  # teal_gemv_in_t
                 ("row_index", ctypes.c_void_p), ("slabs", ctypes.c_void_p), ("nslabs", ctypes.c_int),
                 ("norm_weight", ctypes.c_void_p), ("eps", ctypes.c_float), ("resid_out", ctypes.c_void_p),
                 ("masks", ctypes.c_void_p), ("att_head_dim", ctypes.c_int), ("att_nsplit", ctypes.c_int),
-                ("slabs_interleaved", ctypes.c_int)]
+                ("slabs_interleaved", ctypes.c_int), ("gate_activated", ctypes.c_int)]
 
 
 class GemvOut(ctypes.Structure):  # teal_gemv_out_t
@@ -50,7 +50,7 @@ class GemvOut(ctypes.Structure):  # teal_gemv_out_t
                 ("slabs_interleaved", ctypes.c_int), ("weight_bits", ctypes.c_int), ("scale", ctypes.c_void_p * 3),
                 ("scale_ld", ctypes.c_int * 3), ("groupsize", ctypes.c_int),
                 ("rope", ctypes.c_void_p), ("rope_pos", ctypes.c_void_p), ("k_cache", ctypes.c_void_p), ("v_cache", ctypes.c_void_p),
-                ("rope_head_dim", ctypes.c_int), ("rope_max_seq", ctypes.c_int)]
+                ("rope_head_dim", ctypes.c_int), ("rope_max_seq", ctypes.c_int), ("act_seg0", ctypes.c_int)]
 
 
 def _out(segs, mode, slabs: Optional[torch.Tensor] = None) -> GemvOut:
@@ -177,6 +177,7 @@ class DecodeEngine:
             # on Llama-2-70B (layer_bench LB_PAIRAB, profiles/r03_layer_experiments.txt)
             pair = inter * 3 >= 128 * int(self.L.teal_init()) * 2
         self.pair = bool(pair) and can_pair
+        self.gate_act = False  # (set by _build: unpaired 16-bit / int8 gate | up stores silu(gate) | up)
         self.s_wo, self.s_down = e(MAX_SLABS, dim, dtype=torch.float32), e(MAX_SLABS, dim, dtype=torch.float32)
         self.s_qkv = e(8, self.nqkv, dtype=torch.float32)  # wqkv split-K slabs, summed by the attention launch
         self.logits = e(1, 1, cfg.vocab_size)
@@ -280,7 +281,12 @@ class DecodeEngine:
                 k4_out.mask_tau = th["down"]
                 k5_in = GemvIn(mode=TEAL_IN_MASKED, x=self.h_mlp.data_ptr(), masks=self.h_mask.data_ptr())
             else:
-                k5_in = GemvIn(mode=TEAL_IN_SILU_MUL, x=self.gu.data_ptr())
+                # unpaired: the gate tiles apply silu in their epilogue (act_seg0: once per column, by the two waves that
+                # reduce the tile) and down's producer only multiplies — the activation out of the prologue of each of
+                # down's 256 workgroups: -0.6 % per token on Llama-2-7B @ 50 % (profiles/r04_layer_experiments.txt)
+                self.gate_act = not self.int4
+                k4_out.act_seg0 = 1 if self.gate_act else 0
+                k5_in = GemvIn(mode=TEAL_IN_SILU_MUL, x=self.gu.data_ptr(), gate_activated=1 if self.gate_act else 0)
             k5_out = _out([seg(ff.w2, 0, dim, th["down"], None)], TEAL_OUT_SLABS, self.s_down)
             kc, vc = at.kv_cache.k_cache, at.kv_cache.v_cache
             assert kc.is_contiguous() and kc.shape[0] == 1 and kc.shape[2] == self.max_seq
@@ -421,7 +427,8 @@ class DecodeEngine:
                     out[i]["mlp_mid"] = self.h_mlp.float().abs().clone()
                 else:
                     g, u = self.gu[:inter].float(), self.gu[inter:]
-                    out[i]["mlp_mid"] = (torch.nn.functional.silu(g).to(dt) * u).float().abs()
+                    sg = self.gu[:inter] if self.gate_act else torch.nn.functional.silu(g).to(dt)  # (act_seg0: silu already applied)
+                    out[i]["mlp_mid"] = (sg * u).float().abs()
 
         self(idx, input_pos, hook=hook)
         return out

@@ -263,9 +263,18 @@ def test_engine_launches_vs_oracle_under_sparsity(oracle, name, tdt, sparsity, n
                 gub = bits_from_torch(eng.gu)
                 for nm, wk, t, sl in (("gate", "gate", seen["tg"], slice(0, inter)), ("up", "up", seen["tu"], slice(inter, 2 * inter))):
                     truth = O.truth64(seen["x2"], W[wk], dim, inter, t, dtype=dtype)
+                    tol = tolerance(O, truth, dtype)
+                    if nm == "gate" and eng.gate_act:
+                        # act_seg0: the gate tiles store round(silu(round(gate))) (model.py:258); |d silu / d g| <= 1.0998
+                        truth, tol = truth / (1.0 + np.exp(-truth)), 1.1 * tol
+                        tol = tol + O.ulp16(truth, dtype) + 1e-7
                     err = np.abs(O.from_bits(gub[sl], dtype) - truth)
-                    assert (err <= tolerance(O, truth, dtype)).all(), (nm, float(err.max()))
-                hv = _silu_mul_variants(O, gub, inter, dtype)
+                    assert (err <= tol).all(), (nm, float(err.max()))
+                if eng.gate_act:  # down's producer only multiplies: a product of two 16-bit values is exact in fp32, one rounding
+                    sgf = O.from_bits(gub[:inter], dtype).astype(np.float32)
+                    hv = [O.to_bits((sgf * O.from_bits(gub[inter:], dtype).astype(np.float32)).astype(np.float32), dtype)]
+                else:
+                    hv = _silu_mul_variants(O, gub, inter, dtype)
                 seen["hb"] = hv[0]
                 seen["td"] = _safe_tau(O, hv, sparsity, dtype)
                 k5_out.tau[0] = seen["td"]
