@@ -63,6 +63,9 @@ def parse():
                     "for long-context experiments; 0 = the reference's value (2048 for 7B)")
     ap.add_argument("--experiment", type=int, default=0, help="teal_set_experiment mask (A/B switches, include/teal_hip.h; 0 = production)")
     ap.add_argument("--wave-local", type=int, default=1, help="wave-local compaction (A/B switch)")
+    ap.add_argument("--profile-markers", action="store_true",
+                    help="bracket the timed region with one marker dispatch each (compact_kernel on 64 elements) so that "
+                         "scripts/summarize_prof.py can restrict a rocprofv3 trace / counter pass to the timed hipGraph replays")
     return ap.parse_args()
 
 
@@ -96,11 +99,28 @@ def barrier(world):
         dist.barrier()
 
 
-def timed_decode(step_fn, steps, warmup, world):
+_MARK = {}
+
+
+def profile_marker():
+    """one dispatch with a name nothing else in a decode step uses (compact_kernel): rocprofv3 traces of this command are cut
+    at these dispatches (scripts/summarize_prof.py) — outside the timed region, between the synchronisations"""
+    from teal_amd import _lib, runtime
+    if not _MARK:
+        _MARK["x"] = torch.zeros(64, device="cuda", dtype=torch.float16)
+        _MARK["idx"] = torch.zeros(64, device="cuda", dtype=torch.int32)
+        _MARK["n"] = torch.zeros(1, device="cuda", dtype=torch.int32)
+    _lib.load().teal_compact(_MARK["x"].data_ptr(), 0.5, 64, 0, _MARK["idx"].data_ptr(), _MARK["n"].data_ptr(), runtime.stream_ptr())
+    _sync()
+
+
+def timed_decode(step_fn, steps, warmup, world, markers=False):
     """W untimed steps, then exactly K steps between barrier+synchronize on both sides."""
     for _ in range(warmup):
         step_fn()
     _sync()
+    if markers:
+        profile_marker()
     barrier(world)
     _sync()
     t0 = time.perf_counter()
@@ -109,6 +129,8 @@ def timed_decode(step_fn, steps, warmup, world):
     _sync()
     barrier(world)
     t = time.perf_counter() - t0
+    if markers:
+        profile_marker()
     if world > 1:  # the job's time is the slowest replica's
         import torch.distributed as dist
         tt = torch.tensor([t], device="cuda" if torch.cuda.is_available() else "cpu", dtype=torch.float64)
@@ -443,7 +465,7 @@ def main():
         step, info = make_engine_stepper(model, a)
     else:
         step, info = make_stepper(model, a)
-    t = timed_decode(step, a.steps, a.warmup, world)
+    t = timed_decode(step, a.steps, a.warmup, world, markers=a.profile_markers)
     tps = aggregate_tokens_per_sec(world, a.steps, t)
     out = {"metric": "decode tokens/sec (bs=1), Llama-2-7B fp16 @50% activation sparsity", "value": tps, "unit": "tokens/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": t / a.steps * 1e3,
@@ -513,10 +535,14 @@ def main():
                 a_c = argparse.Namespace(**vars(a))
                 a_c.prompt_tokens, a_c.steps, a_c.warmup = ctx, min(a.steps, 60), min(a.warmup, 10)
                 model.config.block_size = max(model.config.block_size, 4096 if ctx > 1900 else 2048)
-                cstep, _ = make_engine_stepper(model, a_c, ths=info["thresholds"])
+                cstep, cinfo = make_engine_stepper(model, a_c, ths=info["thresholds"])
                 tc = timed_decode(cstep, a_c.steps, a_c.warmup, 1)
                 out["value_at_context"][str(ctx)] = a_c.steps / tc
-                del cstep
+                # the kept fractions ON THOSE positions (the o projection's input shrinks with the context on synthetic weights;
+                # thresholds were re-taken on the timed range of this context)
+                out.setdefault("kept_fraction_at_context", {})[str(ctx)] = {
+                    k: round(v, 4) for k, v in cinfo["engine"].mean_kept_fractions(cinfo["first_token"], cinfo["pos0"], cinfo["span"], 2).items()}
+                del cstep, cinfo
                 torch.cuda.empty_cache()
             out["value_at_context_note"] = ("tokens/s of the same decode step with ~1000 / ~3800 cached positions (block_size raised to "
                                             "4096 for the latter); `value` is the reference's default 6-token prompt")
