@@ -467,7 +467,8 @@ def main():
         step, info = make_stepper(model, a)
     t = timed_decode(step, a.steps, a.warmup, world, markers=a.profile_markers)
     tps = aggregate_tokens_per_sec(world, a.steps, t)
-    out = {"metric": "decode tokens/sec (bs=1), Llama-2-7B fp16 @50% activation sparsity", "value": tps, "unit": "tokens/s",
+    mname = {"7B": "Llama-2-7B", "13B": "Llama-2-13B", "70B": "Llama-2-70B", "llama-3-8b": "Llama-3-8B"}.get(a.model, a.model)
+    out = {"metric": f"decode tokens/sec (bs=1), {mname} {a.precision} @{a.sparsity:.0%} activation sparsity", "value": tps, "unit": "tokens/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": t / a.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if dt == torch.float16 else "bf16",
            "data": "synthetic (random-init weights at exact shapes, random token ids, thresholds calibrated to the kept fraction)",
@@ -476,11 +477,11 @@ def main():
                       "mode": mode, "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
                       "prompt_tokens": a.prompt_tokens, "context_positions": f"{a.prompt_tokens}..{a.prompt_tokens + a.warmup + a.steps}"}}
     if a.weights == "int8":
-        out["metric"] = out["metric"].replace("fp16", "int8-weight/fp16-activation")
+        out["metric"] = out["metric"].replace(a.precision, f"int8-weight/{a.precision}-activation")
         out["dtype"] = out["dtype"] + " activations, int8 weights (per-channel scales)"
         out["config"]["workload"] += ", int8 weight-only"
     if a.weights == "int4":
-        out["metric"] = out["metric"].replace("fp16", "int4-g32-weight/fp16-activation")
+        out["metric"] = out["metric"].replace(a.precision, f"int4-g32-weight/{a.precision}-activation")
         out["dtype"] = out["dtype"] + " activations, int4 group-quantised weights (g32), 16-bit lm_head"
         out["config"]["workload"] += ", int4 group-quantised projections (g32), 16-bit lm_head"
     out.update(info.get("report", {}))
