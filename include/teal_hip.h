@@ -234,12 +234,6 @@ typedef struct teal_gemv_out {
     void* v_cache;
     int rope_head_dim;         /* 64 or 128 */
     int rope_max_seq;
-    const void* resid_add;     /* TEAL_OUT_ROUNDED, one segment, lean kernel only (TEAL_ERR_CONFIG otherwise): y = round(resid_add +
-                                * round(sum)), the residual add of model.py:158-161 done by the projection itself (split-K: by the
-                                * last slice of a tile to arrive) so that the consumer's RESID_NORM producer reads one 16-bit vector
-                                * instead of residual + slabs.  MEASURED SLOWER than the slab hand-over on Llama-2-7B (the arrival
-                                * ticket sits behind the slowest workgroup of wo / down): profiles/r04_layer_experiments.txt; the
-                                * decode engine does not use it */
     int act_seg0;              /* TEAL_OUT_ROUNDED: y[0] = round(silu(round(sum))) for segment 0 (the gate projection of an
                                 * unpaired gate | up launch, model.py:258); the other segments are stored as usual.  16-bit
                                 * and int8 weights (not the int4 kernel) */

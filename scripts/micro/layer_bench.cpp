@@ -84,7 +84,6 @@ struct Layer {
 int main(int argc, char** argv) {
     int n_layer = 32, steps = 100, pos0 = 64, warm = 5, att_split = 0, pair = 1;
     int gate_act = getenv("LB_GATEACT") ? atoi(getenv("LB_GATEACT")) : 1;  // silu in the gate tiles' epilogue (act_seg0)
-    int slim = getenv("LB_SLIM") ? atoi(getenv("LB_SLIM")) : 0;  // verdict lever (a): wo / down add the residual themselves (tickets), consumers read h only
     int use_rope = getenv("LB_ROPE") ? atoi(getenv("LB_ROPE")) : 1;  // RoPE + KV append in the qkv launch's epilogue (TEAL_OUT_QKV_ROPE)
     float sparsity = 0.5f;
     bool phase = false, dense = false, bf = false;
@@ -209,7 +208,6 @@ int main(int argc, char** argv) {
         in.mode = TEAL_IN_RESID_NORM; in.resid_in = i == 0 ? (const void*)emb : (const void*)A; in.row_index = i == 0 ? tok : nullptr;
         in.slabs = i == 0 ? nullptr : s_down; in.nslabs = i == 0 ? 0 : n_down; in.slabs_interleaved = 1;
         in.norm_weight = l.norm1; in.eps = eps; in.resid_out = B;
-        if (slim && i > 0) { in.resid_in = B; in.slabs = nullptr; in.nslabs = 0; in.resid_out = nullptr; }  // down left h in B
         const void* w[3] = {l.wqkv, l.wqkv, l.wqkv}; const int ld[3] = {ldq, ldq, ldq}; const int c0[3] = {0, dim, dim + kv};
         const int nc[3] = {dim, kv, kv}; const float tau[3] = {tq, tq, tq};
         teal_gemv_out_t o = mk_out(3, w, ld, c0, nc, tau, nullptr, TEAL_OUT_SLABS, s_qkv);
@@ -238,7 +236,6 @@ int main(int argc, char** argv) {
         else { in.mode = TEAL_IN_MASKED; in.x = y_attn; in.masks = y_mask; }
         const void* w[1] = {l.wo}; const int ld[1] = {ldo}; const int c0[1] = {0}; const int nc[1] = {dim}; const float tau[1] = {to};
         teal_gemv_out_t o = mk_out(1, w, ld, c0, nc, tau, nullptr, TEAL_OUT_SLABS, s_wo);
-        if (slim) { o.mode = TEAL_OUT_ROUNDED; o.slabs = nullptr; o.y[0] = A; o.resid_add = B; }  // A = B + wo(y), by the last slice of a tile
         apply_tune("wo");
         TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, &n_wo, ls));
     };
@@ -247,7 +244,6 @@ int main(int argc, char** argv) {
         teal_gemv_in_t in; memset(&in, 0, sizeof in);
         in.mode = TEAL_IN_RESID_NORM; in.resid_in = B; in.slabs = s_wo; in.nslabs = n_wo; in.slabs_interleaved = 1;
         in.norm_weight = l.norm2; in.eps = eps; in.resid_out = A;
-        if (slim) { in.resid_in = A; in.slabs = nullptr; in.nslabs = 0; in.resid_out = nullptr; }
         const void* w[2] = {l.w1, l.w3}; const int ld[2] = {ldi, ldi}; const int c0[2] = {0, 0}; const int nc[2] = {inter, inter};
         const float tau[2] = {tg, tg};
         apply_tune("gu");
@@ -270,7 +266,6 @@ int main(int argc, char** argv) {
         else { in.mode = TEAL_IN_SILU_MUL; in.x = gu; in.gate_activated = gate_act; }
         const void* w[1] = {l.w2}; const int ld[1] = {ldd}; const int c0[1] = {0}; const int nc[1] = {dim}; const float tau[1] = {td};
         teal_gemv_out_t o = mk_out(1, w, ld, c0, nc, tau, nullptr, TEAL_OUT_SLABS, s_down);
-        if (slim) { o.mode = TEAL_OUT_ROUNDED; o.slabs = nullptr; o.y[0] = B; o.resid_add = A; }
         apply_tune("down");
         TK(teal_fused_gemv(&in, &o, inter, dt, ws, ws_bytes, &n_down, ls));
     };
@@ -278,7 +273,6 @@ int main(int argc, char** argv) {
         teal_gemv_in_t in; memset(&in, 0, sizeof in);
         in.mode = TEAL_IN_RESID_NORM; in.resid_in = A; in.slabs = s_down; in.nslabs = n_down; in.slabs_interleaved = 1;
         in.norm_weight = normf; in.eps = eps; in.resid_out = nullptr;
-        if (slim) { in.resid_in = B; in.slabs = nullptr; in.nslabs = 0; }
         const void* w[1] = {wout}; const int ld[1] = {ldv}; const int c0[1] = {0}; const int nc[1] = {S.vocab}; const float tau[1] = {NEG};
         void* y[1] = {logits};
         teal_gemv_out_t o = mk_out(1, w, ld, c0, nc, tau, y, TEAL_OUT_ROUNDED, nullptr);
@@ -481,23 +475,6 @@ int main(int argc, char** argv) {
             const double ta = time_graph(g1, steps, true), tb = time_graph(ge2, steps, true);
             printf("  two-queue bound round %d: one stream %.1f us (%.2f/layer)   two streams, no dependencies %.1f us (%.2f/layer)\n", r, ta, ta / n_layer, tb, tb / n_layer);
         }
-        return 0;
-    }
-    if (getenv("LB_SLIMAB")) {
-        // verdict lever (a): slab hand-over (every consumer workgroup sums residual + slabs) vs residual-adding projections
-        // (arrival tickets in wo / down, consumers read one 16-bit vector)
-        const int s0 = slim;
-        slim = 0; token_step(); CK(hipStreamSynchronize(st)); hipGraphExec_t ga = capture(token_step);
-        slim = 1; token_step(); CK(hipStreamSynchronize(st)); hipGraphExec_t gb = capture(token_step);
-        slim = s0;
-        double sa = 0, sb = 0; const int rounds = 6;
-        for (int r = 0; r < rounds; ++r) {
-            const double ta = time_graph(ga, steps, true), tb = time_graph(gb, steps, true);
-            printf("  slim A/B round %d: slabs %.1f us  residual-adding projections %.1f us\n", r, ta, tb);
-            if (r) { sa += ta; sb += tb; }
-        }
-        printf("slim A/B mean (rounds 1..): slabs %.1f us/token, residual-adding projections %.1f us/token  -> %+.2f %%\n", sa / (rounds - 1),
-               sb / (rounds - 1), (sb / sa - 1.0) * 100.0);
         return 0;
     }
     if (getenv("LB_ROPEAB")) {

@@ -77,7 +77,6 @@ struct Params {
     const uint16_t* rope; const int* rope_pos; uint16_t* kc; uint16_t* vc;
     int rope_hd, rope_max_seq;
     int act0;                   // rounded output of segment 0 goes through silu (and is rounded again)
-    const uint16_t* resid_add;  // rounded output: y = round(resid_add + round(sum)); lean kernel only
     Seg seg[kMaxSeg];
 };
 

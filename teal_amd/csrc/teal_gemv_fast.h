@@ -498,9 +498,6 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
                 }
             } else if (a.act0 && s == 0) {  // the gate tiles of gate | up: activation applied here (model.py:258)
                 reinterpret_cast<uint16_t*>(a.y)[c] = silu_bits<BF16>(gs);
-            } else if (a.resid_add) {
-                const float yv = bits_to_float(float_to_bits<BF16>(gs), BF16);
-                reinterpret_cast<uint16_t*>(a.y)[c] = float_to_bits<BF16>(bits_to_float(a.resid_add[c], BF16) + yv);
             } else {
                 reinterpret_cast<uint16_t*>(a.y)[c] = float_to_bits<BF16>(gs);
             }
@@ -530,9 +527,7 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
                 float sum = 0.0f;
                 for (int sl = 0; sl < split; ++sl)
                     sum += __hip_atomic_load(&a.ws[c * (uint32_t)a.ws_stride + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                uint16_t ob = (a.act0 && s == 0) ? silu_bits<BF16>(sum) : float_to_bits<BF16>(sum);
-                if (a.resid_add) ob = float_to_bits<BF16>(bits_to_float(a.resid_add[c], BF16) + bits_to_float(ob, BF16));
-                reinterpret_cast<uint16_t*>(a.y)[c] = ob;
+                reinterpret_cast<uint16_t*>(a.y)[c] = (a.act0 && s == 0) ? silu_bits<BF16>(sum) : float_to_bits<BF16>(sum);
                 if (tid == 0) __hip_atomic_store(&a.ticket[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }

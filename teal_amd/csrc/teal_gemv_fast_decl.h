@@ -32,7 +32,6 @@ struct FastArgs {
     uint16_t* kc;                   // K cache [n_kv_head][max_seq][head_dim]
     uint16_t* vc;                   // V cache
     int rope_hd, rope_dim, rope_kv, rope_max_seq;  // head_dim, n_head * head_dim, n_kv_head * head_dim, cache rows
-    const uint16_t* resid_add;      // rounded output: y = round(resid_add + round(sum)) (residual add folded into the projection)
     int act0;                       // rounded output of threshold segment 0 goes through silu (the gate of gate | up)
     int gate_act;                   // MODE 2: the gate half already holds round(silu(gate))
 };

@@ -327,7 +327,6 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
     f.a.seg_tile2 = (!p.pair && p.nseg > 2) ? p.seg[2].tile0 : INT_MAX;
     f.a.exp = g_exp;
     f.a.act0 = p.act0;
-    f.a.resid_add = p.resid_add;
     f.a.gate_act = p.in.gate_act;
     f.a.ws_stride = (to_ws || ticketed) ? ((c.split + 3) & ~3) : 0;
     f.a.ticket = ticketed ? p.tickets : nullptr;
@@ -495,7 +494,6 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
     {
         FastLaunch f;
         const bool lean = fast_eligible(p, c, to_ws, ws_bytes, f);
-        if (p.resid_add && !lean) return TEAL_ERR_CONFIG;  // the residual-adding output exists in the lean kernel only
         if (p.rope && !lean) return TEAL_ERR_CONFIG;  // the RoPE epilogue exists in the lean kernel only: never fall through unrotated
         if (lean) {
             g_rope_taken = f.a.rope != nullptr;
@@ -858,8 +856,6 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
         if (rc == TEAL_OK && out->slabs_interleaved && !p.ws_il) return TEAL_ERR_CONFIG;  // > 8 slices cannot interleave
     } else if (out->mode == TEAL_OUT_ROUNDED) {
         p.act0 = out->act_seg0 ? 1 : 0;
-        if (out->resid_add && out->nseg != 1) return TEAL_ERR_ARG;
-        p.resid_add = reinterpret_cast<const uint16_t*>(out->resid_add);
         rc = run_gemv(p, dtype, ws, ws_bytes, false, st, &used, false);
     } else if (out->mode == TEAL_OUT_QKV_ROPE) {
         if (out->nseg != 3 || in->mode != TEAL_IN_RESID_NORM || !out->y[0] || !out->rope || !out->rope_pos || !out->k_cache ||
