@@ -431,6 +431,16 @@ def main(args) -> Dict:
         from teal_amd.gpt_fast.tokenizer import get_tokenizer
         tokenizer = get_tokenizer(args.checkpoint_path.parent / "tokenizer.model", args.checkpoint_path)
         prompt = torch.tensor([tokenizer.bos_id()] + tokenizer.encode(args.prompt), dtype=torch.int, device=device)
+    # tensor parallelism as in the reference (gpt-fast/generate.py:285-289, tp.py): one process per GPU under
+    # torch.distributed.run; a single process (the north-star configuration) is untouched
+    from teal_amd.gpt_fast import tp
+    tp_rank = tp.maybe_init_dist()
+    if tp_rank is not None:
+        tp.apply_tp(model)  # wqkv / w1 / w3 column-wise, wo / w2 row-wise, one all-reduce per attention and per MLP
+        args.engine = False
+        if tp_rank != 0:
+            import builtins
+            builtins.print = lambda *a, **k: None  # rank 0 reports (tp.py's `print` override)
     thresholds = None
     if not args.dense and (args.hist_path is not None or args.synthetic):
         # like the reference, patching is gated on hist_path, not on sparsity (generate.py:328)
@@ -444,7 +454,8 @@ def main(args) -> Dict:
     torch.manual_seed(1234)
     model_size = _get_model_size(model)
     decoder = GraphedDecoder(model, args.compile, args.temperature, args.top_k)
-    use_engine = args.engine or (args.compile and thresholds is not None and not getattr(args, "no_engine", False))
+    use_engine = args.engine or (args.compile and thresholds is not None and not getattr(args, "no_engine", False)
+                                 and tp_rank is None)  # the fused single-GPU step does not span ranks
     if use_engine and not args.engine:
         # --compile implies the device-resident engine loop only for models the fused step can run (int4 blocks, head_dim 48,
         # ... decode through the patched modules under the same hipGraph capture instead)
