@@ -147,10 +147,10 @@ __device__ __forceinline__ float bits_to_float(uint32_t b16, bool bf16) {
 template <bool BF16>
 __device__ __forceinline__ uint16_t float_to_bits(float f) {
     if (BF16) {
-        uint32_t u = __float_as_uint(f);
-        if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
-        u += 0x7FFFu + ((u >> 16) & 1u);
-        return (uint16_t)(u >> 16);
+        // gfx950 converts in hardware (v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN): one instruction where the
+        // integer form (add 0x7FFF + lsb, shift, NaN test) took six — the RMSNorm producer rounds four times per element
+        // (profiles/r04_layer_phase_timing_8b_bf16.txt: "x ready" 1.75 us against 1.05 us in fp16 before this)
+        return __builtin_bit_cast(uint16_t, (__bf16)f);
     }
     _Float16 h = (_Float16)f;  // v_cvt_f16_f32, round-to-nearest-even
     return __builtin_bit_cast(uint16_t, h);

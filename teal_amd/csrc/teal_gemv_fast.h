@@ -550,12 +550,10 @@ template <bool BF16, int MODE, bool PAIR, int LPR, int KR, bool EXACT, bool W8 =
 hipError_t launch_fast_e(const FastLaunch& f, hipStream_t st) {
     const dim3 grid(f.ntiles, f.split), block(1024);
     if constexpr (!W8) {
-        if (f.a.phase) {
-            if constexpr (!BF16) {  // stamped instantiations exist for fp16 only (diagnostics)
-                hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, true>), grid, block, f.lds, st, f.in0, f.in1,
-                                   f.in2, f.row_index, f.Z, f.nslabs, f.eps, f.a);
-                return hipGetLastError();
-            }
+        if (f.a.phase) {  // stamped instantiations (diagnostics: teal_set_phase_buffer), both activation dtypes
+            hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, true>), grid, block, f.lds, st, f.in0, f.in1,
+                               f.in2, f.row_index, f.Z, f.nslabs, f.eps, f.a);
+            return hipGetLastError();
         }
     }
     if constexpr (MODE == 1 && !PAIR && !W8) {
