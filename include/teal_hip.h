@@ -87,8 +87,10 @@ size_t teal_workspace_bytes(int Z, int N);
  * rounded output run as ONE launch (per-tile arrival tickets; the last slice to arrive sums the partials in slice
  * order) and a large-vocabulary sampler as several workgroups; every launch re-arms what it used, so a graph that was
  * captured with the workspace can be replayed indefinitely.  An unprepared workspace (plain memory of
- * teal_workspace_bytes) is still valid everywhere: the same results from GEMV + ordered reduce launch / a
- * single-workgroup sampler.  If a launch is aborted (device reset), prepare again.  teal_workspace_release() forgets the
+ * teal_workspace_bytes) is still valid everywhere: 16-bit weights give the SAME bits from GEMV + ordered reduce launch (the
+ * same slices summed in the same order) and the sampler the same tokens from a single workgroup; int8 / int4 weights pick
+ * their split-K factor by whether tickets are available, so there the two ways agree to the tolerance of the fp32
+ * summation order (one ulp of the 16-bit output), not bit for bit.  If a launch is aborted (device reset), prepare again.  teal_workspace_release() forgets the
  * pointer; call it before freeing the memory. */
 int teal_workspace_init(void* ws, size_t ws_bytes, void* stream);
 int teal_workspace_release(void* ws);

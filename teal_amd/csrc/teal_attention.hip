@@ -231,7 +231,7 @@ __device__ __forceinline__ void merge_head(const float* __restrict__ p, uint16_t
                 const float ls = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lf), s0 + u));
                 if (ls > 0.0f) {
                     L += ls;
-                    O += v[u] * fs;
+                    O = fmaf(v[u], fs, O);  // explicit (not left to -ffp-contract): the merge launch must round like this everywhere
                 }
             }
         }

@@ -31,6 +31,11 @@
 #include "teal_common.h"
 
 #include <limits.h>
+
+// Same rule as the 16-bit GEMV units (teal_gemv_kernel.h): no implicit contraction — every fused multiply-add below is an
+// explicit fmaf(), so the slab path and the rounded path, and this unit against the merge producers elsewhere, cannot drift
+// by an ulp when the compiler changes its mind.
+#pragma clang fp contract(off)
 #include <stdio.h>
 
 namespace teal {
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(1024) void sparse_gemv_int4_kernel(const I4Args a) 
             if constexpr (BF16) t = A[k] - 136.0f * X;                         // (128 + q) - 136
             else if (k & 1) t = fmaf(A[k], 0.0625f, -72.0f * X);               // ((1024 + 16 q) - 1024) / 16 - 8
             else t = A[k] - 1032.0f * X;                                       // (1024 + q) - 1032
-            total[k] += sc * t + zr * X;
+            total[k] += fmaf(sc, t, zr * X);
         }
     };
     // unit u belongs to slice u % split, and inside the slice to wave (u / split) % 16

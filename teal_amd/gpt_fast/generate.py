@@ -168,7 +168,6 @@ def refine_thresholds_on_decode(model: Transformer, sparsities: Dict[str, List[f
     projection keeps its target fraction on decode activations — with random weights the attention output shrinks with
     the context length, and thresholds from a short prefill keep ~10 % of the o-projection's rows after 100 positions.
     The refined values are written back into the blocks' thresh_* attributes; the caches are released again."""
-    from teal_amd.gpt_fast.engine import DecodeEngine
     dev = model.output.weight.device
     span = min(n_decode, model.config.block_size - n_prompt - 8)
     if span < 8:

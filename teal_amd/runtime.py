@@ -17,6 +17,8 @@ from . import _lib
 F16, BF16 = 0, 1
 _DTYPE_CODE = {torch.float16: F16, torch.bfloat16: BF16}
 _workspaces: dict[tuple[int, int], torch.Tensor] = {}
+_retired: list[torch.Tensor] = []  # capture workspaces that were replaced: graphs captured earlier still hold their pointers
+_MAX_STREAM_WORKSPACES = 8           # per device; the least recently created per-stream entries beyond this are dropped
 _inited: set[int] = set()
 
 
@@ -49,8 +51,9 @@ def _prepared(idx: int, nbytes: int) -> torch.Tensor:
     allocator may hand the address to anything else — a finalizer releases it (teal_workspace_release).  Keep the
     tensor itself alive for as long as launches (or captured graphs) use its pointer; do not keep views instead."""
     L = _lib.load()
-    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=torch.device("cuda", idx))
-    _lib.check(L.teal_workspace_init(ws.data_ptr(), ws.numel() * 4, stream_ptr()), "teal_workspace_init")
+    with torch.cuda.device(idx):  # allocation, the header memset's stream and the library's device context: all device idx
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=torch.device("cuda", idx))
+        _lib.check(L.teal_workspace_init(ws.data_ptr(), ws.numel() * 4, stream_ptr()), "teal_workspace_init")
     weakref.finalize(ws, L.teal_workspace_release, ws.data_ptr())
     return ws
 
@@ -76,8 +79,18 @@ def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
         for k in (key, (idx, -1)):
             old = _workspaces.get(k)
             if old is None or old.numel() * 4 < nbytes:
-                _workspaces[k] = _prepared(idx, nbytes)  # (a replaced tensor's finalizer releases its registration)
+                if old is not None and k[1] == -1:
+                    # a graph captured through the ops may hold this pointer (slabs AND the arrival-ticket header): never
+                    # hand the memory back to the allocator while the process lives — park it
+                    _retired.append(old)
+                _workspaces.pop(k, None)
+                _workspaces[k] = _prepared(idx, nbytes)  # (a replaced eager tensor's finalizer releases its registration)
         ws = _workspaces[key]
+        # bound the per-stream entries of this device (each keeps ~ 8 x 2 x N x 4 bytes): oldest first, never the capture one
+        mine = [k for k in _workspaces if k[0] == idx and k[1] != -1]
+        for k in mine[: max(0, len(mine) - _MAX_STREAM_WORKSPACES)]:
+            if k != key:
+                del _workspaces[k]
     return ws
 
 
