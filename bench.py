@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--n_layer", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense comparator run")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="skip the rocprofv3 --pmc subprocess that measures roofline.traffic in this run (the committed pass is reported instead)")
     ap.add_argument("--no-context-sweep", action="store_true", help="skip the value_at_context runs (1000 and 3800 cache positions)")
     ap.add_argument("--swizzle", type=int, default=0, help="XCD-decorrelating tile swizzle (A/B switch)")
     ap.add_argument("--block_size", type=int, default=0, help="override the architecture's context length (RoPE table / cache limit) "
@@ -288,17 +290,70 @@ def roofline_engine_gateup(eng, a):
     t = float(np.median(ts))
     n = len(launches)
     kname = eng.L.teal_last_launch_desc().decode()  # the instantiation run_gemv actually launched
-    traffic, tsrc = pmc_traffic(kname)
+    live = False
+    traffic, tsrc = (None, "disabled (--no-live-traffic)") if (getattr(a, "no_live_traffic", False) or eng.int8 or eng.int4) else pmc_traffic_live(cfg, a, kname, pair=eng.pair)
+    if traffic is not None:
+        live = True
+    else:
+        why = tsrc
+        traffic, tsrc = pmc_traffic(kname)  # the committed pass of this command (profiles/), flagged as such
+        if tsrc:
+            tsrc = f"{tsrc}; live pass: {why}"
     return {"bound": "hbm", "achieved": total_bytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": total_bytes / t / 1e9 / HBM_PEAK_GBS, "frac_of_measured_ceiling": total_bytes / t / 1e9 / HBM_MEASURED_CEILING_GBS,
             "measured_ceiling": HBM_MEASURED_CEILING_GBS, "traffic": traffic, "traffic_source": tsrc,
-            "traffic_measured_in_this_run": False,
+            "traffic_measured_in_this_run": live,
             "kernel": kname + f" (fused RMSNorm -> mask -> gate|up GEMV{' -> silu*mul' if eng.pair else ''}, Z={Z}, N=2x{N}"
                       + ("; int4: algorithmic bytes count kept ROWS at half a byte per weight + the dense group parameters — the kernel "
                          "fetches row PAIRS, 1.5x those weight bytes at 50 %" if eng.int4 else "") + ")",
             "algorithmic_bytes": total_bytes / n, "us_per_launch": t / n * 1e6, "launches_timed": n,
             "timing": "HIP events (launch stream) around a hipGraph of one launch per layer with that layer's weights; "
                       "per-launch time includes the same-stream launch boundary, like rocprofv3's per-dispatch duration"}
+
+
+def pmc_traffic_live(cfg, a, kernel_desc, pair=False, timeout_s=150):
+    """HBM read bytes per launch of the dominant kernel, measured IN THIS RUN: scripts/pmc_gateup.py (the same launch on its
+    own: same entry point, geometry and kept fraction) as a subprocess under `rocprofv3 --kernel-trace --pmc FETCH_SIZE`
+    (counters in a pass of their own, kernel trace only), FETCH_SIZE KiB x 2 as MI355X_MICROARCH.md prescribes for gfx950
+    (calibrated on this access pattern: profiles/r04_bench_summary.txt, FETCH x 2 / algorithmic = 1.01-1.02 on four launches).
+    Returns (bytes, source) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="teal_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = [prof, "--kernel-trace", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", out, "-o", "gateup", "--", sys.executable,
+           os.path.join(ROOT, "scripts", "pmc_gateup.py"), "--dim", str(cfg.dim), "--inter", str(cfg.intermediate_size),
+           "--sparsity", str(a.sparsity), "--dtype", a.precision, "--pair", str(int(pair))]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd="/tmp")
+        if r.returncode != 0:
+            return None, f"rocprofv3 pass failed (rc {r.returncode})"
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        info = json.loads(line[-1]) if line else {}
+        want = info.get("kernel", kernel_desc).split(" grid")[0].replace(" ", "")
+        vals = []
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if row["Counter_Name"] == "FETCH_SIZE" and "gemv_fast_kernel" in row["Kernel_Name"]:
+                    m = re.search(r"gemv_fast_kernel<([^>]*)>", row["Kernel_Name"])
+                    if m and ("gemv_fast_kernel<" + m.group(1).replace(" ", "") + ">") == want:
+                        vals.append(float(row["Counter_Value"]))
+        if len(vals) < 4:
+            return None, "no counter rows for the dominant kernel"
+        vals = vals[len(vals) // 4:]  # drop the first passes (cold TLBs / first touch)
+        return (sum(vals) / len(vals)) * 1024 * 2, {
+            "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE over scripts/pmc_gateup.py, a subprocess of this run (FETCH_SIZE KiB x 2, per dispatch)",
+            "dispatches": len(vals), "kept_fraction": info.get("kept_fraction"), "algorithmic_bytes_of_that_launch": info.get("algorithmic_bytes")}
+    except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as e:
+        return None, f"counter pass not available: {type(e).__name__}"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
 
 
 def pmc_traffic(kernel_desc):

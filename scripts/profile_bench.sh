@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/prof_${ROUND:-r04}${TAG:-}
 rm -rf "$OUT"; mkdir -p "$OUT"
-COMMON="--no-dense --no-cpu-baseline --no-context-sweep --profile-markers ${BENCH_ARGS:-}"
+COMMON="--no-dense --no-cpu-baseline --no-context-sweep --no-live-traffic --profile-markers ${BENCH_ARGS:-}"
 T="timeout ${PASS_TIMEOUT:-240}"   # every pass bounded: a pass that stalls must not eat the box's time limit
 $T rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python bench.py --steps ${STEPS:-100} --warmup 10 $COMMON > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"

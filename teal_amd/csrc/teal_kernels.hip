@@ -497,9 +497,11 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
         if (p.rope && !lean) return TEAL_ERR_CONFIG;  // the RoPE epilogue exists in the lean kernel only: never fall through unrotated
         if (lean) {
             g_rope_taken = f.a.rope != nullptr;
-            snprintf(g_last_desc, sizeof g_last_desc, "gemv_fast_kernel<%s,%d,%s,%d,%d,%s,false%s> grid (%d,%d) x 1024",
+            // (the instantiation as rocprofv3 prints it: BF16, MODE, PAIR, LPR, KR, EXACT, PHASE, U, W8, ROPE)
+            snprintf(g_last_desc, sizeof g_last_desc, "gemv_fast_kernel<%s,%d,%s,%d,%d,%s,%s%s,%s> grid (%d,%d) x 1024",
                      dtype == TEAL_BF16 ? "true" : "false", f.mode, f.pair ? "true" : "false", f.lpr, f.kr,
-                     (f.mode == 1 && f.Z == 1024 * f.kr) ? "true" : "false", f.w8 ? ",4,true" : ",4,false", f.ntiles, f.split);
+                     (f.mode == 1 && f.Z == 1024 * f.kr) ? "true" : "false", (f.a.phase && !f.w8) ? "true" : "false",
+                     f.w8 ? ",4,true" : ",4,false", f.a.rope ? "true" : "false", f.ntiles, f.split);
             const hipError_t e = f.w8 ? (dtype == TEAL_BF16 ? launch_fast_w8_bf16(f, st) : launch_fast_w8_f16(f, st))
                                       : (dtype == TEAL_BF16 ? launch_fast_bf16(f, st) : launch_fast_f16(f, st));
             return e == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;

@@ -84,7 +84,7 @@ def _int8_gemv_vs_truth(oracle, Z, N, dtype, tau, L, fast):
     bad = np.abs(got - truth) > tolerance(oracle, truth, dtype)
     assert not bad.any(), (int(bad.sum()), float(np.abs(got - truth).max()))
     desc = L.teal_last_launch_desc().decode()
-    is_lean = "gemv_fast_kernel" in desc and ",4,true>" in desc
+    is_lean = "gemv_fast_kernel" in desc and ",4,true," in desc
     assert not (is_lean and not fast), desc
     if fast and (Z, N) in ((4096, 4096), (4096, 11008), (11008, 4096), (4096, 14336), (4096, 32000)):  # the Llama projection shapes
         assert is_lean, desc
@@ -224,7 +224,7 @@ def test_int8_engine_runs_lean_kernel_and_equals_general_at_real_width(name, tdt
             for k, d in descs.items():
                 if k[0] == "head" and model.config.vocab_size > 64 * 1024:
                     continue  # a 128 k-entry vocabulary takes 256-column tiles: the general kernel
-                assert "gemv_fast_kernel" in d and ",4,true>" in d, (k, d)
+                assert "gemv_fast_kernel" in d and ",4,true," in d, (k, d)
             kept = eng.kept_fractions(tok, pos)
             assert all(0.2 < v < 0.85 for v in kept.values()), kept
             L.teal_set_fast(0)
