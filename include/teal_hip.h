@@ -15,6 +15,8 @@
  *   teal_fused_gemv        <- gpt-fast/model.py:158-161,289-291 residual adds + RMSNorm, :258-259 silu * up,
  *                             folded into the GEMV launch as producers
  *   teal_decode_attention* <- gpt-fast/model.py:170-186       RoPE, kv_cache.update, SDPA at S == 1
+ *                             (TEAL_OUT_QKV_ROPE + teal_decode_attention_split_roped: RoPE and the cache append in the wqkv
+ *                             projection's epilogue, :170-178, SDPA in the attention launch)
  *   teal_sample_topk       <- gpt-fast/generate.py:49-66      logits_to_probs + multinomial_sample_one
  *   teal_sparse_qkv_gemv_i8 <- gpt-fast/quantize.py:339-357   WeightOnlyInt8Linear.forward on the masked x
  *   teal_sparse_qkv_gemv_i4 <- gpt-fast/quantize.py:58-162,483-526 group-quantised int4 linear on the masked x

@@ -477,6 +477,22 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
+    if (getenv("LB_GATEAB")) {
+        // A/B inside one process: silu in the gate tiles' epilogue (act_seg0, down's producer multiplies) against silu in down's producer
+        const int g0 = gate_act;
+        gate_act = 0; token_step(); CK(hipStreamSynchronize(st)); hipGraphExec_t ga = capture(token_step);
+        gate_act = 1; token_step(); CK(hipStreamSynchronize(st)); hipGraphExec_t gb = capture(token_step);
+        gate_act = g0;
+        double sa = 0, sb = 0; const int rounds = 6;
+        for (int r = 0; r < rounds; ++r) {
+            const double ta = time_graph(ga, steps, true), tb = time_graph(gb, steps, true);
+            printf("  gate-act A/B round %d: silu in down's producer %.1f us  silu in the gate epilogue %.1f us\n", r, ta, tb);
+            if (r) { sa += ta; sb += tb; }
+        }
+        printf("gate-act A/B mean (rounds 1..): silu in down's producer %.1f us/token, in the gate epilogue %.1f us/token  -> %+.2f %%\n", sa / (rounds - 1),
+               sb / (rounds - 1), (sb / sa - 1.0) * 100.0);
+        return 0;
+    }
     if (getenv("LB_ROPEAB")) {
         // A/B inside one process: RoPE + KV append in the qkv epilogue (+ the attention launch that starts from finished rows)
         // against the slab hand-over (attention sums the slabs, rotates, appends)
