@@ -284,7 +284,7 @@ class DecodeEngine:
                 # unpaired: the gate tiles apply silu in their epilogue (act_seg0: once per column, by the two waves that
                 # reduce the tile) and down's producer only multiplies — the activation out of the prologue of each of
                 # down's 256 workgroups: -0.6 % per token on Llama-2-7B @ 50 % (profiles/r04_layer_experiments.txt)
-                self.gate_act = not self.int4
+                self.gate_act = not self.int4 and getattr(self, "use_gate_act", True)  # (use_gate_act = False: tests / A/B)
                 k4_out.act_seg0 = 1 if self.gate_act else 0
                 k5_in = GemvIn(mode=TEAL_IN_SILU_MUL, x=self.gu.data_ptr(), gate_activated=1 if self.gate_act else 0)
             k5_out = _out([seg(ff.w2, 0, dim, th["down"], None)], TEAL_OUT_SLABS, self.s_down)

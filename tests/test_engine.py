@@ -668,3 +668,44 @@ def test_rope_epilogue_equals_attention_side_rope(name, dtype):
     finally:
         del model
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name,dtype", [("7B", torch.float16), ("llama-3-8b", torch.bfloat16)])
+def test_silu_in_gate_epilogue_equals_silu_in_down_producer(name, dtype):
+    """act_seg0 / gate_activated (the gate tiles of the unpaired gate | up launch store round(silu(round(gate))), down's producer
+    multiplies) against silu in down's producer (model.py:258-259 either way): the same bits in the down projection's slabs,
+    the residual stream and the logits; the gate half of the hand-over buffer is silu of the other run's gate half."""
+    from teal_amd.gpt_fast import generate as G
+    from teal_amd.gpt_fast.engine import DecodeEngine
+    model = G.build_synthetic_model(name, DEV, dtype, seed=37, n_layer=2)
+    ths = G.apply_sparsity(model, sparsity=0.5, hist_path=None, greedy_lookup=None, synthetic=True)
+    prompt = torch.randint(0, model.config.vocab_size, (7,), device=DEV, dtype=torch.int, generator=torch.Generator(device=DEV).manual_seed(8))
+    try:
+        with torch.no_grad():
+            model.max_seq_length = -1
+            model.setup_caches(1, 32)
+            model(prompt.view(1, -1), torch.arange(7, device=DEV))
+            eng = DecodeEngine(model, ths, pair=False)
+            assert eng.gate_act and not eng.pair
+            tok = torch.tensor([[11]], device=DEV, dtype=torch.int)
+            pos = torch.tensor([7], device=DEV, dtype=torch.int)
+            inter = eng.inter
+
+            def run(flag):
+                eng.use_gate_act = flag
+                eng._build(ths)
+                assert eng.gate_act == flag
+                logits = eng(tok, pos).clone()
+                return logits, eng.s_down.clone(), eng.resid[0].clone(), eng.resid[1].clone(), eng.gu.clone()
+
+            a, b = run(True), run(False)
+            for i in range(4):
+                assert torch.equal(a[i].view(torch.uint8), b[i].view(torch.uint8)), i
+            assert torch.equal(a[4][inter:].view(torch.int16), b[4][inter:].view(torch.int16)), "up half"
+            sg = torch.nn.functional.silu(b[4][:inter].float())  # last layer's gate, activation restated in fp32
+            err = (a[4][:inter].float() - sg).abs()
+            ulp = sg.abs().clamp_min(6e-5) * (2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7)
+            assert bool((err <= ulp).all()), float((err / ulp).max())
+    finally:
+        del model
+        torch.cuda.empty_cache()
