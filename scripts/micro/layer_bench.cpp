@@ -615,6 +615,21 @@ int main(int argc, char** argv) {
             for (int e = li + 2; e < n_layer; ++e) full_layer(e);
             CK(hipStreamSynchronize(st));
             CK(hipMemcpy(hp.data(), ph, region * nreg * 8, hipMemcpyDeviceToHost));
+            if (getenv("LB_WGDUMP") && it >= 6) {
+                // per-workgroup end of stream (slowest wave) and end of kernel, relative to the launch's first entry, with the
+                // XCC the workgroup ran on: is the spread between workgroups systematic (by XCD, by tile) or random?
+                const int gsel = atoi(getenv("LB_WGDUMP"));
+                const unsigned long long* base = &hp[region * gsel];
+                const int nwg = (int)(base[13] & 0xFFFFFFFFull);
+                double t0 = 1e30; for (int b = 0; b < nwg; ++b) t0 = std::min(t0, (double)base[(size_t)b * 32]);
+                printf("WGDUMP it %d launch %s nwg %d:", it, sn[gsel], nwg);
+                for (int b = 0; b < nwg; ++b) {
+                    const unsigned long long* r = &base[(size_t)b * 32];
+                    double wmax = 0; for (int w = 0; w < 16; ++w) wmax = std::max(wmax, (double)r[16 + w]);
+                    printf(" %d:%llu:%.2f:%.2f:%.2f", b, r[12] & 0xFull, ((double)r[0] - t0) / 100.0, (wmax - t0) / 100.0, ((double)r[7] - t0) / 100.0);
+                }
+                printf("\n");
+            }
             double prev_end = 0;
             for (int g = 0; g < nreg; ++g) {
                 const unsigned long long* base = &hp[region * g];

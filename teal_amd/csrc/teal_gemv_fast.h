@@ -38,7 +38,7 @@ namespace teal {
 //   MODE 0 plain x; 1 residual + slabs -> RMSNorm (in0 residual, in1 slabs, in2 norm weight); 2 x = silu(gate) * up with
 //   gate|up contiguous [2Z] at in0 (gpt-fast/model.py:258-259, the roundings of the unfused sequence); 3 x + producer
 //   masks (in0 x, in1 masks); 4 split-KV attention partials (in0).  Element-wise modes (0, 2, 3, 4) cache the rounds of
-//   the workgroup's own slice only: register k <-> round slice + k * split.
+//   the workgroup's own slice only: register k <-> chunk slice + split * (wave + 16 k).
 //   EXACT (MODE 1): Z == 1024 * KR, every cached chunk exists — no clamps, no guards.
 template <bool BF16, int MODE, bool PAIR, int LPR, int KR, bool EXACT, bool PHASE, int U = 4, bool W8 = false, bool ROPE = false>
 __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const void* in1, const void* in2,
@@ -80,11 +80,17 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
     uint32_t wb[MODE == 1 ? KR : 1];
     unsigned long long mk[MODE == 3 ? KR : 1];
     {
-        int kmod = 0;  // MODE 1 caches every round; round k belongs to slice k mod split
+        // Which chunks (64 activations) a workgroup streams — balanced over the slices to within one chunk (round 4; whole
+        // rounds of 16 chunks per slice left Llama-2-7B's down projection, 172 chunks over 4 slices, at 48 / 48 / 44 / 32 and its
+        // last workgroups 1.8 us behind the first: -0.2 % per token at 7B, -0.8 % at Llama-3-8B, -0.7 % at 70B widths):
+        //   element-wise producers: chunk c belongs to slice c mod split, inside the slice to wave (c div split) mod 16;
+        //   MODE 1 (every workgroup caches the whole vector, wave w holds chunks w + 16 k): chunk (w, k) belongs to slice
+        //   (k + w) mod split — the slices' extra rounds rotate over the waves.
+        // sparse_gemv_kernel (teal_gemv_kernel.h: chunk_of / kmod) uses the same rule: bit-identical outputs.
+        int kmod = (MODE == 1 && split > 1) ? wave % split : 0;
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
-            const int round = MODE == 1 ? k : slice + k * split;
-            const int c = wave + WAVES * round;
+            const int c = MODE == 1 ? wave + WAVES * k : slice + split * (wave + WAVES * k);
             cidx[k] = c;
             own[k] = (EXACT || c < nch) && (MODE != 1 || kmod == slice);
             kmod = (kmod + 1 == split) ? 0 : kmod + 1;
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
             constexpr int NS = decltype(ns_tag)::value;
             static_assert(KR * NS <= 64, "one lane per (chunk, split)");
             const int kk = min(lane / NS, KR - 1), qq = lane % NS;
-            const int ck = min(wave + WAVES * (slice + kk * split), nch - 1);
+            const int ck = min(slice + split * (wave + WAVES * kk), nch - 1);
             const float2 st = *reinterpret_cast<const float2*>(att + ((size_t)((ck << 6) / hd) * NS + qq) * hs);
             float ov[KR][NS];
 #pragma unroll

@@ -148,10 +148,12 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
     // PAIR: the list is the union of the two keep sets (smaller threshold); see the stream loop
     const float tau = PAIR ? fminf(p.seg[0].tau, p.seg[1].tau) : sg.tau;
     // register k of wave w caches chunk w + WAVES * k (round k of the wave).  Slice-local (wave-local compaction
-    // with an element-wise producer): a workgroup only ever needs the rounds of ITS slice, so register k caches
-    // round slice + k * split instead — 1/split of the loads, and vectors up to split * 16 rounds fit the cache
-    const int kbase = p.sl ? slice : 0, kstep = p.sl ? p.split : 1;
-    auto chunk_of = [&](const int k) { return wave + WAVES * (kbase + k * kstep); };
+    // with an element-wise producer): a workgroup only ever needs the chunks of ITS slice, so register k caches
+    // chunk slice + split * (wave + WAVES k) instead — 1/split of the loads, and vectors up to split * 16 rounds fit the cache
+    // (balanced over the slices to within one chunk, the rule of gemv_fast_kernel: slice-local chunk c belongs to slice c mod
+    //  split and wave (c div split) mod WAVES; otherwise wave w holds chunks w + WAVES k and owns those with (k + w) mod split
+    //  == slice)
+    auto chunk_of = [&](const int k) { return p.sl ? slice + p.split * (wave + WAVES * k) : wave + WAVES * k; };
     uint32_t xr[KR];
     int mcl[KR];  // clamped element index of (k, lane)
 #pragma unroll
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
         //      barrier between the activation and the first weight load.  Per-wave row counts differ by
         //      the binomial spread only; the launch is HBM-bound, so that does not cost time.
         uint32_t* mylist = list + (size_t)wave * p.cap;
-        int base = 0, kmod = 0;
+        int base = 0, kmod = (p.sl || p.split == 1) ? 0 : wave % p.split;
         unsigned long long mk[KR];
         if constexpr (MODE == 3) {
 #pragma unroll
