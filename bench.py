@@ -322,6 +322,9 @@ def pmc_traffic_live(cfg, a, kernel_desc, pair=False, timeout_s=150):
     import shutil
     import subprocess
     import tempfile
+    # this process is itself being profiled (rocprofv3 / rocprofiler-sdk tool preloaded): no nested counter pass
+    if any(k.startswith(("ROCPROF", "ROCPROFILER", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "bench.py is running under a profiler: no nested counter pass"
     prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if prof is None:
         return None, "rocprofv3 not found"
