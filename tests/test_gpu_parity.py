@@ -363,3 +363,87 @@ def test_deja_vu_comparator_computes_the_same_masked_gemv():
         assert torch.equal(flags.bool(), keep)
         want = (buf[:, :N].double() * (x.double() * keep)[:, None]).sum(0)
         assert torch.allclose(y32.double(), want, atol=1e-3, rtol=1e-4), float((y32.double() - want).abs().max())
+
+
+def test_c_abi_round4_additions_qkv_rope_and_act_seg0():
+    """TEAL_OUT_QKV_ROPE straight through the C ABI: the epilogue's rotated q / appended k, v against a torch restatement of
+    gpt-fast/model.py:170-178 applied to the SAME launch's slab-mode projection (general kernel: the request falls back to
+    slabs and says so); argument rules of act_seg0 / gate_activated."""
+    import ctypes
+    from teal_amd import _lib, runtime
+    from teal_amd.gpt_fast.engine import GemvIn, GemvOut, TEAL_IN_PLAIN, TEAL_IN_RESID_NORM, TEAL_OUT_QKV_ROPE, TEAL_OUT_ROUNDED, TEAL_OUT_SLABS
+    L = _lib.load()
+    runtime.init()
+    dim, nkv, hd, max_seq, P = 4096, 32, 128, 64, 9
+    kv = nkv * hd
+    nqkv, ld = dim + 2 * kv, dim + 2 * kv + 64
+    g = torch.Generator(device=DEV).manual_seed(12)
+    for dt, code in ((torch.float16, 0), (torch.bfloat16, 1)):
+        w = ((torch.rand(dim, ld, device=DEV, generator=g) - 0.5) * 0.05).to(dt)
+        resid = torch.randn(dim, device=DEV, generator=g).to(dt)
+        normw = (1.0 + 0.1 * torch.randn(dim, device=DEV, generator=g)).to(dt)
+        ang = torch.outer(torch.arange(max_seq, device=DEV).float(), 1.0 / (10000 ** (torch.arange(0, hd, 2, device=DEV).float() / hd)))
+        rope = torch.stack((torch.cos(ang), torch.sin(ang)), dim=-1).to(dt).contiguous()
+        pos = torch.tensor([P], device=DEV, dtype=torch.int32)
+        kc = torch.zeros(nkv, max_seq, hd, device=DEV, dtype=dt)
+        vc = torch.zeros_like(kc)
+        q = torch.zeros(nqkv, device=DEV, dtype=dt)
+        slabs = torch.zeros(8 * nqkv, device=DEV, dtype=torch.float32)
+        hout = torch.zeros(dim, device=DEV, dtype=dt)
+        ws = runtime.new_workspace(dim, nqkv)
+        gin = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=resid.data_ptr(), slabs=None, nslabs=0, slabs_interleaved=1,
+                     norm_weight=normw.data_ptr(), eps=1e-5, resid_out=hout.data_ptr())
+        tau = 0.6
+
+        def out(mode):
+            o = GemvOut()
+            o.nseg, o.mode = 3, mode
+            for i, (c0, nc) in enumerate(((0, dim), (dim, kv), (dim + kv, kv))):
+                o.w[i], o.ld[i], o.col0[i], o.ncols[i], o.tau[i], o.y[i] = w.data_ptr(), ld, c0, nc, tau, q.data_ptr() + 2 * c0
+            o.slabs, o.slabs_bytes, o.slabs_interleaved = slabs.data_ptr(), slabs.numel() * 4, 1
+            o.rope, o.rope_pos, o.k_cache, o.v_cache = rope.data_ptr(), pos.data_ptr(), kc.data_ptr(), vc.data_ptr()
+            o.rope_head_dim, o.rope_max_seq = hd, max_seq
+            return o
+
+        n = ctypes.c_int(-1)
+        args = (ctypes.byref(gin), None, dim, code, ws.data_ptr(), ws.numel() * 4, ctypes.byref(n), runtime.stream_ptr())
+        o = out(TEAL_OUT_QKV_ROPE)
+        assert L.teal_fused_gemv(args[0], ctypes.byref(o), *args[2:]) == 0 and n.value == 0  # the epilogue ran
+        got_q, got_k, got_v = q[:dim].clone(), kc[:, P].clone(), vc[:, P].clone()
+        assert float(kc[:, :P].abs().max()) == 0 and float(kc[:, P + 1:].abs().max()) == 0  # only the token's row was written
+        o = out(TEAL_OUT_SLABS)
+        assert L.teal_fused_gemv(args[0], ctypes.byref(o), *args[2:]) == 0 and n.value == 1
+        proj = slabs[: nqkv * 4].view(nqkv, 4)[:, 0].to(dt)  # one slab, rounded like the epilogue rounds it
+        c_, s_ = rope[P, :, 0].float(), rope[P, :, 1].float()
+
+        def rot(v):  # interleaved pairs, fp32 with the helper's fused multiply-add (model.py: apply_rotary_emb)
+            v = v.float().view(-1, hd // 2, 2)
+            a = torch.addcmul(-(v[..., 1] * s_), v[..., 0], c_)
+            b = torch.addcmul(v[..., 0] * s_, v[..., 1], c_)
+            return torch.stack((a, b), dim=-1).reshape(-1)
+
+        want_q, want_k = rot(proj[:dim]), rot(proj[dim:dim + kv])
+        ulp = lambda t: t.abs().clamp_min(6e-5) * (2.0 ** -10 if dt == torch.float16 else 2.0 ** -7)  # noqa: E731
+        assert bool(((got_q.float() - want_q).abs() <= ulp(want_q)).all()), "rotated q"
+        assert bool(((got_k.float().view(-1) - want_k).abs() <= ulp(want_k)).all()), "rotated k row"
+        assert torch.equal(got_v.view(-1).view(torch.int16), proj[dim + kv:].view(torch.int16)), "v row: the rounded projection, bit for bit"
+        # the general kernel has no such epilogue: the request falls back to the slabs and reports it
+        L.teal_set_fast(0)
+        try:
+            o = out(TEAL_OUT_QKV_ROPE)
+            assert L.teal_fused_gemv(args[0], ctypes.byref(o), *args[2:]) == 0 and n.value >= 1
+            o.slabs = None
+            assert L.teal_fused_gemv(args[0], ctypes.byref(o), *args[2:]) == -1  # TEAL_ERR_ARG: nowhere to fall back to
+        finally:
+            L.teal_set_fast(1)
+        # act_seg0 belongs to rounded outputs; gate_activated / act_seg0 are refused by the int4 kernel
+        o = out(TEAL_OUT_SLABS)
+        o.act_seg0 = 1
+        assert L.teal_fused_gemv(args[0], ctypes.byref(o), *args[2:]) == -1
+        o = out(TEAL_OUT_ROUNDED)
+        o.weight_bits, o.groupsize, o.act_seg0 = 4, 32, 1
+        for i in range(3):
+            o.scale[i], o.scale_ld[i] = w.data_ptr(), nqkv
+        gp = GemvIn(mode=TEAL_IN_PLAIN, x=resid.data_ptr())
+        assert L.teal_fused_gemv(ctypes.byref(gp), ctypes.byref(o), *args[2:]) == -1
+    torch.cuda.synchronize()
