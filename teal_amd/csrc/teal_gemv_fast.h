@@ -87,14 +87,10 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
         //   MODE 1 (every workgroup caches the whole vector, wave w holds chunks w + 16 k): chunk (w, k) belongs to slice
         //   (k + w) mod split — the slices' extra rounds rotate over the waves.
         // sparse_gemv_kernel (teal_gemv_kernel.h: chunk_of / kmod) uses the same rule: bit-identical outputs.
-        int kmod = (MODE == 1 && split > 1) ? wave % split : 0;
+        // (own[] is filled in right before the compaction: with the RMSNorm producer it needs gridDim.y — a scalar load the
+        //  activation loads below must not wait for)
 #pragma unroll
-        for (int k = 0; k < KR; ++k) {
-            const int c = MODE == 1 ? wave + WAVES * k : slice + split * (wave + WAVES * k);
-            cidx[k] = c;
-            own[k] = (EXACT || c < nch) && (MODE != 1 || kmod == slice);
-            kmod = (kmod + 1 == split) ? 0 : kmod + 1;
-        }
+        for (int k = 0; k < KR; ++k) cidx[k] = MODE == 1 ? wave + WAVES * k : slice + split * (wave + WAVES * k);
     }
     if constexpr (MODE == 1) {
         const uint16_t* resid = x16;
@@ -273,6 +269,14 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
     if (tile >= a.seg_tile2) s = 2;
     const float tau_s = s == 0 ? a.tau0 : (s == 1 ? a.tau1 : a.tau2);
     const float tau = PAIR ? fminf(a.tau0, a.tau1) : tau_s;  // PAIR: union of the two keep sets
+    {
+        int kmod = (MODE == 1 && split > 1) ? wave % split : 0;
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            own[k] = (EXACT || cidx[k] < nch) && (MODE != 1 || kmod == slice);
+            kmod = (kmod + 1 == split) ? 0 : kmod + 1;
+        }
+    }
     uint32_t* list = reinterpret_cast<uint32_t*>(smem + 64) + (size_t)wave * a.cap;
     float* red = reinterpret_cast<float*>(smem + 64 + (size_t)WAVES * a.cap * 4);
     int nloc = 0;
