@@ -22,8 +22,8 @@ SOURCES = ("teal_kernels.hip", "teal_attention.hip", "teal_gemv_w16_f16.hip", "t
            "teal_gemv_fast_w8_f16.hip", "teal_gemv_fast_w8_bf16.hip", "teal_comparators.hip")
 # translation units whose kernels take their hot arguments as scalar parameters: the command processor preloads the
 # first 11 dwords into SGPRs at wave launch (no scalar-cache miss before the first activation load)
-PRELOAD = {"teal_gemv_fast_f16.hip": 11, "teal_gemv_fast_bf16.hip": 11, "teal_gemv_fast_w8_f16.hip": 11,
-           "teal_gemv_fast_w8_bf16.hip": 11, "teal_attention.hip": 12}
+PRELOAD = {"teal_gemv_fast_f16.hip": 12, "teal_gemv_fast_bf16.hip": 12, "teal_gemv_fast_w8_f16.hip": 12,
+           "teal_gemv_fast_w8_bf16.hip": 12, "teal_attention.hip": 12}
 INCLUDE = os.path.join(_ROOT, "include")
 OBJ_DIR = os.path.join(CSRC, "_obj")
 LIB_PATH = os.path.join(_PKG, "libteal_hip.so")

@@ -43,7 +43,7 @@ namespace teal {
 template <bool BF16, int MODE, bool PAIR, int LPR, int KR, bool EXACT, bool PHASE, int U = 4, bool W8 = false, bool ROPE = false>
 __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const void* in1, const void* in2,
                                                          const int* row_index, const int Z, const int nslabs,
-                                                         const float eps, const FastArgs a) {
+                                                         const float eps, const int split_p, const FastArgs a) {
     static_assert(!(W8 && PAIR), "int8 gate|up runs unpaired (two images of 128-byte row segments)");
     static_assert(!ROPE || (MODE == 1 && !PAIR && !W8), "the RoPE / KV-append epilogue belongs to the fused wqkv projection");
     constexpr int WAVES = 16;
@@ -61,7 +61,11 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x, slice = blockIdx.y, split = gridDim.y;
+    // split = gridDim.y, handed over as a PRELOADED scalar argument: gridDim lives in the dispatch packet / hidden kernel
+    // arguments, i.e. behind a scalar load — and the element-wise producers need it for the address of their first activation
+    // load (round 4: the ISA of the down / wo launches opened with s_load gridDim.y; s_waitcnt lgkmcnt(0) — the 0.4-0.5 us
+    // "kernarg" phase of those launches)
+    const int tile = blockIdx.x, slice = blockIdx.y, split = split_p;
     const int nch = Z >> 6;
     const uint32_t bid = blockIdx.y * gridDim.x + blockIdx.x;
     auto stamp = [&](const int i) {
@@ -87,8 +91,7 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
         //   MODE 1 (every workgroup caches the whole vector, wave w holds chunks w + 16 k): chunk (w, k) belongs to slice
         //   (k + w) mod split — the slices' extra rounds rotate over the waves.
         // sparse_gemv_kernel (teal_gemv_kernel.h: chunk_of / kmod) uses the same rule: bit-identical outputs.
-        // (own[] is filled in right before the compaction: with the RMSNorm producer it needs gridDim.y — a scalar load the
-        //  activation loads below must not wait for)
+        // (own[] is filled in right before the compaction)
 #pragma unroll
         for (int k = 0; k < KR; ++k) cidx[k] = MODE == 1 ? wave + WAVES * k : slice + split * (wave + WAVES * k);
     }
@@ -177,19 +180,22 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
     } else if constexpr (MODE == 4) {
         // attention output merged from the split-KV partials {max, sum, o[hd]} per (head, split): see the merge
         // producer of sparse_gemv_kernel; one lane per (cached chunk, split) fetches {max, sum}
+        // head_dim (64 / 128) and the partials per head arrive in the preloaded `nslabs` slot as att_ns | log2(head_dim) << 8:
+        // nothing the merge's loads need waits for the argument batch, and head_dim divides by shifts
         const float* att = reinterpret_cast<const float*>(in0);
-        const int hd = a.att_hd, hs = hd + 2;
+        const int hsh = nslabs >> 8, att_ns = nslabs & 0xFF;
+        const int hd = 1 << hsh, hs = hd + 2;
         auto merge = [&](auto ns_tag) {
             constexpr int NS = decltype(ns_tag)::value;
             static_assert(KR * NS <= 64, "one lane per (chunk, split)");
             const int kk = min(lane / NS, KR - 1), qq = lane % NS;
             const int ck = min(slice + split * (wave + WAVES * kk), nch - 1);
-            const float2 st = *reinterpret_cast<const float2*>(att + ((size_t)((ck << 6) / hd) * NS + qq) * hs);
+            const float2 st = *reinterpret_cast<const float2*>(att + ((size_t)((ck << 6) >> hsh) * NS + qq) * hs);
             float ov[KR][NS];
 #pragma unroll
             for (int k = 0; k < KR; ++k) {
                 const int m = (min(cidx[k], nch - 1) << 6) + lane;
-                const int h = m / hd, d = m - h * hd;
+                const int h = m >> hsh, d = m & (hd - 1);
                 const float* b = att + (size_t)h * NS * hs + 2 + d;
 #pragma unroll
                 for (int q = 0; q < NS; ++q) ov[k][q] = b[q * hs];
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
             }
         };
         if constexpr (KR * 8 <= 64) {
-            if (a.att_ns == 8) merge(std::integral_constant<int, 8>{});
+            if (att_ns == 8) merge(std::integral_constant<int, 8>{});
             else merge(std::integral_constant<int, 4>{});
         } else {
             merge(std::integral_constant<int, 4>{});
@@ -562,19 +568,19 @@ hipError_t launch_fast_e(const FastLaunch& f, hipStream_t st) {
     if constexpr (!W8) {
         if (f.a.phase) {  // stamped instantiations (diagnostics: teal_set_phase_buffer), both activation dtypes
             hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, true>), grid, block, f.lds, st, f.in0, f.in1,
-                               f.in2, f.row_index, f.Z, f.nslabs, f.eps, f.a);
+                               f.in2, f.row_index, f.Z, f.nslabs, f.eps, f.split, f.a);
             return hipGetLastError();
         }
     }
     if constexpr (MODE == 1 && !PAIR && !W8) {
         if (f.a.rope) {  // fused wqkv projection, split == 1: RoPE + KV-cache append in the epilogue
             hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, false, 4, W8, true>), grid, block, f.lds, st, f.in0, f.in1,
-                               f.in2, f.row_index, f.Z, f.nslabs, f.eps, f.a);
+                               f.in2, f.row_index, f.Z, f.nslabs, f.eps, f.split, f.a);
             return hipGetLastError();
         }
     }
     hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, false, 4, W8>), grid, block, f.lds, st, f.in0, f.in1, f.in2,
-                       f.row_index, f.Z, f.nslabs, f.eps, f.a);
+                       f.row_index, f.Z, f.nslabs, f.eps, f.split, f.a);
     return hipGetLastError();
 }
 

@@ -303,7 +303,9 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
                 break;
         case 2: f.in0 = p.x; break;  // gate | up contiguous [2Z]
         case 3: f.in0 = p.x; f.in1 = p.in.masks; break;
-        case 4: f.in0 = p.in.att; f.a.att_hd = p.in.att_hd; f.a.att_ns = p.in.att_ns; break;
+        case 4: f.in0 = p.in.att; f.a.att_hd = p.in.att_hd; f.a.att_ns = p.in.att_ns;
+                f.nslabs = p.in.att_ns | ((p.in.att_hd == 128 ? 7 : 6) << 8);  // the preloaded slot of the merge producer
+                break;
         default: f.in0 = p.x; break;
     }
     const size_t wb = p.w8 ? 1 : 2;  // bytes per weight
