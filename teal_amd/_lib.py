@@ -26,7 +26,8 @@ PRELOAD = {"teal_gemv_fast_f16.hip": 12, "teal_gemv_fast_bf16.hip": 12, "teal_ge
            "teal_gemv_fast_w8_bf16.hip": 12, "teal_attention.hip": 12}
 INCLUDE = os.path.join(_ROOT, "include")
 OBJ_DIR = os.path.join(CSRC, "_obj")
-LIB_PATH = os.path.join(_PKG, "libteal_hip.so")
+# TEAL_LIB_PATH: load another build of the library (same C ABI) instead of the in-tree one — same-box A/B of two builds
+LIB_PATH = os.environ.get("TEAL_LIB_PATH") or os.path.join(_PKG, "libteal_hip.so")
 
 # every symbol include/teal_hip.h declares
 EXPORTS = (

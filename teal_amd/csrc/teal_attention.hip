@@ -296,9 +296,9 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
     // the first 12 dwords are preloaded into SGPRs (teal_amd/_lib.py: PRELOAD): everything the FIRST loads need — the K / V
     // prefetch, q and *pos — with no scalar load and no integer division in front of them (round 4: the kernel used to open
     // with s_load n_head / n_kv / max_seq / nsplit, a wait, and three divisions: blockIdx / nsplit, n_head / n_kv, h / rep;
-    // now the grid is (split, head) and the heads-per-KV-head ratio arrives as a shift)
+    // now the grid is (split, query head inside its group, KV head): no division for any ratio)
     const int* __restrict__ pos_ptr, uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache,
-    const uint16_t* __restrict__ qkv, const int max_seq, const int nsplit, const int rep_shift, const int qkv_nslabs,
+    const uint16_t* __restrict__ qkv, const int max_seq, const int nsplit, const int rep, const int qkv_nslabs,
     const float* __restrict__ qkv_slabs, float* __restrict__ partials, const uint16_t* __restrict__ rope, const int n_head,
     const int n_kv, const float scale, unsigned long long* __restrict__ phase, const int exp,
     unsigned* __restrict__ ticket, uint16_t* __restrict__ y, unsigned long long* __restrict__ mask_out, const float mask_tau) {
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
     __shared__ unsigned fold_flag;
     const bool fold = ticket != nullptr;  // merge folded into this launch (fold_merge): partials are published write-through
     const unsigned long long t_entry = wall_clock64();
-    const int sp = blockIdx.x, h = blockIdx.y;  // grid (nsplit, n_head): no division
+    const int sp = blockIdx.x, kvh = blockIdx.z, h = kvh * rep + blockIdx.y;  // grid (nsplit, rep, n_kv): no division
     const int wg = h * nsplit + sp;            // linear index: partials, phase stamps
     auto stamp_p = [&](const int i) { if (phase && threadIdx.x == 0) phase[(size_t)wg * kPhaseRowA + i] = wall_clock64(); };
     extern __shared__ __align__(16) unsigned char smem[];
@@ -318,9 +318,7 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
     float* part = red + 2 * NW;      // [NW][hd]
     float* sc = part + NW * hd;      // [local steps][STEP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // query heads per KV head: a power of two in every Llama (rep_shift >= 0); the general ratio only behind the branch
-    const int kvh = rep_shift >= 0 ? (h >> rep_shift) : h / (n_head / n_kv);
-    auto first_of_group = [&]() { return rep_shift >= 0 ? (h & ((1 << rep_shift) - 1)) == 0 : h % (n_head / n_kv) == 0; };
+    auto first_of_group = [&]() { return blockIdx.y == 0; };  // the query head that appends the group's k / v row
     const int dim = n_head * hd, kvs = n_kv * hd;
     uint16_t* kc = k_cache + (size_t)kvh * max_seq * hd;
     uint16_t* vc = v_cache + (size_t)kvh * max_seq * hd;
@@ -361,7 +359,12 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
     uint16_t lr[4] = {0, 0, 0, 0};
     // ROPED (after a TEAL_OUT_QKV_ROPE projection): qkv = the rotated, rounded query; the token's k / v rows are in the caches
     u32x4 qraw = {0u, 0u, 0u, 0u};
-    if constexpr (ROPED) qraw = *reinterpret_cast<const u32x4*>(qkv + (size_t)h * hd + ds * 8);
+    if constexpr (ROPED) {
+        qraw = *reinterpret_cast<const u32x4*>(qkv + (size_t)h * hd + ds * 8);
+        // nothing below may be scheduled above these loads: the compiler otherwise hoists address arithmetic on arguments that
+        // are NOT preloaded (partials, phase, n_head ...) — and with it an s_waitcnt for their scalar loads — in front of them
+        __builtin_amdgcn_sched_barrier(0);
+    }
     const bool rot = !ROPED && tid < hd / 2, vld = !ROPED && tid >= 128 && tid < 128 + hd;
     if (rot) {
         raw_at(h * hd + 2 * tid, la[0], lb[0], lr[0]);
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
     }
     const int pos = min(max(pos_ptr[0], 0), max_seq - 1), n = pos + 1;  // clamped: never writes past the cache
     float* out = partials + (size_t)wg * (hd + 2);
-    if (phase && threadIdx.x == 0) { phase[(size_t)wg * kPhaseRowA] = t_entry; phase[(size_t)wg * kPhaseRowA + 13] = ((unsigned long long)NW << 32) | (gridDim.x * gridDim.y); }
+    if (phase && threadIdx.x == 0) { phase[(size_t)wg * kPhaseRowA] = t_entry; phase[(size_t)wg * kPhaseRowA + 13] = ((unsigned long long)NW << 32) | (gridDim.x * gridDim.y * gridDim.z); }
     stamp_p(1);
     if (sp * STEP >= n) {  // no row group of this workgroup is in range yet (short sequence, many splits)
         if (tid < hd) store_partial(out + 2 + tid, 0.0f, fold);
@@ -1524,8 +1527,7 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
     // grouped-query models at long contexts: one workgroup per (KV head, split) serves all the query heads of the group
     // (the per-query-head kernel is 2-3 us faster below ~2 k positions: scripts/attention_context_sweep.py)
     const int rep = n_head / n_kv_head;
-    const dim3 grid2(nsplit, n_head);                               // the per-query-head kernel: (split, head), no division
-    const int rep_shift = (rep & (rep - 1)) == 0 ? __builtin_ctz((unsigned)rep) : -1;
+    const dim3 grid2(nsplit, rep, n_kv_head);  // the per-query-head kernel: (split, query head of the group, KV head), no division
     bool gqa = ((rep == 8 && max_seq >= kGqaMinSeq8) || (rep == 4 && max_seq >= kGqaMinSeq)) && !(g_exp & 8) && !roped;
     // y requested (the consumer does not merge): the merge can be FOLDED into the split launch — the last workgroup of a head
     // (or KV-head group) to arrive merges it (prepared workspace) — instead of a merge launch.  MEASURED, NOT FASTER
@@ -1554,7 +1556,7 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
     }
     if (!gqa) {
         if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
-#define TEAL_ATTS_R(BF, HDV, NTV, RP) hipLaunchKernelGGL((decode_attention_split_kernel<BF, HDV, NTV, RP>), grid2, block, lds, st, pos, kc, vc, q, max_seq, nsplit, rep_shift, qkv_nslabs, qkv_slabs, pw, r, n_head, n_kv_head, scale, ph, g_exp, tk, yo, mo, mask_tau)
+#define TEAL_ATTS_R(BF, HDV, NTV, RP) hipLaunchKernelGGL((decode_attention_split_kernel<BF, HDV, NTV, RP>), grid2, block, lds, st, pos, kc, vc, q, max_seq, nsplit, rep, qkv_nslabs, qkv_slabs, pw, r, n_head, n_kv_head, scale, ph, g_exp, tk, yo, mo, mask_tau)
 #define TEAL_ATTS(BF, HDV, NTV) do { if (roped) TEAL_ATTS_R(BF, HDV, NTV, true); else TEAL_ATTS_R(BF, HDV, NTV, false); } while (0)
 #define TEAL_ATTS_NT(BF, HDV) do { if (nt == 1024) TEAL_ATTS(BF, HDV, 1024); else TEAL_ATTS(BF, HDV, 256); } while (0)
     if (dtype == TEAL_BF16) { if (head_dim == 128) TEAL_ATTS_NT(true, 128); else TEAL_ATTS_NT(true, 64); }

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
         tot = wave_sum_f(tot);
         const float rstd = rsqrtf(tot / (float)Z + eps);
         uint16_t* rout = reinterpret_cast<uint16_t*>(a.resid_out);
-        const bool writer = rout && bid == 0;
+        const bool writer = rout && blockIdx.x == 0 && blockIdx.y == 0;  // (not via bid: gridDim.x is a scalar load)
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
             const float xn = bits_to_float(float_to_bits<BF16>(rv[k] * rstd), BF16);
