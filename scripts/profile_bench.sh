@@ -17,10 +17,17 @@ T="timeout ${PASS_TIMEOUT:-240}"   # every pass bounded: a pass that stalls must
 $T rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python bench.py --steps ${STEPS:-100} --warmup 10 $COMMON > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
 if [ "${PASSES:-all}" = "all" ]; then
-$T rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- python bench.py --steps 10 --warmup 2 $COMMON > "$OUT/pmc_fetch.log" 2>&1
-echo "pmc fetch rc=$?"
-$T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- python bench.py --steps 10 --warmup 2 $COMMON > "$OUT/pmc_write.log" 2>&1
-echo "pmc write rc=$?"
+# Counter passes run with AMD_SERIALIZE_KERNEL=3 (the HIP runtime waits before and after every launch; the counters of a launch
+# do not depend on it).  Without it rocprofv3 7.2.0's counter mode — which serialises dispatches itself and adds its own packets
+# around each — falls behind this command's asynchronous launch stream (thousands of dispatches between synchronisations), the
+# intercepted queue fills, and the process dies in librocprofiler-sdk's queue write interceptor reading one packet past the end
+# of the 1 MiB ring (SIGSEGV) or with HSA_STATUS_ERROR_INVALID_PACKET_FORMAT: 9 of 10 unserialised passes of the round's last
+# builds ended that way (gdb backtrace in profiles/README.md), every serialised one completed.
+for C in FETCH_SIZE WRITE_SIZE; do
+  tag=pmc_$(echo ${C%_SIZE} | tr A-Z a-z)
+  AMD_SERIALIZE_KERNEL=3 timeout ${PMC_TIMEOUT:-120} rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$tag" -o bench -- python bench.py --steps 10 --warmup 2 $COMMON > "$OUT/$tag.log" 2>&1
+  echo "$tag rc=$?"
+done
 fi
 find "$OUT" -name "*.db" -delete
 python scripts/summarize_prof.py "$OUT" "${MODEL:-7B}" > "$OUT/summary.txt" 2>&1

@@ -101,7 +101,9 @@ def main(root, model="7B"):
         st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         if window and not (window[0] <= st and en <= window[1]):
             continue
-        wgs = (int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))) * (int(r["Grid_Size_Y"]) // max(1, int(r["Workgroup_Size_Y"])))
+        wgs = 1
+        for ax in "XYZ":  # every axis: the split attention kernel's grid is (split, query head of the group, KV head)
+            wgs *= int(r.get("Grid_Size_" + ax, 1) or 1) // max(1, int(r.get("Workgroup_Size_" + ax, 1) or 1))
         d = en - st
         a = agg[(short(r["Kernel_Name"]), wgs)]
         a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
