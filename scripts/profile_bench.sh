@@ -32,7 +32,7 @@ fi
 find "$OUT" -name "*.db" -delete
 python scripts/summarize_prof.py "$OUT" "${MODEL:-7B}" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
-tail -1 "$OUT/trace.log" > "$OUT/bench_line_under_trace.json"
+grep '^{"metric"' "$OUT/trace.log" | tail -1 > "$OUT/bench_line_under_trace.json"
 # keep the merge-back small: drop the big traces, keep stats + counters aggregated by the summary
 find "$OUT" -name "*kernel_trace.csv" -size +8M -delete
 find "$OUT" -name "*counter_collection.csv" -size +8M -delete
