@@ -303,7 +303,9 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
     const int n_kv, const float scale, unsigned long long* __restrict__ phase, const int exp,
     unsigned* __restrict__ ticket, uint16_t* __restrict__ y, unsigned long long* __restrict__ mask_out, const float mask_tau) {
     constexpr int NW = NT / 64, hd = HD, SL = HD / 8, RW = 64 / SL;
-    constexpr int PF = 4, STEP = NW * RW;
+    // PF row groups of K and of V leave before *pos is known; a workgroup with more than PF groups in range (cache positions
+    // beyond PF x STEP x nsplit) keeps RD groups of each in flight from the moment it knows (rolling refill, see below)
+    constexpr int PF = 4, RD = 8, STEP = NW * RW;
     __shared__ unsigned fold_flag;
     const bool fold = ticket != nullptr;  // merge folded into this launch (fold_merge): partials are published write-through
     const unsigned long long t_entry = wall_clock64();
@@ -326,12 +328,14 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
     const int ds = lane % SL, rw = lane / SL;
     const int rbase = wave * RW + rw;                  // row inside a step
     auto row_of = [&](const int i) { return (sp + i * nsplit) * STEP + rbase; };  // local step i -> cache row
-    u32x4 kreg[PF], vreg[PF];
+    u32x4 kreg[RD], vreg[RD];
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
         const size_t off = (size_t)min(row_of(i), max_seq - 1) * hd + ds * 8;
         kreg[i] = *reinterpret_cast<const u32x4*>(kc + off);
         vreg[i] = *reinterpret_cast<const u32x4*>(vc + off);
+        // group by group: the first two loads leave after the first group's address arithmetic, not after all four groups'
+        __builtin_amdgcn_sched_barrier(0);
     }
     // q, k, v of this head: the rounded projection, or its fp32 split-K slabs, interleaved [col][(nslabs + 3) & ~3],
     // summed in slice order and rounded once here (what the ordered reduce launch would have written)
@@ -385,6 +389,19 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
         return;
     }
     const int nsteps = ((n + STEP - 1) / STEP - sp + nsplit - 1) / nsplit;  // local steps with a row in range
+    // More row groups than the blind prefetch covers (workgroup-uniform): groups PF .. RD-1 of K are requested ahead of the
+    // score loop, V's right behind it, and both loops refill a register the moment they have consumed it — RD loads of the
+    // stream in flight per lane until the rows run out.  (Until round 4 the groups past PF were loaded one at a time,
+    // `global_load; s_waitcnt vmcnt(0)` per group in the ISA: a memory round trip per row group; same box, 7B heads, split +
+    // merge launch: 4096 positions x 8 splits 21.1 -> 19.3 us, x 4 splits 30.2 -> 21.6 us, 512 positions x 4 11.5 -> 9.9 us,
+    // profiles/r04_attention_context_sweep.txt.)  Rows past the end are clamped to row n - 1: every lane then reads the same
+    // line, no HBM traffic, and the loads stay unconditional so that the compiler's vmcnt bookkeeping stays exact
+    // (`s_waitcnt vmcnt(7)` in the steady state).  Measured and not kept: K's and V's second halves requested together
+    // (K's registers are still live: 20.1 us at 4096 x 8); both requested unconditionally where *pos arrives in the 16-wave
+    // instantiations (21.0 us, and 546 against 554 tok/s at ~1000 positions where the 8 extra loads buy nothing).
+    const bool rolling = nsteps > PF;
+    auto k_roll = [&](const int i) { return *reinterpret_cast<const u32x4*>(kc + (size_t)min(row_of(i), n - 1) * hd + ds * 8); };
+    auto v_roll = [&](const int i) { return *reinterpret_cast<const u32x4*>(vc + (size_t)min(row_of(i), n - 1) * hd + ds * 8); };
     const bool has_new = !ROPED && ((pos / STEP) % nsplit) == sp;  // this workgroup's rows include the token being decoded
     if (rot) {
         const float c = bits_to_float(rope[((size_t)pos * (hd / 2) + tid) * 2], BF16);
@@ -442,12 +459,27 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
             lmax = fmaxf(lmax, sv);
         }
     };
+    if (!rolling) {
 #pragma unroll
-    for (int i = 0; i < PF; ++i)
-        if (i < nsteps) score_row(i, kreg[i]);  // workgroup-uniform guard
-#pragma unroll 4
-    for (int i = PF; i < nsteps; ++i)
-        score_row(i, *reinterpret_cast<const u32x4*>(kc + (size_t)min(row_of(i), max_seq - 1) * hd + ds * 8));
+        for (int i = 0; i < PF; ++i)
+            if (i < nsteps) score_row(i, kreg[i]);  // workgroup-uniform guard
+    } else {
+        // (issued inside this branch, not where *pos arrives: after a conditional issue the compiler's merged wait counts
+        // make every later wait of the shared code drain these loads too)
+#pragma unroll
+        for (int i = PF; i < RD; ++i) kreg[i] = k_roll(i);
+        for (int i0 = 0; i0 < nsteps; i0 += RD) {
+#pragma unroll
+            for (int u = 0; u < RD; ++u) {
+                if (i0 + u < nsteps) score_row(i0 + u, kreg[u]);
+                kreg[u] = k_roll(i0 + u + RD);  // RD groups ahead, into the register just consumed
+            }
+        }
+        // V groups PF .. RD-1: in flight across the softmax (K's registers are free now; asking for them together with K's
+        // costs 32 more VGPRs through the score loop: spills at 16 waves per workgroup)
+#pragma unroll
+        for (int i = PF; i < RD; ++i) vreg[i] = v_roll(i);
+    }
     if (exp & 2) {  // A/B: the round-1 form (six ds_bpermute round trips)
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, d));
@@ -494,12 +526,19 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
             }
         }
     };
+    if (!rolling) {
 #pragma unroll
-    for (int i = 0; i < PF; ++i)
-        if (i < nsteps) pv_row(i, vreg[i]);
-#pragma unroll 4
-    for (int i = PF; i < nsteps; ++i)
-        pv_row(i, *reinterpret_cast<const u32x4*>(vc + (size_t)min(row_of(i), max_seq - 1) * hd + ds * 8));
+        for (int i = 0; i < PF; ++i)
+            if (i < nsteps) pv_row(i, vreg[i]);
+    } else {
+        for (int i0 = 0; i0 < nsteps; i0 += RD) {
+#pragma unroll
+            for (int u = 0; u < RD; ++u) {
+                if (i0 + u < nsteps) pv_row(i0 + u, vreg[u]);
+                vreg[u] = v_roll(i0 + u + RD);
+            }
+        }
+    }
     if (exp & 4) {
         for (int off = SL; off < 64; off <<= 1) {
 #pragma unroll

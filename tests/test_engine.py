@@ -626,6 +626,58 @@ def test_sampler_window_and_radix_kernels_pick_the_same_tokens(dtype, V, law):
             assert set(outs[0]) == {777}
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_decode_attention_roped_long_context(dtype):
+    """teal_decode_attention_split_roped (rotated q in, the token's k / v rows already in the caches) against torch at cache
+    lengths on both sides of what the blind K / V prefetch covers (4 row groups per workgroup): past it the kernel keeps 8 row
+    groups of K and of V in flight and refills each register as it is consumed (round 4) — one, several and partial rounds of
+    that loop, 4- and 16-wave workgroups, both head sizes, grouped heads.  Rows past the position hold NaN: a clamped or
+    stray read that reached the sums would show."""
+    from teal_amd import _lib, runtime
+    L = _lib.load()
+    runtime.init()
+    code = runtime.dtype_code(dtype)
+    #          heads kv  hd   pos   S    nsplit      (row groups per workgroup = ceil(ceil((pos + 1) / step) / nsplit))
+    cases = ((32, 32, 128, 235, 333, 4),     # the headline's launch: 16-row groups, 4 per workgroup, no refill
+             (32, 32, 128, 300, 333, 4),     # same launch one group further: 5
+             (8, 8, 128, 511, 512, 4),       # 4-wave workgroups, 8 groups: one full round of the loop
+             (8, 8, 128, 2047, 4096, 8),     # 16-wave workgroups, 64-row groups: exactly 4 (no refill)
+             (8, 8, 128, 2048, 4096, 8),     # ... and 5 in ONE workgroup of each head only
+             (8, 8, 128, 3800, 4096, 8),     # bench.py's long-context point: 8
+             (16, 4, 64, 4095, 4096, 4),     # head_dim 64 (32-row groups at 4 waves do not apply: 16 waves, 128-row groups), grouped heads
+             (8, 2, 128, 8191, 8192, 8),     # 16 groups: two rounds
+             (4, 4, 64, 5000, 8192, 3),      # ragged: 14 groups of 128 rows over 3 workgroups (5 / 5 / 4)
+             (8, 8, 128, 0, 4096, 8), (8, 1, 128, 63, 2048, 4), (8, 8, 128, 64, 2048, 4))
+    for n_head, n_kv, hd, pos, S, nsplit in cases:
+        g = torch.Generator(device=DEV).manual_seed(pos + hd + nsplit)
+        q = (torch.randn(n_head * hd, device=DEV, generator=g) * 0.5).to(dtype)
+        kc = (torch.randn(n_kv, S, hd, device=DEV, generator=g) * 0.5).to(dtype)
+        vc = (torch.randn(n_kv, S, hd, device=DEV, generator=g) * 0.5).to(dtype)
+        kc[:, pos + 1:] = float("nan")
+        vc[:, pos + 1:] = float("nan")
+        kc0, vc0 = kc.clone(), vc.clone()
+        p = torch.tensor([pos], device=DEV, dtype=torch.int32)
+        y = torch.empty(n_head * hd, device=DEV, dtype=dtype)
+        m = torch.zeros(n_head * hd // 64, device=DEV, dtype=torch.int64)
+        ws = torch.full((n_head * nsplit * (hd + 2),), float("nan"), device=DEV, dtype=torch.float32)
+        assert L.teal_decode_attention_split_roped(q.data_ptr(), p.data_ptr(), kc.data_ptr(), vc.data_ptr(), y.data_ptr(), m.data_ptr(),
+                                                   0.02, n_head, n_kv, hd, S, nsplit, ws.data_ptr(), ws.numel() * 4, code, None, 0,
+                                                   runtime.stream_ptr()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(kc.view(torch.int16), kc0.view(torch.int16)) and torch.equal(vc.view(torch.int16), vc0.view(torch.int16))
+        rep = n_head // n_kv
+        K = kc[:, :pos + 1].repeat_interleave(rep, dim=0).float()
+        V = vc[:, :pos + 1].repeat_interleave(rep, dim=0).float()
+        sc = torch.einsum("hd,htd->ht", q.view(n_head, hd).float(), K) / hd ** 0.5
+        want = torch.einsum("ht,htd->hd", torch.softmax(sc.to(dtype).float(), dim=-1), V).reshape(-1)
+        tol = 4e-3 if dtype == torch.float16 else 3e-2
+        assert torch.isfinite(y.float()).all(), (n_head, n_kv, hd, pos, S, nsplit)
+        assert torch.allclose(y.float(), want, atol=tol, rtol=tol), (n_head, n_kv, hd, pos, S, nsplit, float((y.float() - want).abs().max()))
+        bits = (y.float().abs() > 0.02).view(-1, 64)
+        got = torch.stack([(m >> i) & 1 for i in range(64)], dim=1).bool()
+        assert torch.equal(bits, got)
+
+
 @pytest.mark.parametrize("name,dtype", [("7B", torch.float16), ("7B", torch.bfloat16), ("70B", torch.float16)])
 def test_rope_epilogue_equals_attention_side_rope(name, dtype):
     """TEAL_OUT_QKV_ROPE (RoPE of q / the new k row and the KV-cache append in the wqkv launch's epilogue, then
