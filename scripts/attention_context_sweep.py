@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--voff", type=int, default=0, help="shift every V cache this many bytes into its allocation (DRAM channel phase of K vs V)")
     ap.add_argument("--models", nargs="*", default=["7B", "8B", "70B"])
     ap.add_argument("--ctx", type=int, nargs="*", default=[1024, 4096, 16384])
+    ap.add_argument("--pos", type=int, default=0, help="decode position inside the cache (default: the cache's last but one row); a position well "
+                    "inside a long cache shows what a launch reads past the sequence")
     ap.add_argument("--fold", type=int, default=0, help="1: merge folded into the split launch (prepared workspace); 0: split + merge launch")
     a = ap.parse_args()
     L = _lib.load(); runtime.init()
@@ -32,7 +34,7 @@ def main():
         if name not in a.models:
             continue
         for S in a.ctx:
-            pos = S - 2
+            pos = min(a.pos, S - 2) if a.pos > 0 else S - 2
             nrot = max(2, min(16, int(600e6 // (n_kv * S * hd * 4)) + 1))
             kcs = [torch.randn(n_kv, S, hd, device="cuda").to(dt) for _ in range(nrot)]
             vcs = []
@@ -46,7 +48,8 @@ def main():
             y = torch.empty(n_head * hd, device="cuda", dtype=dt)
             p = torch.tensor([pos], device="cuda", dtype=torch.int32)
             kv_bytes = n_kv * (pos + 1) * hd * 2 * 2
-            line = f"{name:>3} heads {n_head}/{n_kv} ctx {S:>5} ({kv_bytes / 1e6:6.1f} MB K/V)"
+            ptag = f" pos {pos}" if a.pos > 0 else ""
+            line = f"{name:>3} heads {n_head}/{n_kv} ctx {S:>5}{ptag} ({kv_bytes / 1e6:6.1f} MB K/V)"
             for ns in a.splits:
                 ws = torch.zeros(n_head * ns * (hd + 2), device="cuda", dtype=torch.float32)
                 st = torch.cuda.Stream()

@@ -647,7 +647,7 @@ __global__ __launch_bounds__(NT) void decode_attention_gqa_kernel(
     const float scale, const int qkv_nslabs, const int lrows, unsigned* __restrict__ ticket, uint16_t* __restrict__ y,
     unsigned long long* __restrict__ mask_out, const float mask_tau) {
     constexpr int NW = NT / 64, hd = HD, SL = HD / 8, RW = 64 / SL;
-    constexpr int PF = 4, STEP = NW * RW;
+    constexpr int PF = 4, RD = 8, STEP = NW * RW;  // blind prefetch depth; depth of the stream once *pos is known
     __shared__ unsigned fold_flag;
     const bool fold = ticket != nullptr;  // merge folded into this launch (fold_merge): partials are published write-through
     constexpr int NPAIR = (REP + 2) * (HD / 2), NITEM = (NPAIR + NT - 1) / NT;  // q pairs of REP heads, k pairs, v pairs
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(NT) void decode_attention_gqa_kernel(
     auto row_of = [&](const int i) { return (sp + i * nsplit) * STEP + rbase; };
     auto k_at = [&](const int i) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kc + (size_t)min(row_of(i), max_seq - 1) * hd + ds * 8)); };
     auto v_at = [&](const int i) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vc + (size_t)min(row_of(i), max_seq - 1) * hd + ds * 8)); };
-    u32x4 kb[PF], vb[PF];  // the first PF row groups of K and of V leave at the first instruction
+    u32x4 kb[RD], vb[RD];  // the first PF row groups of K and of V leave at the first instruction
 #pragma unroll
     for (int i = 0; i < PF; ++i) kb[i] = k_at(i);
 #pragma unroll
@@ -717,6 +717,8 @@ __global__ __launch_bounds__(NT) void decode_attention_gqa_kernel(
     }
     const int nsteps = ((n + STEP - 1) / STEP - sp + nsplit - 1) / nsplit;
     const bool has_new = ((pos / STEP) % nsplit) == sp;
+    auto k_roll = [&](const int i) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kc + (size_t)min(row_of(i), n - 1) * hd + ds * 8)); };
+    auto v_roll = [&](const int i) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vc + (size_t)min(row_of(i), n - 1) * hd + ds * 8)); };
 #pragma unroll
     for (int u = 0; u < NITEM; ++u) {
         const int it = u * NT + tid;
@@ -748,31 +750,45 @@ __global__ __launch_bounds__(NT) void decode_attention_gqa_kernel(
 #pragma unroll
         for (int r = 0; r < REP; ++r) qp[r] = *reinterpret_cast<const u32x4*>(qsb + r * (hd / 2) + ds * 4);
         const u32x4 knw = *reinterpret_cast<const u32x4*>(knb + ds * 4);
-        for (int i0 = 0; i0 < nsteps; i0 += PF) {
+        auto k_step = [&](const int i, u32x4 w) {
+            const int t = row_of(i);
+            if (t == pos) w = knw;
+            float a[REP];
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int i = i0 + u;
-                u32x4 w = kb[u];
-                kb[u] = k_at(i + PF);  // PF row groups ahead (clamped address past the end: harmless, unused)
-                if (i < nsteps) {  // workgroup-uniform
-                    const int t = row_of(i);
-                    if (t == pos) w = knw;
-                    float a[REP];
+            for (int r = 0; r < REP; ++r) {
+                float acc = 0.0f;
 #pragma unroll
-                    for (int r = 0; r < REP; ++r) {
-                        float acc = 0.0f;
+                for (int j = 0; j < 4; ++j) acc = dot2_acc<BF16>(qp[r][j], w[j], acc);
+                a[r] = acc;
+            }
+            const float tot = gqa_reduce_scatter<REP, SL>(a, lane);
+            const float sv = bits_to_float(float_to_bits<BF16>(tot * scale), BF16);
+            if (t < n) {
+                sc[(i * STEP + rbase) * REP + myhead] = sv;  // the lanes that share a head write the same value
+                lmax = fmaxf(lmax, sv);
+            }
+        };
+        // Past the blind prefetch (more than PF row groups in range, workgroup-uniform): RD groups of the stream in flight per
+        // lane, a register refilled when consumed, rows past the position clamped to row n - 1 (one line for every lane: no HBM
+        // traffic — the blind form's clamp, max_seq - 1, made every refill past the position fetch real rows: up to
+        // PF x STEP x nsplit rows per phase whenever the cache is longer than the sequence).  Same structure as
+        // decode_attention_split_kernel (round 4); inside the prefetch no refill is requested at all.
+        if (nsteps <= PF) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc = dot2_acc<BF16>(qp[r][j], w[j], acc);
-                        a[r] = acc;
-                    }
-                    const float tot = gqa_reduce_scatter<REP, SL>(a, lane);
-                    const float sv = bits_to_float(float_to_bits<BF16>(tot * scale), BF16);
-                    if (t < n) {
-                        sc[(i * STEP + rbase) * REP + myhead] = sv;  // the lanes that share a head write the same value
-                        lmax = fmaxf(lmax, sv);
-                    }
+            for (int u = 0; u < PF; ++u)
+                if (u < nsteps) k_step(u, kb[u]);  // workgroup-uniform guard
+        } else {
+#pragma unroll
+            for (int u = PF; u < RD; ++u) kb[u] = k_roll(u);
+            for (int i0 = 0; i0 < nsteps; i0 += RD) {
+#pragma unroll
+                for (int u = 0; u < RD; ++u) {
+                    if (i0 + u < nsteps) k_step(i0 + u, kb[u]);
+                    kb[u] = k_roll(i0 + u + RD);
                 }
             }
+#pragma unroll
+            for (int u = PF; u < RD; ++u) vb[u] = v_roll(u);  // in flight across the softmax
         }
     }
     // max per head: lanes with the same `myhead` differ in the row group bits (lane / SL) and in the duplicated low bits
@@ -806,34 +822,39 @@ __global__ __launch_bounds__(NT) void decode_attention_gqa_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[r][j] = (f32x2){0.0f, 0.0f};
     const u32x4 vnw = *reinterpret_cast<const u32x4*>(vnb + ds * 4);
-    for (int i0 = 0; i0 < nsteps; i0 += PF) {
+    auto v_step = [&](const int i, u32x4 w) {
+        const int t = row_of(i);
+        if (t < n) {
+            if (t == pos) w = vnw;
+            f32x2 vf[4];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int i = i0 + u;
-            u32x4 w = vb[u];
-            vb[u] = v_at(i + PF);
-            if (i < nsteps) {
-                const int t = row_of(i);
-                if (t < n) {
-                    if (t == pos) w = vnw;
-                    f32x2 vf[4];
+            for (int j = 0; j < 4; ++j) vf[j] = (f32x2){bits_to_float(w[j] & 0xFFFFu, BF16), bits_to_float(w[j] >> 16, BF16)};
+            float pr[REP];
+            const f32x4* pp = reinterpret_cast<const f32x4*>(sc + (size_t)(i * STEP + rbase) * REP);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) vf[j] = (f32x2){bits_to_float(w[j] & 0xFFFFu, BF16), bits_to_float(w[j] >> 16, BF16)};
-                    float pr[REP];
-                    const f32x4* pp = reinterpret_cast<const f32x4*>(sc + (size_t)(i * STEP + rbase) * REP);
+            for (int q4 = 0; q4 < REP / 4; ++q4) {
+                const f32x4 pv = pp[q4];
 #pragma unroll
-                    for (int q4 = 0; q4 < REP / 4; ++q4) {
-                        const f32x4 pv = pp[q4];
+                for (int e = 0; e < 4; ++e) pr[q4 * 4 + e] = pv[e];
+            }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) pr[q4 * 4 + e] = pv[e];
-                    }
+            for (int r = 0; r < REP; ++r) {
+                const f32x2 p2 = (f32x2){pr[r], pr[r]};
 #pragma unroll
-                    for (int r = 0; r < REP; ++r) {
-                        const f32x2 p2 = (f32x2){pr[r], pr[r]};
+                for (int j = 0; j < 4; ++j) o[r][j] += p2 * vf[j];
+            }
+        }
+    };
+    if (nsteps <= PF) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) o[r][j] += p2 * vf[j];
-                    }
-                }
+        for (int u = 0; u < PF; ++u)
+            if (u < nsteps) v_step(u, vb[u]);
+    } else {
+        for (int i0 = 0; i0 < nsteps; i0 += RD) {
+#pragma unroll
+            for (int u = 0; u < RD; ++u) {
+                if (i0 + u < nsteps) v_step(i0 + u, vb[u]);
+                vb[u] = v_roll(i0 + u + RD);
             }
         }
     }
