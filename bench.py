@@ -65,6 +65,9 @@ def parse():
                     "for long-context experiments; 0 = the reference's value (2048 for 7B)")
     ap.add_argument("--experiment", type=int, default=0, help="teal_set_experiment mask (A/B switches, include/teal_hip.h; 0 = production)")
     ap.add_argument("--wave-local", type=int, default=1, help="wave-local compaction (A/B switch)")
+    ap.add_argument("--graph-tokens", type=int, default=1,
+                    help="decode steps per hipGraph replay (token, position and RNG counter are device-resident, so a graph can span "
+                         "several tokens; the timed region still runs exactly --steps steps, the remainder one token per replay)")
     ap.add_argument("--profile-markers", action="store_true",
                     help="bracket the timed region with one marker dispatch each (compact_kernel on 64 elements) so that "
                          "scripts/summarize_prof.py can restrict a rocprofv3 trace / counter pass to the timed hipGraph replays")
@@ -118,16 +121,23 @@ def profile_marker():
 
 def timed_decode(step_fn, steps, warmup, world, markers=False):
     """W untimed steps, then exactly K steps between barrier+synchronize on both sides."""
-    for _ in range(warmup):
-        step_fn()
+    run = getattr(step_fn, "run", None)  # engine stepper: run(n) = exactly n decode steps (--graph-tokens: several per replay)
+    if run is not None:
+        run(warmup)
+    else:
+        for _ in range(warmup):
+            step_fn()
     _sync()
     if markers:
         profile_marker()
     barrier(world)
     _sync()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step_fn()
+    if run is not None:
+        run(steps)
+    else:
+        for _ in range(steps):
+            step_fn()
     _sync()
     barrier(world)
     t = time.perf_counter() - t0
@@ -543,6 +553,8 @@ def main():
         out["dtype"] = out["dtype"] + " activations, int4 group-quantised weights (g32), 16-bit lm_head"
         out["config"]["workload"] += ", int4 group-quantised projections (g32), 16-bit lm_head"
     out.update(info.get("report", {}))
+    if info.get("graph_tokens", 1) > 1:
+        out["config"]["graph_tokens"] = info["graph_tokens"]  # decode steps per hipGraph replay (device-resident loop state)
     if rank == 0 and mode == "engine":
         eng = info["engine"]
         # achieved kept fraction of all seven projections on the DECODE activations of one more step

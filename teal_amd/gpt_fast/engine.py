@@ -224,7 +224,7 @@ class DecodeEngine:
         self.tok_buf = torch.zeros(1, 1, dtype=torch.int32, device=dev)   # loop-carried token
         self.pos_buf = torch.zeros(1, dtype=torch.int32, device=dev)      # loop-carried position
         self.history = torch.zeros(max(8, model.max_seq_length), dtype=torch.int32, device=dev)
-        self._graph, self._graph_key = None, None
+        self._graph, self._graph_key, self._graphs = None, None, {}
         self._build(thresholds)
 
     # ---- static launch descriptors (pointers never change: hipGraph-capture friendly) -------------
@@ -529,9 +529,16 @@ class DecodeEngine:
         logits = self(self.tok_buf, self.pos_buf)
         self.sample_fused(logits, temperature, top_k, feed=True)
 
-    def capture_loop(self, temperature: float, top_k: Optional[int]):
-        key = (float(temperature), int(top_k or 0))
+    def capture_loop(self, temperature: float, top_k: Optional[int], tokens: int = 1):
+        """hipGraph of `tokens` consecutive decode steps (token, position and RNG counter stay on the device between them, so
+        a graph can span any number of tokens; each replay costs one host launch and one graph boundary on the GPU)."""
+        key = (float(temperature), int(top_k or 0), int(tokens))
         if self._graph is not None and self._graph_key == key:
+            return self._graph
+        if self._graph is None:
+            self._graphs = {}
+        if key in self._graphs:
+            self._graph, self._graph_key = self._graphs[key], key
             return self._graph
         state = (self.tok_buf.clone(), self.pos_buf.clone(), self.rng_state.clone())
         s = torch.cuda.Stream()
@@ -539,10 +546,13 @@ class DecodeEngine:
         with torch.cuda.stream(s):  # warm-up outside capture (KV rows it writes are rewritten by the real run)
             self._self_step(temperature, top_k)
         torch.cuda.current_stream().wait_stream(s)
+        self.tok_buf.copy_(state[0]); self.pos_buf.copy_(state[1]); self.rng_state.copy_(state[2])
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._self_step(temperature, top_k)
+            for _ in range(int(tokens)):
+                self._self_step(temperature, top_k)
         self.tok_buf.copy_(state[0]); self.pos_buf.copy_(state[1]); self.rng_state.copy_(state[2])
+        self._graphs[key] = g
         self._graph, self._graph_key = g, key
         return g
 
@@ -610,6 +620,8 @@ def make_engine_stepper(model: Transformer, a, ths: Optional[List[Dict[str, floa
             ths = eng.calibrate_on_decode(sp, tok, npr, span)
         eng.tok_buf.copy_(tok.view(1, 1))
         eng.pos_buf.fill_(npr)
+        U = max(1, int(getattr(a, "graph_tokens", 1)))
+        graph_u = eng.capture_loop(0.8, 200, U) if U > 1 else None
         graph = eng.capture_loop(0.8, 200)
     # capture_loop replays the step a few times: read back where the stream stands
     state = {"pos": int(eng.pos_buf.item())}
@@ -624,7 +636,20 @@ def make_engine_stepper(model: Transformer, a, ths: Optional[List[Dict[str, floa
         graph.replay()
         state["pos"] += 1
 
-    return step, {"thresholds": ths, "engine": eng, "prefill_s": prefill_s, "first_token": tok, "pos0": npr, "span": span}
+    def run(n):
+        """exactly n decode steps: replays of the U-token graph, the remainder one token at a time"""
+        while n > 0:
+            if graph_u is not None and n >= U and state["pos"] + U < max_seq:
+                graph_u.replay()
+                state["pos"] += U
+                n -= U
+            else:
+                step()
+                n -= 1
+
+    step.run = run
+    return step, {"thresholds": ths, "engine": eng, "prefill_s": prefill_s, "first_token": tok, "pos0": npr, "span": span,
+                  "graph_tokens": U}
 
 
 def pick_engine(model: Transformer, need_caches: bool = True):
