@@ -56,3 +56,68 @@ def test_shard_ranges():
         tp.shard_range(10, 0, 4)
     with pytest.raises(ValueError):
         tp.shard_features(10, 0, 2, [4, 4])
+
+
+def test_int8_weight_only_linears_shard_with_their_scales():
+    """column-wise: the rank's output features AND their per-channel scales; row-wise: input features, every scale kept
+    (gpt-fast/tp.py:55-106 shards `scales` along with the weight of a WeightOnlyInt8Linear).  The sharded linears applied to
+    the rank's inputs reproduce the unsharded int8 linear: concatenation (column-wise), sum over ranks (row-wise)."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from teal_amd.gpt_fast import tp
+    from teal_amd.quantize import WeightOnlyInt8Linear
+    g = torch.Generator().manual_seed(3)
+    lin = torch.nn.Linear(64, 96, bias=False)
+    lin.weight.data = torch.randn(96, 64, generator=g)
+    x = torch.randn(1, 1, 64, generator=g)
+    full = WeightOnlyInt8Linear.from_linear(lin)
+    want = full(x)
+    cols, rows = [], []
+    for rank in range(2):
+        c = WeightOnlyInt8Linear.from_linear(lin)
+        tp.shard_linear(c, "colwise", rank, 2, [32, 32, 32])  # q | k | v thirds: the rank's half of each
+        assert tuple(c.weight.shape) == (48, 64) and tuple(c.scales.shape) == (48,) and c.out_features == 48
+        cols.append(c(x))
+        r = WeightOnlyInt8Linear.from_linear(lin)
+        tp.shard_linear(r, "rowwise", rank, 2)
+        assert tuple(r.weight.shape) == (96, 32) and tuple(r.scales.shape) == (96,) and r.in_features == 32
+        rows.append(r(x[..., rank * 32:(rank + 1) * 32]))
+    got_c = torch.cat([torch.cat([cols[0][..., 16 * p:16 * (p + 1)], cols[1][..., 16 * p:16 * (p + 1)]], dim=-1) for p in range(3)], dim=-1)
+    assert torch.equal(got_c, want)
+    assert torch.allclose(rows[0] + rows[1], want, rtol=1e-5, atol=1e-5)
+
+
+def test_bench_runs_exactly_the_requested_steps_through_multi_token_graphs(monkeypatch):
+    """bench.py's timed region hands the step count to the engine stepper's run(n): n decode steps whatever the number of tokens a
+    graph replay spans (remainder one token per replay), never past the cache."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class Stepper:
+        def __init__(self, U, max_seq):
+            self.U, self.max_seq, self.pos, self.tokens, self.replays = U, max_seq, 6, 0, []
+
+        def __call__(self):
+            if self.pos + 1 >= self.max_seq:
+                self.pos = 6
+            self.pos += 1
+            self.tokens += 1
+            self.replays.append(1)
+
+        def run(self, n):  # the loop of engine.make_engine_stepper, on counters
+            while n > 0:
+                if self.U > 1 and n >= self.U and self.pos + self.U < self.max_seq:
+                    self.pos += self.U
+                    self.tokens += self.U
+                    self.replays.append(self.U)
+                    n -= self.U
+                else:
+                    self()
+                    n -= 1
+
+    monkeypatch.setattr(bench, "_sync", lambda: None)
+    for U, steps, warm in ((1, 20, 5), (4, 20, 5), (8, 203, 7), (4, 3, 0)):
+        s = Stepper(U, 64)
+        bench.timed_decode(s, steps, warm, 1)
+        assert s.tokens == steps + warm and s.pos < 64
+        assert max(s.replays) <= U
