@@ -100,6 +100,8 @@ class DecodeEngine:
             if not all(i4[:-1]) or i4[-1] or model.output.weight.dtype not in (torch.float16, torch.bfloat16):
                 return "int4 blocks need every projection int4 group-quantised and the lm_head in fp16 / bf16"
             kvw = cfg.n_local_heads * cfg.head_dim
+            if int(getattr(model, "tp_world", 1)) > 1:
+                return "int4 group-quantised blocks are not sharded (tp.shard_linear)"
             for j, lin in enumerate(lins[:-1]):
                 if not int4_kernel_supports(lin.in_features, lin.out_features, lin.groupsize, kvw if j % 5 == 0 else 0):
                     return f"int4 linear {lin.in_features}x{lin.out_features} g{lin.groupsize} is outside the int4 kernel's shape contract"
@@ -114,9 +116,15 @@ class DecodeEngine:
         if cfg.head_dim not in (64, 128):
             return f"head_dim {cfg.head_dim} (the attention launches are built for 64 and 128)"
         kv = cfg.n_local_heads * cfg.head_dim
-        if cfg.dim % 64 or cfg.dim > 16384 or cfg.dim != cfg.n_head * cfg.head_dim:
-            return f"dim {cfg.dim} (need a multiple of 64, <= 16384, = n_head * head_dim)"
-        if cfg.intermediate_size % 8 or cfg.intermediate_size > 65536 or kv % 8 or cfg.vocab_size % 8:
+        # under tensor parallelism (tp.apply_tp) cfg.n_head / n_local_heads and the projections' widths are the RANK's: q is
+        # n_head * head_dim = dim / world wide, the residual stream stays dim wide
+        world = int(getattr(model, "tp_world", 1))
+        if cfg.dim % 64 or cfg.dim > 16384 or cfg.dim != cfg.n_head * cfg.head_dim * world:
+            return f"dim {cfg.dim} (need a multiple of 64, <= 16384, = n_head * head_dim [* TP world])"
+        inter = model.layers[0].feed_forward.w1.out_features
+        if (cfg.n_head * cfg.head_dim) % 64:
+            return f"rank-local query width {cfg.n_head * cfg.head_dim} must be a multiple of 64"
+        if inter % 8 or inter > 65536 or kv % 8 or cfg.vocab_size % 8:
             return "intermediate_size / kv width / vocab_size must be multiples of 8 (intermediate_size <= 65536)"
         if not need_caches:  # a static verdict (shapes and weight formats), before setup_caches has run
             return None if model.output.weight.is_cuda else "model is not on a HIP device"
@@ -147,9 +155,22 @@ class DecodeEngine:
         self.int8 = lins[0].weight.dtype == torch.int8    # int8 weight-only linears (teal_amd/quantize.py)
         self.dtype, self.code = dt, runtime.dtype_code(dt)
         assert model.freqs_cis is not None, "call model.setup_caches() first"
-        dim, inter, hd = cfg.dim, cfg.intermediate_size, cfg.head_dim
-        kv = cfg.n_local_heads * hd
-        self.dim, self.inter, self.kv, self.nqkv = dim, inter, kv, dim + 2 * kv
+        # widths: `dim` = the residual stream (replicated under tensor parallelism), `qdim` / `kv` / `inter` = this rank's query,
+        # key-value and intermediate columns (= the model's own without TP: tp.apply_tp divided cfg.n_head / n_local_heads and
+        # sliced the linears, gpt-fast/tp.py:110-140)
+        dim, hd = cfg.dim, cfg.head_dim
+        inter = model.layers[0].feed_forward.w1.out_features
+        qdim, kv = cfg.n_head * hd, cfg.n_local_heads * hd
+        self.dim, self.qdim, self.inter, self.kv, self.nqkv = dim, qdim, inter, kv, qdim + 2 * kv
+        for layer in model.layers:
+            at_, ff_ = layer.attention, layer.feed_forward
+            shapes = ((at_.wqkv.out_features, at_.wqkv.in_features), (at_.wo.out_features, at_.wo.in_features),
+                      (ff_.w1.out_features, ff_.w1.in_features), (ff_.w3.out_features, ff_.w3.in_features),
+                      (ff_.w2.out_features, ff_.w2.in_features))
+            assert shapes == ((self.nqkv, dim), (dim, qdim), (inter, dim), (inter, dim), (dim, inter)), shapes
+        # the block's two partial outputs (wo, down) summed over the ranks: reduce(fp32 slab buffer) in place, None = one rank
+        self.reduce = getattr(model, "tp_reduce", None)
+        self.tp_world = int(getattr(model, "tp_world", 1))
         for layer in model.layers:
             for lin in (layer.attention.wqkv, layer.attention.wo, layer.feed_forward.w1, layer.feed_forward.w3,
                         layer.feed_forward.w2):
@@ -158,9 +179,9 @@ class DecodeEngine:
         to_column_major(model.output)
         e = lambda *shape, dtype=dt: torch.zeros(*shape, device=dev, dtype=dtype)  # noqa: E731
         self.resid = [e(dim), e(dim)]
-        self.qkv, self.y_attn, self.gu = e(self.nqkv), e(dim), e(2 * inter)
+        self.qkv, self.y_attn, self.gu = e(self.nqkv), e(qdim), e(2 * inter)
         self.h_mlp = e(inter)                                                  # silu(gate) * up (PAIR epilogue)
-        self.y_mask = e((dim + 63) // 64, dtype=torch.int64)                   # keep masks of y_attn vs tau_o
+        self.y_mask = e((qdim + 63) // 64, dtype=torch.int64)                  # keep masks of y_attn vs tau_o
         self.h_mask = e((inter + 63) // 64, dtype=torch.int64)                 # keep masks of h_mlp vs tau_down
         # gate|up as one PAIR launch needs whole 64-column chunks and Z small enough for a single list
         can_pair = inter % 64 == 0 and dim % 64 == 0 and (dim + 1) * 4 <= 44 * 1024
@@ -201,13 +222,13 @@ class DecodeEngine:
             self.att_split = ns
         elif self.max_seq <= 1024:
             self.att_split = 4
-        elif self.max_seq <= 4096 and dim <= 8192:
+        elif self.max_seq <= 4096 and qdim <= 8192:
             self.att_split = 8
         elif self.max_seq <= 2048:
             self.att_split = 4
         else:
             self.att_split = min(16, max(2, (256 + cfg.n_head - 1) // cfg.n_head, (self.max_seq + 2047) // 2048))
-        self.att_fused_merge = (self.att_split == 4 and dim <= 16384) or (self.att_split == 8 and dim <= 8192)
+        self.att_fused_merge = (self.att_split == 4 and qdim <= 16384) or (self.att_split == 8 and qdim <= 8192)
         # RoPE + KV-cache append in the epilogue of the wqkv launch (TEAL_OUT_QKV_ROPE: -1.3 % per token on Llama-2-7B @ 50 %,
         # profiles/r04_layer_experiments.txt) wherever that launch runs without split-K (the library reports which way it
         # went) and the per-query-head attention kernel follows (the grouped-query kernel of long contexts rotates itself)
@@ -229,7 +250,7 @@ class DecodeEngine:
 
     # ---- static launch descriptors (pointers never change: hipGraph-capture friendly) -------------
     def _build(self, ths):
-        m, dim, inter, kv, nq = self.model, self.dim, self.inter, self.kv, self.nqkv
+        m, dim, qdim, inter, kv = self.model, self.dim, self.qdim, self.inter, self.kv
         hd_ = self.cfg.head_dim
         A, B = self.resid
         self.stages = []
@@ -251,9 +272,9 @@ class DecodeEngine:
                 ld = lin.weight.stride(0) if self.int4 else lin.weight.stride(1)  # int4: bytes per row of the packed image
                 return (lin.weight.data_ptr(), ld, col0, ncols, tau, y) + sc(lin, col0)
 
-            k1_segs = [seg(at.wqkv, 0, dim, th["q"], self.qkv.data_ptr()),
-                       seg(at.wqkv, dim, kv, th["k"], self.qkv.data_ptr() + 2 * dim),
-                       seg(at.wqkv, dim + kv, kv, th["v"], self.qkv.data_ptr() + 2 * (dim + kv))]
+            k1_segs = [seg(at.wqkv, 0, qdim, th["q"], self.qkv.data_ptr()),
+                       seg(at.wqkv, qdim, kv, th["k"], self.qkv.data_ptr() + 2 * qdim),
+                       seg(at.wqkv, qdim + kv, kv, th["v"], self.qkv.data_ptr() + 2 * (qdim + kv))]
             # split attention: the projection writes fp32 slabs that the attention launch sums itself, so a narrow
             # (GQA) wqkv is row-sliced over all CUs without a reduce launch in between
             k1_out = _out(k1_segs, TEAL_OUT_SLABS, self.s_qkv) if self.att_split else _out(k1_segs, TEAL_OUT_ROUNDED)
@@ -370,7 +391,9 @@ class DecodeEngine:
             _lib.check(rc, "teal_decode_attention")
         cb("after", "attn", i)
         cb("before", "wo", i)
-        self._gemv(k3_in, k3_out, self.dim, self.n_wo)
+        self._gemv(k3_in, k3_out, self.qdim, self.n_wo)
+        if self.reduce is not None:
+            self._reduce_slabs(self.s_wo, self.n_wo.value)
         cb("after", "wo", i)
         k4_in.nslabs = self.n_wo.value
         cb("before", "gate_up", i)
@@ -378,7 +401,17 @@ class DecodeEngine:
         cb("after", "gate_up", i)
         cb("before", "down", i)
         self._gemv(k5_in, k5_out, self.inter, self.n_down)
+        if self.reduce is not None:
+            self._reduce_slabs(self.s_down, self.n_down.value)
         cb("after", "down", i)
+
+    def _reduce_slabs(self, slabs: torch.Tensor, n: int):
+        """Tensor parallelism: the ONE sum over the ranks per attention and per MLP (gpt-fast/tp.py:120-121, 139-140), taken on
+        the fp32 split-K slabs of the row-wise projection [dim][(n + 3) & ~3] before anything is rounded: the consumer's
+        RESID_NORM producer then computes h = resid + round(sum over slices AND ranks) with ONE rounding, exactly the
+        unsharded step's expression (the reference all-reduces each rank's fp16-rounded output).  Every rank launches the
+        same geometry (a pure function of the local shape), so the buffers line up slab for slab."""
+        self.reduce(slabs.view(-1)[: self.dim * ((n + 3) & ~3)])
 
     @torch.no_grad()
     def site_activations(self, idx: torch.Tensor, input_pos: torch.Tensor) -> List[Dict[str, torch.Tensor]]:
@@ -532,6 +565,9 @@ class DecodeEngine:
     def capture_loop(self, temperature: float, top_k: Optional[int], tokens: int = 1):
         """hipGraph of `tokens` consecutive decode steps (token, position and RNG counter stay on the device between them, so
         a graph can span any number of tokens; each replay costs one host launch and one graph boundary on the GPU)."""
+        if self.reduce is not None and not getattr(self.reduce, "capturable", False):
+            raise RuntimeError("this tensor-parallel engine's all-reduce cannot be captured into a hipGraph (gloo / host-staged); "
+                               "decode eagerly (use_graph=False) or run the ranks over RCCL")
         key = (float(temperature), int(top_k or 0), int(tokens))
         if self._graph is not None and self._graph_key == key:
             return self._graph
@@ -565,6 +601,8 @@ class DecodeEngine:
         self.pos_buf.fill_(pos)
         self._calls += 1
         self.rng_state.copy_(torch.tensor([self._seed + self._calls, 0], dtype=torch.int64))
+        if use_graph and self.reduce is not None and not getattr(self.reduce, "capturable", False):
+            use_graph = False  # host-staged all-reduce (gloo): the step cannot live in a hipGraph
         if use_graph:
             g = self.capture_loop(temperature, top_k)
             for _ in range(n):

@@ -69,27 +69,43 @@ def sample(logits: torch.Tensor, temperature: float = 1.0, top_k: Optional[int] 
 # model construction
 # ------------------------------------------------------------------------------------------------
 def build_synthetic_model(name: str, device: str, dtype: torch.dtype, seed: int = 1234, std: float = 0.02,
-                          n_layer: Optional[int] = None) -> Transformer:
-    """Random-init weights N(0, std^2) at the exact shapes of the named architecture."""
+                          n_layer: Optional[int] = None, shard=None) -> Transformer:
+    """Random-init weights N(0, std^2) at the exact shapes of the named architecture.
+
+    `shard(model)` (tensor parallelism: tp.apply_tp) runs on the META model, before any storage exists: a rank then
+    allocates only its slices, and fills each from the full random tensor of that parameter — drawn in the unsharded order
+    from the same seed, so the ranks' weights ARE the slices of the unsharded synthetic model (one fp32 temporary of the
+    largest parameter at a time)."""
     cfg = ModelArgs.from_name(name)
     if n_layer is not None:
         cfg.n_layer = n_layer
     with torch.device("meta"):
         model = Transformer(cfg).to(dtype)
+    full_shape = {pname: tuple(p.shape) for pname, p in model.named_parameters()}
+    if shard is not None:
+        shard(model)
     g = torch.Generator(device=device).manual_seed(seed)
     # storage is allocated ONCE, in the target dtype, and filled in place: Llama-2-70B peaks at its 137 GB of weights plus
     # one fp32 temporary (it used to materialise the fp32 meta model first: 279 GB reserved of the GPU's 288 GB)
     model = model.to_empty(device=device)
+    owner = {id(m.weight): m for m in model.modules() if hasattr(m, "_tp")}
     with torch.no_grad():
         for pname, p in model.named_parameters():
             if pname.endswith("norm.weight"):
                 p.data.fill_(1.0)
-            else:
-                p.data.copy_(torch.randn(p.shape, device=device, dtype=torch.float32, generator=g) * std)
+                continue
+            w = torch.randn(full_shape[pname], device=device, dtype=torch.float32, generator=g) * std
+            if id(p) in owner:  # this rank's rows (column-wise) or columns (row-wise) of the full tensor
+                style, ranges = owner[id(p)]._tp
+                w = torch.cat([w.narrow(0 if style == "colwise" else 1, lo, hi - lo) for lo, hi in ranges], dim=0 if style == "colwise" else 1)
+            p.data.copy_(w)
+            del w
     return model.eval()
 
 
-def load_checkpoint_model(checkpoint_path: Path, device: str, dtype: torch.dtype) -> Transformer:
+def load_checkpoint_model(checkpoint_path: Path, device: str, dtype: torch.dtype, shard=None) -> Transformer:
+    """`shard(model)` (tensor parallelism: tp.apply_tp) runs on the memory-mapped CPU tensors right after the state dict is
+    assigned — before anything moves to the device — like the reference (gpt-fast/generate.py:249-256)."""
     with torch.device("meta"):
         model = Transformer.from_name(checkpoint_path.parent.name)
     if "int8" in str(checkpoint_path):  # gpt-fast/generate.py:239-243: an int8 weight-only checkpoint (quantize.py --mode int8)
@@ -107,6 +123,8 @@ def load_checkpoint_model(checkpoint_path: Path, device: str, dtype: torch.dtype
     if "model" in ckpt and "stories" in str(checkpoint_path):
         ckpt = ckpt["model"]
     model.load_state_dict(ckpt, assign=True)
+    if shard is not None:
+        shard(model)
     if int4:  # packed uint8 weights and bf16 group parameters stay as they are; everything else takes the activation dtype
         model = model.to(device=device)
         for prm in model.parameters():
@@ -184,6 +202,8 @@ def refine_thresholds_on_decode(model: Transformer, sparsities: Dict[str, List[f
     model(toks.view(1, -1), torch.arange(n_prompt, device=dev))
     eng = cls(model, ths)
     ths = eng.calibrate_on_decode(sparsities, toks[-1:].clone(), n_prompt, span)
+    from teal_amd.gpt_fast import tp
+    ths = tp.sync_thresholds(ths)
     for layer, th in zip(model.layers, ths):
         at, ff = layer.attention, layer.feed_forward
         at.thresh_q, at.thresh_k, at.thresh_v, at.thresh_o = th["q"], th["k"], th["v"], th["o"]
@@ -210,7 +230,8 @@ def apply_sparsity(model: Transformer, *, sparsity: float, hist_path: Optional[s
         sparsities = {p: [sparsity] * L for p in PROJS}
     device = model.output.weight.device.type
     if synthetic or hist_path is None:
-        ths = calibrate_thresholds(model, sparsities)
+        from teal_amd.gpt_fast import tp
+        ths = tp.sync_thresholds(calibrate_thresholds(model, sparsities))  # (one tau per site on every rank; no-op without TP)
         for i, layer in enumerate(model.layers):
             monkeypatch_layer(i, layer, sparsity, None, device, thresholds=ths[i])
         if decode_calibration and device == "cuda" and any(float(v) > 0 for vals in sparsities.values() for v in vals):
@@ -416,30 +437,32 @@ def main(args) -> Dict:
     if getattr(args, "interactive", False) and args.synthetic:
         raise SystemExit("--interactive needs a tokenizer (a checkpoint directory), not --synthetic")
     dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[args.precision]
+    # tensor parallelism as in the reference (gpt-fast/generate.py:249-256, tp.py): one process per GPU under
+    # torch.distributed.run; FIRST, so that every rank builds / loads its shard on its own device.  A single process (the
+    # north-star configuration) is untouched
+    from teal_amd.gpt_fast import tp
+    tp_rank = tp.maybe_init_dist()
+    shard = None
+    if tp_rank is not None:
+        device = f"cuda:{torch.cuda.current_device()}"
+        shard = tp.apply_tp  # wqkv / w1 / w3 column-wise, wo / w2 row-wise, one all-reduce per attention and per MLP
+        if tp_rank != 0:
+            import builtins
+            builtins.print = lambda *a, **k: None  # rank 0 reports (tp.py's `print` override)
     from teal_amd import runtime
     runtime.init()
     t0 = time.time()
     if args.synthetic:
-        model = build_synthetic_model(args.synthetic, device, dtype, n_layer=args.n_layer)
+        model = build_synthetic_model(args.synthetic, device, dtype, n_layer=args.n_layer, shard=shard)
         prompt = torch.randint(0, model.config.vocab_size, (6,), device=device, dtype=torch.int,
                                generator=torch.Generator(device=device).manual_seed(7))  # "Hello, my name is" + BOS = 6 ids
         tokenizer = None
     else:
         assert args.checkpoint_path.is_file(), args.checkpoint_path
-        model = load_checkpoint_model(args.checkpoint_path, device, dtype)
+        model = load_checkpoint_model(args.checkpoint_path, device, dtype, shard=shard)
         from teal_amd.gpt_fast.tokenizer import get_tokenizer
         tokenizer = get_tokenizer(args.checkpoint_path.parent / "tokenizer.model", args.checkpoint_path)
         prompt = torch.tensor([tokenizer.bos_id()] + tokenizer.encode(args.prompt), dtype=torch.int, device=device)
-    # tensor parallelism as in the reference (gpt-fast/generate.py:285-289, tp.py): one process per GPU under
-    # torch.distributed.run; a single process (the north-star configuration) is untouched
-    from teal_amd.gpt_fast import tp
-    tp_rank = tp.maybe_init_dist()
-    if tp_rank is not None:
-        tp.apply_tp(model)  # wqkv / w1 / w3 column-wise, wo / w2 row-wise, one all-reduce per attention and per MLP
-        args.engine = False
-        if tp_rank != 0:
-            import builtins
-            builtins.print = lambda *a, **k: None  # rank 0 reports (tp.py's `print` override)
     thresholds = None
     if not args.dense and (args.hist_path is not None or args.synthetic):
         # like the reference, patching is gated on hist_path, not on sparsity (generate.py:328)
@@ -452,9 +475,10 @@ def main(args) -> Dict:
     print(f"Time to load model: {time.time() - t0:.02f} seconds")
     torch.manual_seed(1234)
     model_size = _get_model_size(model)
-    decoder = GraphedDecoder(model, args.compile, args.temperature, args.top_k)
-    use_engine = args.engine or (args.compile and thresholds is not None and not getattr(args, "no_engine", False)
-                                 and tp_rank is None)  # the fused single-GPU step does not span ranks
+    # a hipGraph holds the step only if the ranks' all-reduce can be captured (RCCL); a host-staged gloo reduce decodes eagerly
+    use_graph = args.compile and (tp_rank is None or bool(getattr(getattr(model, "tp_reduce", None), "capturable", False)))
+    decoder = GraphedDecoder(model, use_graph, args.temperature, args.top_k)
+    use_engine = args.engine or (args.compile and thresholds is not None and not getattr(args, "no_engine", False))
     if use_engine and not args.engine:
         # --compile implies the device-resident engine loop only for models the fused step can run (int4 blocks, head_dim 48,
         # ... decode through the patched modules under the same hipGraph capture instead)
@@ -465,7 +489,7 @@ def main(args) -> Dict:
             use_engine = False
     if use_engine:
         assert thresholds is not None, "--engine needs thresholds (--hist_path or --synthetic)"
-        decoder = EngineDecoder(model, thresholds, args.compile, args.temperature, args.top_k)
+        decoder = EngineDecoder(model, thresholds, use_graph, args.temperature, args.top_k)
         # the engine re-lays every projection (and lm_head) out column-major when it is built, lazily, after the first
         # prefill: do it NOW so that a --compile_prefill graph never captures pointers to storage that is freed later
         from teal_amd.monkeypatch import UP_SHIFT_BYTES, to_column_major

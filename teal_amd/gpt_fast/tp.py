@@ -12,10 +12,17 @@ features), and the block's two partial outputs — attention and MLP — are sum
   partial sum over its kept rows is one term of the all-reduce.
 
 Single-batch decode is the north-star path and does not shard (BASELINE.json: "no RCCL"); TP is the capacity feature that
-puts Llama-2-70B-class models on several GPUs.  Per layer and token the data path then pays two all-reduces of `dim`
-16-bit values (8 KB at Llama-2-7B, 16 KB at 70B) over RCCL / xGMI — latency-bound at that size, see DESIGN.md §6 — next to
-the five launches of the layer.  This module is the partition math and the collective wiring; it is exercised on CPU with
-gloo at world_size 2 (tests/test_tp.py) and has NOT been timed on a multi-GPU node (the round's lease is one GPU).
+puts Llama-2-70B-class models on several GPUs.  Per layer and token the data path then pays two all-reduces over RCCL /
+xGMI — latency-bound at that size, see DESIGN.md §6 — next to the five launches of the layer.
+
+A sharded model keeps the FUSED decode step (engine.py): `DecodeEngine` takes the rank-local widths from the sliced linears
+and calls `model.tp_reduce` on the fp32 split-K slabs of `wo` and `down` (the row-wise projections' partial sums), so the
+consumer's RESID_NORM producer rounds the sum over slices AND ranks once — the unsharded step's own expression.  The reference
+all-reduces each rank's fp16-rounded output (`funcol.all_reduce(output, "sum")`); the module path here (prefill) does the same.
+
+Exercised on CPU with gloo at world_size 2 (tests/test_tp.py: partition math, module path) and on ONE GPU shared by two
+processes (tests/test_tp_gpu.py: the fused engine with a host-staged gloo all-reduce against the unsharded engine, and every
+rank's launches at 7B / 8B / 70B rank-local widths against the oracle).  NOT timed on a multi-GPU node (the lease is one GPU).
 
 Entry points mirror the reference's: `maybe_init_dist()`, `apply_tp(model)`.
 """
@@ -41,19 +48,65 @@ def _rank_world(rank: Optional[int], world: Optional[int]) -> Tuple[int, int]:
 
 def maybe_init_dist() -> Optional[int]:
     """One process per GPU, launched by torch.distributed.run (gpt-fast/tp.py:37-52): returns the rank, or None when the
-    job has fewer than two ranks (TP is a no-op).  RCCL ("nccl") when a GPU is visible, gloo otherwise (the CPU tests)."""
+    job has fewer than two ranks (TP is a no-op).  Call it FIRST — before any model is built — so that every rank
+    materialises its shard on its own device (`torch.cuda.current_device()` afterwards).  RCCL ("nccl") with one GPU per
+    rank; gloo without a GPU (the CPU tests) or when the ranks outnumber the visible GPUs and share one (RCCL refuses two
+    ranks on a device: the single-GPU TP tests); TEAL_TP_BACKEND overrides."""
     world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
     if world < 2:
         return None
     rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("TEAL_TP_BACKEND")
     if torch.cuda.is_available():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver
-        torch.cuda.set_device(rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        ndev = torch.cuda.device_count()
+        torch.cuda.set_device(rank % ndev)
+        if backend is None:
+            backend = "nccl" if ndev >= world else "gloo"
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank % ndev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group(backend or "gloo", rank=rank, world_size=world)
     return rank
+
+
+def make_reduce(group=None):
+    """sum-over-ranks of a tensor, in place: what the block's two partial outputs go through (tp.py:120-121, 139-140).
+    RCCL reduces device tensors on the current stream (capturable into a hipGraph: `.capturable`); gloo is staged through the
+    host explicitly (synchronises the stream: eager decode only)."""
+    if dist.get_backend(group) == "nccl":
+        def reduce(t: torch.Tensor) -> torch.Tensor:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return t
+        reduce.capturable = True
+        return reduce
+
+    def reduce(t: torch.Tensor) -> torch.Tensor:
+        if t.is_cuda:
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t
+    reduce.capturable = False
+    return reduce
+
+
+def sync_thresholds(ths, group=None):
+    """Synthetic calibration under TP: thresholds are properties of the activation SITES, not of a rank — the row-wise
+    projections' sites (attention output, silu(gate) * up) are sliced over the ranks, so a quantile taken on a rank's slice
+    is averaged over the ranks; every rank then masks with the same tau (the rank-local slice of ONE global mask)."""
+    if not dist.is_initialized() or dist.get_world_size(group) < 2:
+        return ths
+    keys = sorted(ths[0].keys())
+    t = torch.tensor([[float(th[k]) for k in keys] for th in ths], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    t /= dist.get_world_size(group)
+    return [{k: float(t[i, j]) for j, k in enumerate(keys)} for i in range(len(ths))]
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -92,6 +145,9 @@ def shard_linear(linear: nn.Module, style: str, rank: int, world: int, splits: S
     if hasattr(linear, "scales_and_zeros"):
         raise NotImplementedError("int4 group-quantised linears are sharded before packing (quantise the sharded model)")
     w = linear.weight
+    # (which slice of the unsharded weight this is: a builder that materialises the shard from a full tensor — the synthetic
+    #  model of generate.build_synthetic_model — reads it back)
+    linear._tp = (style, shard_features(linear.out_features if style == "colwise" else linear.in_features, rank, world, splits))
     if style == "colwise":
         ranges = shard_features(linear.out_features, rank, world, splits)
         new_w = _take(w.data, ranges, 0)
@@ -109,11 +165,14 @@ def shard_linear(linear: nn.Module, style: str, rank: int, world: int, splits: S
 
 
 def _reduce_hook(group):
+    if not dist.is_initialized():  # a single process looking at one rank's shard: partial outputs stay partial
+        return lambda _module, _inputs, output: output
+    reduce = make_reduce(group)
+
     def hook(_module, _inputs, output):
         # the block's partial output: ONE sum over the ranks (tp.py:120-121, 139-140).  16-bit partials are summed as they
         # are, like the reference's funcol.all_reduce(output, "sum")
-        dist.all_reduce(output, op=dist.ReduceOp.SUM, group=group)
-        return output
+        return reduce(output)
     return hook
 
 
@@ -138,10 +197,12 @@ def apply_tp_attn(attn: Attention, rank: int, world: int, group=None) -> None:
 
 
 def apply_tp(model: Transformer, rank: Optional[int] = None, world: Optional[int] = None, group=None) -> None:
-    """Shard every block of `model` for this rank (tp.py:152-158).  Call before `setup_caches` (the KV caches are
-    allocated for the rank's KV heads) and before `monkeypatch_layer` (which lays the LOCAL weight images out and takes
-    the thresholds from the histograms: thresholds are properties of the activation sites, unchanged by the sharding).
-    The fused single-GPU decode step (engine.py) does not span ranks: a TP model decodes through the module path."""
+    """Shard every block of `model` for this rank (tp.py:152-158).  Call before the weights move to the device (meta or CPU
+    tensors shard without touching HBM), before `setup_caches` (the KV caches are allocated for the rank's KV heads) and
+    before `monkeypatch_layer` (which lays the LOCAL weight images out and takes the thresholds from the histograms:
+    thresholds are properties of the activation sites, unchanged by the sharding).  Single-token calls of the sharded model
+    still run the fused decode step: the engine reads the rank-local widths off the linears and sums the partial outputs of
+    `wo` / `down` over the ranks through `model.tp_reduce`."""
     rank, world = _rank_world(rank, world)
     if world < 2:
         return
@@ -155,12 +216,14 @@ def apply_tp(model: Transformer, rank: Optional[int] = None, world: Optional[int
     # what setup_caches reads: KV heads of this rank (the residual stream, embeddings, norms and lm_head stay replicated)
     cfg.n_head //= world
     cfg.n_local_heads //= world
-    model.fused_decode = False
     model.tp_world, model.tp_rank = world, rank
+    # (no process group, e.g. a single process checking a rank's shard: the sum over the ranks is the caller's business)
+    model.tp_reduce = make_reduce(group) if dist.is_initialized() else None
 
 
 def collectives_per_token(model: Transformer, bytes_per_elem: int = 2) -> dict:
-    """The data-path collectives of one decode token under TP: two all-reduces of [1, 1, dim] per layer."""
+    """The data-path collectives of one decode token under TP: two all-reduces of [1, 1, dim] per layer
+    (module path: 16-bit outputs, bytes_per_elem = 2; fused engine: the fp32 slab buffer [dim][4 or 8], bytes_per_elem = 16 / 32)."""
     dim = model.tok_embeddings.weight.shape[1]
     n = 2 * len(model.layers)
     return {"all_reduce_calls": n, "elements_each": dim, "bytes_each": dim * bytes_per_elem, "bytes_per_token": n * dim * bytes_per_elem}

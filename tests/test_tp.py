@@ -121,3 +121,29 @@ def test_bench_runs_exactly_the_requested_steps_through_multi_token_graphs(monke
         bench.timed_decode(s, steps, warm, 1)
         assert s.tokens == steps + warm and s.pos < 64
         assert max(s.replays) <= U
+
+
+def test_synthetic_builder_materialises_each_ranks_slices():
+    """generate.build_synthetic_model(shard=apply_tp): the shard happens on the META model, every rank fills only its slices,
+    and they ARE the slices of the unsharded synthetic model (same seed, same draw order) — what lets the GPU test compare a
+    tensor-parallel engine with the unsharded one."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from teal_amd.gpt_fast import generate as G
+    from teal_amd.gpt_fast import tp
+    full = G.build_synthetic_model("tiny-gqa-test", "cpu", torch.float32, seed=5)
+    cfg = full.config
+    q, kv = cfg.n_head * cfg.head_dim, cfg.n_local_heads * cfg.head_dim
+    parts = [G.build_synthetic_model("tiny-gqa-test", "cpu", torch.float32, seed=5, shard=lambda m, r=r: tp.apply_tp(m, r, 2)) for r in range(2)]
+    for r, m in enumerate(parts):
+        assert m.tp_world == 2 and m.tp_rank == r and m.tp_reduce is None and m.config.n_head == cfg.n_head // 2
+        assert torch.equal(m.tok_embeddings.weight, full.tok_embeddings.weight) and torch.equal(m.output.weight, full.output.weight)
+        for lf, lm in zip(full.layers, m.layers):
+            rows = [i for lo, hi in tp.shard_features(q + 2 * kv, r, 2, [q, kv, kv]) for i in range(lo, hi)]
+            assert torch.equal(lm.attention.wqkv.weight, lf.attention.wqkv.weight[rows])
+            lo, hi = tp.shard_range(q, r, 2)
+            assert torch.equal(lm.attention.wo.weight, lf.attention.wo.weight[:, lo:hi])
+            lo, hi = tp.shard_range(cfg.intermediate_size, r, 2)
+            assert torch.equal(lm.feed_forward.w1.weight, lf.feed_forward.w1.weight[lo:hi])
+            assert torch.equal(lm.feed_forward.w3.weight, lf.feed_forward.w3.weight[lo:hi])
+            assert torch.equal(lm.feed_forward.w2.weight, lf.feed_forward.w2.weight[:, lo:hi])
