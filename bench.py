@@ -31,10 +31,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-# best read rate any kernel of this repo sustains on this part: a 1 GiB dense GEMV through teal_dense_gemv, launch boundary
-# included (scripts/micro/hbm_ceiling.py -> profiles/r02_hbm_ceiling.txt; round 3's bare contiguous-read probe tops out at
-# 6.39 TB/s the same way, profiles/r03_cu_cap_probe.txt)
-HBM_MEASURED_CEILING_GBS = 6340.0
+
+
+def measured_read_ceiling_gbs():
+    """The best read rate a kernel of this repo sustains ON THIS BOX, measured in this run: a 1 GiB dense GEMV through
+    teal_dense_gemv (8192 x 65536 fp16, every row kept, one launch incl. its boundary; median of 9 after 3 warm-up launches —
+    6.34 TB/s on the boxes of rounds 2-4, which differ by ~1 %).  `roofline.frac_of_measured_ceiling` divides by THIS number."""
+    from teal_amd.kernels import sparse_gemv as K
+    Z, N = 8192, 65536
+    w = torch.empty(Z, N, device="cuda", dtype=torch.float16).normal_(0, 0.02).T  # [N, Z], strides (1, N): the W^T image [Z][N]
+    x = torch.randn(1, 1, Z, device="cuda", dtype=torch.float16)
+    ts = []
+    for i in range(12):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        K.dense_gemv(x, w)
+        e1.record()
+        e1.synchronize()
+        if i >= 3:
+            ts.append(e0.elapsed_time(e1) * 1e-3)
+    del w
+    torch.cuda.empty_cache()
+    return (Z * N * 2 + Z * 2 + N * 2) / float(np.median(ts)) / 1e9
 
 
 def parse():
@@ -60,10 +78,8 @@ def parse():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="skip the rocprofv3 --pmc subprocess that measures roofline.traffic in this run (the committed pass is reported instead)")
     ap.add_argument("--no-context-sweep", action="store_true", help="skip the value_at_context runs (1000 and 3800 cache positions)")
-    ap.add_argument("--swizzle", type=int, default=0, help="XCD-decorrelating tile swizzle (A/B switch)")
     ap.add_argument("--block_size", type=int, default=0, help="override the architecture's context length (RoPE table / cache limit) "
                     "for long-context experiments; 0 = the reference's value (2048 for 7B)")
-    ap.add_argument("--experiment", type=int, default=0, help="teal_set_experiment mask (A/B switches, include/teal_hip.h; 0 = production)")
     ap.add_argument("--wave-local", type=int, default=1, help="wave-local compaction (A/B switch)")
     ap.add_argument("--graph-tokens", type=int, default=1,
                     help="decode steps per hipGraph replay (token, position and RNG counter are device-resident, so a graph can span "
@@ -309,9 +325,11 @@ def roofline_engine_gateup(eng, a):
         traffic, tsrc = pmc_traffic(kname)  # the committed pass of this command (profiles/), flagged as such
         if tsrc:
             tsrc = f"{tsrc}; live pass: {why}"
+    ceiling = measured_read_ceiling_gbs()
     return {"bound": "hbm", "achieved": total_bytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": total_bytes / t / 1e9 / HBM_PEAK_GBS, "frac_of_measured_ceiling": total_bytes / t / 1e9 / HBM_MEASURED_CEILING_GBS,
-            "measured_ceiling": HBM_MEASURED_CEILING_GBS, "traffic": traffic, "traffic_source": tsrc,
+            "frac": total_bytes / t / 1e9 / HBM_PEAK_GBS, "frac_of_measured_ceiling": total_bytes / t / 1e9 / ceiling,
+            "measured_ceiling": ceiling, "measured_ceiling_how": "1 GiB dense GEMV (8192 x 65536 fp16) through teal_dense_gemv in this run, "
+            "median of 9 launches incl. the launch boundary", "traffic": traffic, "traffic_source": tsrc,
             "traffic_measured_in_this_run": live,
             "kernel": kname + f" (fused RMSNorm -> mask -> gate|up GEMV{' -> silu*mul' if eng.pair else ''}, Z={Z}, N=2x{N}"
                       + ("; int4: algorithmic bytes count kept ROWS at half a byte per weight + the dense group parameters — the kernel "
@@ -493,9 +511,7 @@ def main():
     from teal_amd.gpt_fast import generate as G
     runtime.init()
     from teal_amd import _lib
-    _lib.load().teal_set_swizzle(a.swizzle)
     _lib.load().teal_set_wave_local(a.wave_local)
-    _lib.load().teal_set_experiment(a.experiment)
     if a.tuning:
         assert _lib.load().teal_set_tuning(*[int(v) for v in a.tuning.split(",")]) == 0
     if a.pair is not None:

@@ -28,7 +28,7 @@
  *     the duration of the stream-ordered launch and never allocates.  Library state: the properties of each device,
  *     cached the first time it is used (teal_init(); immutable), a host-side registry of the workspaces prepared by
  *     teal_workspace_init() (which device memory holds a valid header), and the diagnostics / tuning switches of the
- *     last section (teal_set_tuning, teal_set_fast, teal_set_wave_local, teal_set_swizzle, teal_set_phase_*):
+ *     last section (teal_set_tuning, teal_set_fast, teal_set_wave_local, teal_set_phase_*):
  *     host-side variables read at launch time, NOT thread-safe, meant for benchmarks and tests.  No device memory
  *     belongs to the library: the arrival counters of the single-launch split-K GEMVs and the scratch of the
  *     multi-workgroup sampler live in the header of the CALLER's workspace, so two streams, two captured graphs or two
@@ -280,12 +280,10 @@ int teal_decode_attention_split_slabs(const float* qkv_slabs, int qkv_nslabs, co
                                       void* k_cache, void* v_cache, void* y, void* mask_out, float mask_tau, int n_head,
                                       int n_kv_head, int head_dim, int max_seq, int nsplit, void* partials,
                                       size_t partials_bytes, int dtype, void* stream);
-/* General form with the caller's workspace: exactly one of qkv (rounded projection) / qkv_slabs (+ qkv_nslabs) is given.
- * Same launches and results as teal_decode_attention_split / _split_slabs.  Under teal_set_experiment bit 9, with
- * y != NULL and a workspace prepared by teal_workspace_init(), the merge is FOLDED into the split launch: every workgroup
- * publishes its partials write-through and takes a ticket on its head's (grouped-query: its KV head's) counter in the
- * workspace header; the last to arrive merges, rounds, stores y and the masks and re-arms the counter — bit-identical y,
- * one launch less, but measured no faster than split + merge (equal at 4-8 splits, slower at 16-32), hence not the default. */
+/* General form: exactly one of qkv (rounded projection) / qkv_slabs (+ qkv_nslabs) is given.  Same launches and results as
+ * teal_decode_attention_split / _split_slabs.  `ws` / `ws_bytes` are accepted and unused (round 3 folded the merge launch into
+ * the split launch through arrival counters in a prepared workspace: bit-identical y, measured no faster — equal at 4-8
+ * splits, slower at 16-32 — and removed in round 5). */
 int teal_decode_attention_split_ws(const void* qkv, const float* qkv_slabs, int qkv_nslabs, const void* rope,
                                    const int32_t* pos, void* k_cache, void* v_cache, void* y, void* mask_out,
                                    float mask_tau, int n_head, int n_kv_head, int head_dim, int max_seq, int nsplit,
@@ -310,7 +308,7 @@ int teal_decode_attention_split_roped(const void* q, const int32_t* pos, const v
  * teal_sample_topk_ws with a prepared workspace (teal_workspace_init): vocabularies of 8193..131072 entries (multiple
  * of 8) with an active filter run as one workgroup per 8192 logits: local top-k candidates -> workspace header -> the
  * last workgroup to arrive picks the token; same tokens as the single-workgroup kernels, which serve every other case
- * (no / unprepared workspace, other shapes, teal_set_experiment bit 4). */
+ * (no / unprepared workspace, other shapes). */
 int teal_sample_topk(const void* logits, int vocab, int dtype, int top_k, float temperature, void* rng_state,
                      int32_t* token_out, int32_t* pos_inout, int32_t* history, int history_len, void* stream);
 int teal_sample_topk_ws(const void* logits, int vocab, int dtype, int top_k, float temperature, void* rng_state,
@@ -341,23 +339,8 @@ int teal_set_wave_local(int on);
  * string; e.g. for naming the kernel in a benchmark record). */
 const char* teal_last_launch_desc(void);
 
-/* Experiment switches of the lean kernel, for A/B timing inside one process (0 = production behaviour).
- * bit 0: do not issue the first weight batch before the compaction has finished;
- * bit 1: attention scores' running maximum by six shuffle round trips instead of DPP row shifts + readlanes;
- * bit 2: butterfly reductions of the GEMV epilogue and of the attention P.V product by shuffles for every step instead
- *        of a DPP row rotate (lane ^ 8) and a ds_swizzle swap (lane ^ 16).  Results are bit-identical either way;
- * bit 3: grouped-query models keep the per-query-head split attention kernel at every cache length;
- * bit 4: the sampler runs as a single workgroup at every vocabulary size;
- * bit 5: no issue-priority ramp over the waves of a workgroup on short row lists;
- * bit 9: teal_decode_attention_split_ws folds the merge into the split launch (prepared workspace; measured no faster). */
-int teal_set_experiment(int mask);
-
 /* Lean kernel for qualifying shapes (default on; 0 forces the general kernel everywhere: A/B and parity tests). */
 int teal_set_fast(int on);
-
-/* Column-tile XOR swizzle that spreads every XCD over all DRAM channel residues.  Default OFF (0): measured neutral
- * once the row stride is padded; a launch with the swizzle on uses the general kernel. */
-int teal_set_swizzle(int on);
 
 /* Diagnostics: when set (device pointer to >= 32 * workgroups uint64 — 32 stamps per workgroup of the launch), every
  * GEMV workgroup stores 100 MHz wall-clock stamps of its phases, row w of the buffer = workgroup w:

@@ -15,19 +15,16 @@ from teal_amd.gpt_fast.model import precompute_freqs_cis
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--exp", type=int, default=0, help="teal_set_experiment mask")
     ap.add_argument("--splits", type=int, nargs="*", default=[4, 8, 16, 32])
     ap.add_argument("--voff", type=int, default=0, help="shift every V cache this many bytes into its allocation (DRAM channel phase of K vs V)")
     ap.add_argument("--models", nargs="*", default=["7B", "8B", "70B"])
     ap.add_argument("--ctx", type=int, nargs="*", default=[1024, 4096, 16384])
     ap.add_argument("--pos", type=int, default=0, help="decode position inside the cache (default: the cache's last but one row); a position well "
                     "inside a long cache shows what a launch reads past the sequence")
-    ap.add_argument("--fold", type=int, default=0, help="1: merge folded into the split launch (prepared workspace); 0: split + merge launch")
     a = ap.parse_args()
     L = _lib.load(); runtime.init()
     global WSP
     WSP = runtime.new_workspace(64, 64)
-    L.teal_set_experiment(a.exp | (512 if a.fold else 0))
     dt = torch.float16
     hd = 128
     for name, n_head, n_kv in (("7B", 32, 32), ("8B", 32, 8), ("70B", 64, 8)):
@@ -54,10 +51,9 @@ def main():
                 ws = torch.zeros(n_head * ns * (hd + 2), device="cuda", dtype=torch.float32)
                 st = torch.cuda.Stream()
                 def call(i):
-                    # --fold: prepared workspace -> the merge is folded into the split launch (arrival tickets); else split + merge launch
                     return L.teal_decode_attention_split_ws(qkv.data_ptr(), None, 0, rope.data_ptr(), p.data_ptr(), kcs[i % nrot].data_ptr(),
                                                             vcs[i % nrot].data_ptr(), y.data_ptr(), None, 0.0, n_head, n_kv, hd, S, ns,
-                                                            ws.data_ptr(), ws.numel() * 4, 0, WSP.data_ptr() if a.fold else None,
+                                                            ws.data_ptr(), ws.numel() * 4, 0, None,
                                                             WSP.numel() * 4 if a.fold else 0, st.cuda_stream)
                 with torch.cuda.stream(st):
                     rc = call(0)

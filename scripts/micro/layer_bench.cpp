@@ -5,12 +5,15 @@
 //         -Wl,-rpath,'$ORIGIN/../../teal_amd' -o scripts/micro/layer_bench
 //   layer_bench [--layers 32] [--steps 100] [--sparsity 0.5] [--model 7b|8b|70b] [--phase] [--dense] [--pos 64]
 //               [--tune stage:lpr:waves:split:unroll,...]   (stage = qkv|wo|gu|down|head|all)
+//               [--tp W]   one RANK's launches under W-way tensor parallelism (gpt-fast/tp.py:110-140: the rank's query / KV heads
+//                          and intermediate columns, the residual stream replicated; the two all-reduces per layer are NOT in it)
 //
 // One token = per layer {qkv, attention, wo, gate|up, down} + lm_head + sampler, captured in ONE hipGraph and replayed —
 // exactly the launch sequence of DecodeEngine.__call__ + sample_fused (engine.py:206-252).  Weights are random, the
 // thresholds are calibrated layer by layer on the activations the sparse path itself produces (median of |x|), so every
 // projection keeps ~(1 - sparsity) of its rows like the engine's synthetic calibration does.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -82,7 +85,7 @@ struct Layer {
 };
 
 int main(int argc, char** argv) {
-    int n_layer = 32, steps = 100, pos0 = 64, warm = 5, att_split = 0, pair = 1;
+    int n_layer = 32, steps = 100, pos0 = 64, warm = 5, att_split = 0, pair = 1, tp = 1;
     int gate_act = getenv("LB_GATEACT") ? atoi(getenv("LB_GATEACT")) : 1;  // silu in the gate tiles' epilogue (act_seg0)
     int use_rope = getenv("LB_ROPE") ? atoi(getenv("LB_ROPE")) : 1;  // RoPE + KV append in the qkv launch's epilogue (TEAL_OUT_QKV_ROPE)
     float sparsity = 0.5f;
@@ -101,6 +104,7 @@ int main(int argc, char** argv) {
         else if (a == "--bf16") bf = true;
         else if (a == "--att_split") att_split = atoi(nxt().c_str());
         else if (a == "--no_pair") pair = 0;
+        else if (a == "--tp") tp = atoi(nxt().c_str());
         else if (a == "--tune") {
             std::string s = nxt();
             size_t p = 0;
@@ -112,8 +116,11 @@ int main(int argc, char** argv) {
             }
         } else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
     }
-    const Shape S = shape_of(model);
-    const int dim = S.dim, inter = S.inter, hd = S.hd, kv = S.n_kv * hd, nqkv = dim + 2 * kv;
+    Shape S = shape_of(model);
+    if (tp < 1 || S.n_head % tp || S.n_kv % tp || S.inter % tp) { fprintf(stderr, "--tp %d does not divide the heads / intermediate size\n", tp); return 2; }
+    S.n_head /= tp; S.n_kv /= tp; S.inter /= tp;
+    // dim = the residual stream (replicated under TP); qd = this rank's query columns = wo's input rows
+    const int dim = S.dim, inter = S.inter, hd = S.hd, qd = S.n_head * hd, kv = S.n_kv * hd, nqkv = qd + 2 * kv;
     const int dt = bf ? TEAL_BF16 : TEAL_F16;
     const int max_seq = std::max(256, pos0 + steps + warm + 64);
     if (!att_split) att_split = max_seq <= 1024 ? 4 : 8;
@@ -121,7 +128,10 @@ int main(int argc, char** argv) {
     if (ncu <= 0) { fprintf(stderr, "no device\n"); return 1; }
     hipStream_t st; CK(hipStreamCreate(&st));
     g_st = st; g_trace = getenv("LB_TRACE") != nullptr;
-    if (getenv("LB_EXP")) TK(teal_set_experiment(atoi(getenv("LB_EXP"))));  // whole run under an experiment mask (phase stamps of a variant)
+    // experiment builds only (-DTEAL_R05_EXPERIMENTS, teal_amd/_lib.py TEAL_EXTRA_FLAGS): the switch is absent from the product library
+    typedef int (*exp_fn_t)(int);
+    exp_fn_t set_exp = (exp_fn_t)dlsym(RTLD_DEFAULT, "teal_r05_experiment");
+    if (getenv("LB_EXP")) { if (!set_exp) { fprintf(stderr, "LB_EXP: this libteal_hip.so has no experiment switch\n"); return 2; } TK(set_exp(atoi(getenv("LB_EXP")))); }
     hipStream_t st2; CK(hipStreamCreate(&st2));
     hipStream_t ls = st;  // the stream the k_* launch helpers use
     auto alloc16 = [&](size_t n, uint32_t seed, float amp) {
@@ -136,7 +146,7 @@ int main(int argc, char** argv) {
     for (auto& l : Ls) {
         const float a_in = sqrtf(3.0f / dim), a_dn = sqrtf(3.0f / inter);
         l.wqkv = alloc16((size_t)dim * ldq, seed++, a_in * 1.5f);
-        l.wo = alloc16((size_t)dim * ldo, seed++, a_in * 1.5f);
+        l.wo = alloc16((size_t)qd * ldo, seed++, a_in * 1.5f);
         l.w1 = alloc16((size_t)dim * ldi, seed++, a_in * 1.5f);
         {   // LB_W3OFF=<bytes, multiple of 16>: shift the up matrix against the gate matrix (DRAM channel alignment of the pair)
             const size_t off = getenv("LB_W3OFF") ? (size_t)atoi(getenv("LB_W3OFF")) / 2 : 0;
@@ -170,10 +180,10 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(rope, r.data(), r.size() * 2, hipMemcpyHostToDevice));
     }
     uint16_t* A = (uint16_t*)allocz(dim * 2); uint16_t* B = (uint16_t*)allocz(dim * 2);
-    uint16_t* y_attn = (uint16_t*)allocz(dim * 2); uint16_t* h_mlp = (uint16_t*)allocz(inter * 2);
+    uint16_t* y_attn = (uint16_t*)allocz(qd * 2); uint16_t* h_mlp = (uint16_t*)allocz(inter * 2);
     uint16_t* gu = (uint16_t*)allocz((size_t)2 * inter * 2);
     uint16_t* q_rot = (uint16_t*)allocz((size_t)nqkv * 2);
-    unsigned long long* y_mask = (unsigned long long*)allocz(((dim + 63) / 64) * 8);
+    unsigned long long* y_mask = (unsigned long long*)allocz(((qd + 63) / 64) * 8);
     unsigned long long* h_mask = (unsigned long long*)allocz(((inter + 63) / 64) * 8);
     const size_t slab_floats = (size_t)32 * std::max(dim, nqkv);
     float* s_wo = (float*)allocz(slab_floats * 4); float* s_down = (float*)allocz(slab_floats * 4);
@@ -188,7 +198,7 @@ int main(int argc, char** argv) {
     unsigned long long* rng = (unsigned long long*)allocz(16);
     { int32_t p = pos0, t = 3; CK(hipMemcpy(pos, &p, 4, hipMemcpyHostToDevice)); CK(hipMemcpy(tok, &t, 4, hipMemcpyHostToDevice));
       unsigned long long r[2] = {1234, 0}; CK(hipMemcpy(rng, r, 16, hipMemcpyHostToDevice)); }
-    const bool fused_merge = (att_split == 4 && dim <= 16384) || (att_split == 8 && dim <= 8192);
+    const bool fused_merge = (att_split == 4 && qd <= 16384) || (att_split == 8 && qd <= 8192);
     const float NEG = -INFINITY, eps = 1e-5f;
     int n_qkv = 0, n_wo = 0, n_down = 0;
 
@@ -208,8 +218,8 @@ int main(int argc, char** argv) {
         in.mode = TEAL_IN_RESID_NORM; in.resid_in = i == 0 ? (const void*)emb : (const void*)A; in.row_index = i == 0 ? tok : nullptr;
         in.slabs = i == 0 ? nullptr : s_down; in.nslabs = i == 0 ? 0 : n_down; in.slabs_interleaved = 1;
         in.norm_weight = l.norm1; in.eps = eps; in.resid_out = B;
-        const void* w[3] = {l.wqkv, l.wqkv, l.wqkv}; const int ld[3] = {ldq, ldq, ldq}; const int c0[3] = {0, dim, dim + kv};
-        const int nc[3] = {dim, kv, kv}; const float tau[3] = {tq, tq, tq};
+        const void* w[3] = {l.wqkv, l.wqkv, l.wqkv}; const int ld[3] = {ldq, ldq, ldq}; const int c0[3] = {0, qd, qd + kv};
+        const int nc[3] = {qd, kv, kv}; const float tau[3] = {tq, tq, tq};
         teal_gemv_out_t o = mk_out(3, w, ld, c0, nc, tau, nullptr, TEAL_OUT_SLABS, s_qkv);
         o.slabs_bytes = (size_t)8 * nqkv * 4;
         if (use_rope) {
@@ -237,7 +247,7 @@ int main(int argc, char** argv) {
         const void* w[1] = {l.wo}; const int ld[1] = {ldo}; const int c0[1] = {0}; const int nc[1] = {dim}; const float tau[1] = {to};
         teal_gemv_out_t o = mk_out(1, w, ld, c0, nc, tau, nullptr, TEAL_OUT_SLABS, s_wo);
         apply_tune("wo");
-        TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, &n_wo, ls));
+        TK(teal_fused_gemv(&in, &o, qd, dt, ws, ws_bytes, &n_wo, ls));
     };
     auto k_gu = [&](int i, float tg, float td) {
         Layer& l = Ls[i];
@@ -307,7 +317,7 @@ int main(int argc, char** argv) {
         { auto x = norm_of(B); l.tq = quantile_abs(x, sparsity); }
         k_qkv(i, l.tq);
         k_attn(i, true, 0.0f);
-        { auto y = fetch16(y_attn, dim); l.to = quantile_abs(y, sparsity); }
+        { auto y = fetch16(y_attn, qd); l.to = quantile_abs(y, sparsity); }
         k_attn(i, !fused_merge, l.to);
         k_wo(i, l.to);
         k_gu(i, INFINITY, 0.0f);
@@ -332,8 +342,19 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(st));
     printf("model %s dtype %s layers %d cu %d pos0 %d max_seq %d att_split %d pair %d | slabs qkv %d wo %d down %d", model.c_str(), bf ? "bf16" : "f16",
            n_layer, ncu, pos0, max_seq, att_split, pair, n_qkv, n_wo, n_down);
+    if (tp > 1) printf(" | tensor-parallel rank of %d: wqkv %d->%d, wo %d->%d, w1/w3 %d->%d, w2 %d->%d (all-reduces not included)", tp, dim, nqkv, qd, dim,
+                       dim, inter, inter, dim);
     if (!dense && pair) printf(" | kept(down) %.3f", kept[3] / n_layer);
     printf("\n  tau layer0: q %.4f o %.5f g %.4f d %.5f\n", Ls[0].tq, Ls[0].to, Ls[0].tg, Ls[0].td);
+    if (getenv("LB_DESC")) {  // the instantiation and grid run_gemv picked for each GEMV launch of a layer (layer 1: slabs on both sides)
+        const int e = n_layer > 1 ? 1 : 0; Layer& q = Ls[e];
+        k_qkv(e, q.tq); printf("  geometry qkv     : %s, slabs %d\n", teal_last_launch_desc(), n_qkv);
+        k_attn(e, !fused_merge, q.to);
+        k_wo(e, q.to); printf("  geometry wo      : %s, slabs %d\n", teal_last_launch_desc(), n_wo);
+        k_gu(e, q.tg, q.td); printf("  geometry gate|up : %s\n", teal_last_launch_desc());
+        k_down(e, q.td); printf("  geometry down    : %s, slabs %d\n", teal_last_launch_desc(), n_down);
+        CK(hipStreamSynchronize(st));
+    }
 
     if (getenv("LB_VERIFY")) {
         // lean kernel vs general kernel on the same inputs: bit-identical outputs expected (same arithmetic, same order)
@@ -518,8 +539,7 @@ int main(int argc, char** argv) {
                        k0 == k1 ? "same" : "DIFF", v0 == v1 ? "same" : "DIFF");
                 bad += !ok;
             }
-            const bool forced = getenv("LB_EXP") && (atoi(getenv("LB_EXP")) & 1024);  // another geometry than the slab hand-over: other fp32 sums
-            if (bad && !forced) { printf("rope verify FAILED\n"); return 3; }
+            if (bad) { printf("rope verify FAILED\n"); return 3; }
         }
         use_rope = 0; token_step(); CK(hipStreamSynchronize(st)); hipGraphExec_t ga = capture(token_step);
         use_rope = 1; token_step(); CK(hipStreamSynchronize(st)); hipGraphExec_t gb = capture(token_step);
@@ -552,11 +572,13 @@ int main(int argc, char** argv) {
         return 0;
     }
     if (getenv("LB_AB")) {
-        // A/B inside one process: the same token step captured with teal_set_experiment(0) and (mask), timed alternately
+        // A/B inside one process (experiment builds only): the same token step captured with the switch at 0 and at (mask), timed alternately
         const int mask = atoi(getenv("LB_AB"));
-        TK(teal_set_experiment(mask));
+        if (!set_exp) { fprintf(stderr, "LB_AB: this libteal_hip.so has no experiment switch\n"); return 2; }
+        TK(set_exp(mask));
+        token_step(); CK(hipStreamSynchronize(st));
         hipGraphExec_t gexp = capture(token_step);
-        TK(teal_set_experiment(0));
+        TK(set_exp(0));
         double sa = 0, sb = 0; const int rounds = 6;
         for (int r = 0; r < rounds; ++r) {
             const double ta = time_graph(gtok, steps, true), tb = time_graph(gexp, steps, true);

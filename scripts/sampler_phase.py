@@ -21,20 +21,21 @@ for V, dt, code in ((32000, torch.float16, 0), (128256, torch.bfloat16, 1)):
     tok = torch.zeros(1, dtype=torch.int32, device="cuda")
     lgs = [(torch.randn(V, device="cuda", generator=g) * 2.5).to(dt) for _ in range(16)]
     st = torch.cuda.Stream()
-    for exp, label in ((0, "one workgroup per 8192 logits + last arriver"), (16, "single workgroup")):
-        L.teal_set_experiment(exp)
+    for multi, label in ((True, "one workgroup per 8192 logits + last arriver"), (False, "single workgroup")):
         with torch.cuda.stream(st):
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr, stream=st):
-                for lg in lgs:
-                    assert L.teal_sample_topk_ws(lg.data_ptr(), V, code, 200, 0.8, state.data_ptr(), tok.data_ptr(), None, None, 0, WS.data_ptr(), WS.numel() * 4, st.cuda_stream) == 0
+                for lg in lgs:  # (without a prepared workspace the sampler runs as a single workgroup: teal_sample_topk)
+                    if multi:
+                        assert L.teal_sample_topk_ws(lg.data_ptr(), V, code, 200, 0.8, state.data_ptr(), tok.data_ptr(), None, None, 0, WS.data_ptr(), WS.numel() * 4, st.cuda_stream) == 0
+                    else:
+                        assert L.teal_sample_topk(lg.data_ptr(), V, code, 200, 0.8, state.data_ptr(), tok.data_ptr(), None, None, 0, st.cuda_stream) == 0
             gr.replay(); st.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
             for _ in range(8): gr.replay()
             e1.record(st); st.synchronize()
         print(f"V={V}: {label:46s} {e0.elapsed_time(e1) * 1e3 / (8 * 16):6.2f} us per call (incl. launch boundary)")
-    L.teal_set_experiment(16)
     g = torch.Generator(device="cuda").manual_seed(1)
     state = torch.tensor([1234, 0], dtype=torch.int64, device="cuda")
     tok = torch.zeros(1, dtype=torch.int32, device="cuda")
@@ -53,4 +54,3 @@ for V, dt, code in ((32000, torch.float16, 0), (128256, torch.bfloat16, 1)):
     print(f"V={V}: total {sum(med):.2f} us")
     for n, v in zip(names, med):
         print(f"    {n:28s} {v:6.2f} us")
-L.teal_set_experiment(0)

@@ -26,14 +26,18 @@ PRELOAD = {"teal_gemv_fast_f16.hip": 12, "teal_gemv_fast_bf16.hip": 12, "teal_ge
            "teal_gemv_fast_w8_bf16.hip": 12, "teal_attention.hip": 12}
 INCLUDE = os.path.join(_ROOT, "include")
 OBJ_DIR = os.path.join(CSRC, "_obj")
-# TEAL_LIB_PATH: load another build of the library (same C ABI) instead of the in-tree one — same-box A/B of two builds
-LIB_PATH = os.environ.get("TEAL_LIB_PATH") or os.path.join(_PKG, "libteal_hip.so")
+LIB_PATH = os.path.join(_PKG, "libteal_hip.so")  # the in-tree library: what build() writes and, by default, what load() opens
+# TEAL_LIB_PATH: load() opens another build of the library (same C ABI) instead — same-box A/B of two builds.  build() never
+# writes there (an override pointing at an older build must not be overwritten by the current tree), and symbols that build
+# lacks are tolerated (OPTIONAL_WITH_OVERRIDE).
+LIB_OVERRIDE = os.environ.get("TEAL_LIB_PATH") or None
+OPTIONAL_WITH_OVERRIDE = ("teal_decode_attention_split_roped",)
 
 # every symbol include/teal_hip.h declares
 EXPORTS = (
     "teal_version", "teal_strerror", "teal_init", "teal_workspace_bytes", "teal_compact",
     "teal_sparse_gemv", "teal_sparse_qkv_gemv", "teal_dense_gemv", "teal_sparse_gateup_silu",
-    "teal_set_tuning", "teal_get_config", "teal_set_phase_buffer", "teal_fused_gemv", "teal_decode_attention", "teal_sample_topk", "teal_set_swizzle", "teal_set_wave_local", "teal_sparse_qkv_gemv_ld", "teal_decode_attention_masked", "teal_decode_attention_split", "teal_sparse_qkv_gemv_i8", "teal_decode_attention_split_slabs", "teal_set_phase_stride", "teal_set_fast", "teal_last_launch_desc", "teal_sparse_qkv_gemv_i4", "teal_set_experiment",
+    "teal_set_tuning", "teal_get_config", "teal_set_phase_buffer", "teal_fused_gemv", "teal_decode_attention", "teal_sample_topk", "teal_set_wave_local", "teal_sparse_qkv_gemv_ld", "teal_decode_attention_masked", "teal_decode_attention_split", "teal_sparse_qkv_gemv_i8", "teal_decode_attention_split_slabs", "teal_set_phase_stride", "teal_set_fast", "teal_last_launch_desc", "teal_sparse_qkv_gemv_i4",
     "teal_workspace_init", "teal_workspace_release", "teal_sample_topk_ws", "teal_decode_attention_split_ws", "teal_cmp_flag_gemv",
     "teal_decode_attention_split_roped",
 )
@@ -48,20 +52,25 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: cannot build libteal_hip.so (no CPU fallback exists)")
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, out: str | None = None, extra_flags=()) -> str:
     """hipcc --offload-arch=gfx950 -> teal_amd/libteal_hip.so (in-tree, travels with the repo).
-    One `hipcc -c` per translation unit, in parallel, then one link."""
+    One `hipcc -c` per translation unit, in parallel, then one link.
+    `out` + `extra_flags`: a second build next to the product library (e.g. an experiment build with -DTEAL_R05_EXPERIMENTS
+    for a same-box A/B through TEAL_LIB_PATH); its objects live in their own directory and it is always rebuilt."""
     headers = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(INCLUDE, "teal_hip.h")]
     srcs = [os.path.join(CSRC, f) for f in SOURCES]
     newest_header = max(os.path.getmtime(h) for h in headers)
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in srcs + headers):
-        return LIB_PATH
-    os.makedirs(OBJ_DIR, exist_ok=True)
+    lib_path = out or LIB_PATH
+    obj_dir = OBJ_DIR if out is None else os.path.join(OBJ_DIR, os.path.basename(out).replace(".", "_"))
+    force = force or out is not None
+    if not force and os.path.exists(lib_path) and all(os.path.getmtime(lib_path) >= os.path.getmtime(d) for d in srcs + headers):
+        return lib_path
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", f"-I{INCLUDE}", f"-I{CSRC}"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", f"-I{INCLUDE}", f"-I{CSRC}", *extra_flags]
 
     def compile_one(src: str) -> str:
-        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_header):
             return obj
         extra = []
@@ -75,12 +84,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, srcs))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH + ".tmp"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib_path + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(lib_path + ".tmp", lib_path)
+    return lib_path
 
 
 def load() -> ctypes.CDLL:
@@ -93,11 +102,12 @@ def load() -> ctypes.CDLL:
     # would bring in a second runtime that sees no device context.
     import torch  # noqa: F401
 
-    if not os.path.exists(LIB_PATH):
+    path = LIB_OVERRIDE or LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). teal_amd has no CPU/eager fallback for the sparse GEMV path.")
-    L = ctypes.CDLL(LIB_PATH)
+    L = ctypes.CDLL(path)
     vp, ci, cf, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
     L.teal_version.restype = ci
     L.teal_strerror.argtypes = [ci]
@@ -121,20 +131,21 @@ def load() -> ctypes.CDLL:
     L.teal_sample_topk_ws.argtypes = [vp, ci, ci, ci, cf, vp, vp, vp, vp, ci, vp, sz, vp]
     L.teal_workspace_init.argtypes = [vp, sz, vp]
     L.teal_workspace_release.argtypes = [vp]
-    L.teal_set_swizzle.argtypes = [ci]
     L.teal_set_wave_local.argtypes = [ci]
     L.teal_set_fast.argtypes = [ci]
-    L.teal_set_experiment.argtypes = [ci]
     L.teal_last_launch_desc.restype = ctypes.c_char_p
     L.teal_decode_attention_masked.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, ci, vp]
     L.teal_decode_attention_split.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, ci, vp, sz, ci, vp]
     L.teal_decode_attention_split_slabs.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, ci, vp, sz, ci, vp]
     L.teal_decode_attention_split_ws.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, ci, vp, sz, ci, vp, sz, vp]
     L.teal_cmp_flag_gemv.argtypes = [vp, vp, ci, vp, vp, cf, ci, ci, ci, vp]
-    L.teal_decode_attention_split_roped.argtypes = [vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, ci, vp, sz, ci, vp, sz, vp]
+    if hasattr(L, "teal_decode_attention_split_roped"):  # (absent from a pre-round-4 build loaded through TEAL_LIB_PATH)
+        L.teal_decode_attention_split_roped.argtypes = [vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, ci, vp, sz, ci, vp, sz, vp]
     L.teal_decode_attention.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
     L.teal_get_config.argtypes = [ci, ci, ci, ctypes.POINTER(ci)]
     for name in EXPORTS:
+        if LIB_OVERRIDE and name in OPTIONAL_WITH_OVERRIDE and not hasattr(L, name):
+            continue  # an older build loaded for A/B: callers of this entry point fail with AttributeError when they reach it
         getattr(L, name)  # AttributeError if the .so is stale
         if getattr(L, name).restype is None:
             getattr(L, name).restype = ci

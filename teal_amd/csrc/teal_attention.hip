@@ -200,16 +200,12 @@ __global__ __launch_bounds__(NT) void decode_attention_kernel(
 // Merge of one head's split-KV partials {m_s, l_s, o_s[hd]} (s < nsplit <= 64), one thread per output column t < hd
 // (whole waves): lane s of every wave holds {m_s, l_s}, so the scale factors cost one load round trip; the o columns are
 // then summed in split order, 32 independent loads at a time.  Same arithmetic, in the same order, as the merge producer
-// of the GEMV launch.  COHERENT: the partials were written by OTHER workgroups of the running launch (the folded merge:
-// write-through stores + arrival ticket), so they are read past this XCD's L2 (agent-scope loads).
-template <bool BF16, bool COHERENT>
+// of the GEMV launch.
+template <bool BF16>
 __device__ __forceinline__ void merge_head(const float* __restrict__ p, uint16_t* __restrict__ y_head,
                                            unsigned long long* __restrict__ mask_head, const float mask_tau, const int hd,
                                            const int nsplit, const int t, const int lane) {
-    auto ld = [&](const float* q) -> float {
-        if constexpr (COHERENT) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else return *q;
-    };
+    auto ld = [&](const float* q) -> float { return *q; };
     float m = -INFINITY, l = 0.0f;
     if (lane < nsplit) {
         m = ld(p + (size_t)lane * (hd + 2));
@@ -245,41 +241,6 @@ __device__ __forceinline__ void merge_head(const float* __restrict__ p, uint16_t
     }
 }
 
-// The merge FOLDED into the split launch (no merge launch): every workgroup of a group (the splits of one head, or of one
-// KV head with its `heads` query heads) publishes its partials write-through, drains, and takes a ticket on the group's
-// counter in the caller's prepared workspace; the last to arrive merges the group's heads and re-arms the counter
-// (gemv_fast_kernel's single-launch split-K uses the same scheme).  `store_partial` must have been used for every store.
-__device__ __forceinline__ void store_partial(float* q, const float v, const bool coherent) {
-    if (coherent) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *q = v;
-}
-template <bool BF16, int NT>
-__device__ __forceinline__ void fold_merge(unsigned* __restrict__ ticket, const int group, const int nsplit, const int head0,
-                                           const int heads, const int hd, const float* __restrict__ partials,
-                                           uint16_t* __restrict__ y, unsigned long long* __restrict__ mask_out,
-                                           const float mask_tau, unsigned* lds_flag) {
-    const int tid = threadIdx.x;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned t = __hip_atomic_fetch_add(&ticket[group], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = t == (unsigned)nsplit - 1u;
-        if (last) __hip_atomic_store(&ticket[group], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
-        *lds_flag = last ? 1u : 0u;
-    }
-    __syncthreads();
-    if (*lds_flag == 0u) return;
-    const int per_pass = NT / hd;  // heads merged at a time: one thread per output column
-    for (int r0 = 0; r0 < heads; r0 += per_pass) {
-        const int r = r0 + tid / hd;
-        if (r < heads && tid < per_pass * hd) {  // whole waves (hd is 64 or 128)
-            const int h = head0 + r;
-            merge_head<BF16, true>(partials + (size_t)h * nsplit * (hd + 2), y + (size_t)h * hd,
-                                   mask_out ? mask_out + ((size_t)h * hd >> 6) : nullptr, mask_tau, hd, nsplit, tid % hd, tid & 63);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Split-KV decode attention (flash-decoding): the cached positions of a head are dealt to `nsplit` workgroups in
 // groups of STEP = (waves x rows per wave) rows, round-robin (group g belongs to workgroup g mod nsplit), so that
@@ -300,14 +261,11 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
     const int* __restrict__ pos_ptr, uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache,
     const uint16_t* __restrict__ qkv, const int max_seq, const int nsplit, const int rep, const int qkv_nslabs,
     const float* __restrict__ qkv_slabs, float* __restrict__ partials, const uint16_t* __restrict__ rope, const int n_head,
-    const int n_kv, const float scale, unsigned long long* __restrict__ phase, const int exp,
-    unsigned* __restrict__ ticket, uint16_t* __restrict__ y, unsigned long long* __restrict__ mask_out, const float mask_tau) {
+    const int n_kv, const float scale, unsigned long long* __restrict__ phase) {
     constexpr int NW = NT / 64, hd = HD, SL = HD / 8, RW = 64 / SL;
     // PF row groups of K and of V leave before *pos is known; a workgroup with more than PF groups in range (cache positions
     // beyond PF x STEP x nsplit) keeps RD groups of each in flight from the moment it knows (rolling refill, see below)
     constexpr int PF = 4, RD = 8, STEP = NW * RW;
-    __shared__ unsigned fold_flag;
-    const bool fold = ticket != nullptr;  // merge folded into this launch (fold_merge): partials are published write-through
     const unsigned long long t_entry = wall_clock64();
     const int sp = blockIdx.x, kvh = blockIdx.z, h = kvh * rep + blockIdx.y;  // grid (nsplit, rep, n_kv): no division
     const int wg = h * nsplit + sp;            // linear index: partials, phase stamps
@@ -383,9 +341,8 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
     if (phase && threadIdx.x == 0) { phase[(size_t)wg * kPhaseRowA] = t_entry; phase[(size_t)wg * kPhaseRowA + 13] = ((unsigned long long)NW << 32) | (gridDim.x * gridDim.y * gridDim.z); }
     stamp_p(1);
     if (sp * STEP >= n) {  // no row group of this workgroup is in range yet (short sequence, many splits)
-        if (tid < hd) store_partial(out + 2 + tid, 0.0f, fold);
-        if (tid == 0) { store_partial(out, -INFINITY, fold); store_partial(out + 1, 0.0f, fold); }
-        if (fold) fold_merge<BF16, NT>(ticket, h, nsplit, h, 1, hd, partials, y, mask_out, mask_tau, &fold_flag);
+        if (tid < hd) out[2 + tid] = 0.0f;
+        if (tid == 0) { out[0] = -INFINITY; out[1] = 0.0f; }
         return;
     }
     const int nsteps = ((n + STEP - 1) / STEP - sp + nsplit - 1) / nsplit;  // local steps with a row in range
@@ -480,12 +437,7 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
 #pragma unroll
         for (int i = PF; i < RD; ++i) vreg[i] = v_roll(i);
     }
-    if (exp & 2) {  // A/B: the round-1 form (six ds_bpermute round trips)
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, d));
-    } else {
-        lmax = wave_max_f(lmax);  // row_shr DPP: lanes without a predecessor keep their own value (old = src)
-    }
+    lmax = wave_max_f(lmax);  // row_shr DPP: lanes without a predecessor keep their own value (old = src)
     if (lane == 0) red[wave] = lmax;
     __syncthreads();
     stamp_p(3);
@@ -539,17 +491,10 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
             }
         }
     }
-    if (exp & 4) {
-        for (int off = SL; off < 64; off <<= 1) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] += __shfl_xor(o[j], off);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if constexpr (SL <= 8) o[j] = xor_add<8>(o[j]);
-            o[j] = xor_add<32>(xor_add<16>(o[j]));
-        }
+    for (int j = 0; j < 8; ++j) {
+        if constexpr (SL <= 8) o[j] = xor_add<8>(o[j]);
+        o[j] = xor_add<32>(xor_add<16>(o[j]));
     }
     if (lane < SL) {
 #pragma unroll
@@ -561,10 +506,9 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
         float acc = 0.0f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) acc += part[w * hd + tid];
-        store_partial(out + 2 + tid, acc, fold);
+        out[2 + tid] = acc;
     }
-    if (tid == 0) { store_partial(out, mx, fold); store_partial(out + 1, tot, fold); }
-    if (fold) fold_merge<BF16, NT>(ticket, h, nsplit, h, 1, hd, partials, y, mask_out, mask_tau, &fold_flag);
+    if (tid == 0) { out[0] = mx; out[1] = tot; }
     stamp_p(7);
 }
 
@@ -644,12 +588,9 @@ __global__ __launch_bounds__(NT) void decode_attention_gqa_kernel(
     const int* __restrict__ pos_ptr, const float* __restrict__ qkv_slabs, uint16_t* __restrict__ k_cache,
     uint16_t* __restrict__ v_cache, const uint16_t* __restrict__ qkv, float* __restrict__ partials,
     const uint16_t* __restrict__ rope, const int n_head, const int n_kv, const int max_seq, const int nsplit,
-    const float scale, const int qkv_nslabs, const int lrows, unsigned* __restrict__ ticket, uint16_t* __restrict__ y,
-    unsigned long long* __restrict__ mask_out, const float mask_tau) {
+    const float scale, const int qkv_nslabs, const int lrows) {
     constexpr int NW = NT / 64, hd = HD, SL = HD / 8, RW = 64 / SL;
     constexpr int PF = 4, RD = 8, STEP = NW * RW;  // blind prefetch depth; depth of the stream once *pos is known
-    __shared__ unsigned fold_flag;
-    const bool fold = ticket != nullptr;  // merge folded into this launch (fold_merge): partials are published write-through
     constexpr int NPAIR = (REP + 2) * (HD / 2), NITEM = (NPAIR + NT - 1) / NT;  // q pairs of REP heads, k pairs, v pairs
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -710,9 +651,8 @@ __global__ __launch_bounds__(NT) void decode_attention_gqa_kernel(
     const int pos = min(max(pos_ptr[0], 0), max_seq - 1), n = pos + 1;
     auto out_of = [&](const int r) { return partials + ((size_t)(kvh * REP + r) * nsplit + sp) * (hd + 2); };
     if (sp * STEP >= n) {  // no row group of this workgroup is in range yet
-        for (int c = tid; c < REP * hd; c += NT) store_partial(out_of(c / hd) + 2 + (c % hd), 0.0f, fold);
-        if (tid < REP) { store_partial(out_of(tid), -INFINITY, fold); store_partial(out_of(tid) + 1, 0.0f, fold); }
-        if (fold) fold_merge<BF16, NT>(ticket, kvh, nsplit, kvh * REP, REP, hd, partials, y, mask_out, mask_tau, &fold_flag);
+        for (int c = tid; c < REP * hd; c += NT) out_of(c / hd)[2 + (c % hd)] = 0.0f;
+        if (tid < REP) { out_of(tid)[0] = -INFINITY; out_of(tid)[1] = 0.0f; }
         return;
     }
     const int nsteps = ((n + STEP - 1) / STEP - sp + nsplit - 1) / nsplit;
@@ -884,7 +824,7 @@ __global__ __launch_bounds__(NT) void decode_attention_gqa_kernel(
         float acc = 0.0f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) acc += part[w * REP * hd + c];
-        store_partial(out_of(c / hd) + 2 + (c % hd), acc, fold);
+        out_of(c / hd)[2 + (c % hd)] = acc;
     }
     if (tid < REP) {
         float tot = 0.0f;
@@ -893,10 +833,9 @@ __global__ __launch_bounds__(NT) void decode_attention_gqa_kernel(
         float m = red[tid * NW];
 #pragma unroll
         for (int w = 1; w < NW; ++w) m = fmaxf(m, red[tid * NW + w]);
-        store_partial(out_of(tid), m, fold);
-        store_partial(out_of(tid) + 1, tot, fold);
+        out_of(tid)[0] = m;
+        out_of(tid)[1] = tot;
     }
-    if (fold) fold_merge<BF16, NT>(ticket, kvh, nsplit, kvh * REP, REP, hd, partials, y, mask_out, mask_tau, &fold_flag);
 }
 
 // Merge launch (split counts the wo launch's merge producer does not take): one workgroup per head.  Lane s of every
@@ -910,7 +849,7 @@ __global__ __launch_bounds__(128) void decode_attention_merge_kernel(const float
                                                                      const float mask_tau, const int hd, const int nsplit) {
     const int h = blockIdx.x, tid = threadIdx.x;
     if (tid >= hd) return;  // hd = 64 or 128: whole waves
-    merge_head<BF16, false>(partials + (size_t)h * nsplit * (hd + 2), y + (size_t)h * hd,
+    merge_head<BF16>(partials + (size_t)h * nsplit * (hd + 2), y + (size_t)h * hd,
                             mask_out ? mask_out + ((size_t)h * hd >> 6) : nullptr, mask_tau, hd, nsplit, tid, tid & 63);
 }
 
@@ -1588,13 +1527,11 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
     // (the per-query-head kernel is 2-3 us faster below ~2 k positions: scripts/attention_context_sweep.py)
     const int rep = n_head / n_kv_head;
     const dim3 grid2(nsplit, rep, n_kv_head);  // the per-query-head kernel: (split, query head of the group, KV head), no division
-    bool gqa = ((rep == 8 && max_seq >= kGqaMinSeq8) || (rep == 4 && max_seq >= kGqaMinSeq)) && !(g_exp & 8) && !roped;
-    // y requested (the consumer does not merge): the merge can be FOLDED into the split launch — the last workgroup of a head
-    // (or KV-head group) to arrive merges it (prepared workspace) — instead of a merge launch.  MEASURED, NOT FASTER
-    // (profiles/r03_attention_context_sweep.txt): equal at 4-8 splits, 1-7 us slower at 16-32 (the last arriver's drain,
-    // ticket and cross-XCD loads of every split sit behind the slowest workgroup, where the merge launch spreads them over
-    // one workgroup per head).  Off unless teal_set_experiment bit 9 asks for it; bit-identical results either way.
-    unsigned* tk = (y && ws_prepared(ws, ws_bytes) && n_head <= kTicketTiles && (g_exp & 512)) ? ws_tickets(ws) : nullptr;
+    bool gqa = ((rep == 8 && max_seq >= kGqaMinSeq8) || (rep == 4 && max_seq >= kGqaMinSeq)) && !roped;
+    // (y requested — the consumer does not merge: a merge launch follows.  Folding the merge into the split launch by arrival
+    // tickets was built in round 3 and measured no faster — equal at 4-8 splits, 1-7 us slower at 16-32,
+    // profiles/r03_attention_context_sweep.txt — and is gone since round 5; `ws` is accepted for ABI stability and unused.)
+    (void)ws; (void)ws_bytes;
     auto* yo = reinterpret_cast<uint16_t*>(y);
     auto* mo = reinterpret_cast<unsigned long long*>(mask_out);
     if (gqa) {
@@ -1606,7 +1543,7 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
         if (glds > (dctx->gqa_lds_ok ? kGqaMaxLds : 64 * 1024)) gqa = false;
         else {
             const dim3 ggrid(n_kv_head * nsplit), gblock(GNT);
-#define TEAL_ATTG(BF, HDV, REPV) hipLaunchKernelGGL((decode_attention_gqa_kernel<BF, HDV, GNT, REPV>), ggrid, gblock, glds, st, pos, qkv_slabs, kc, vc, q, pw, r, n_head, n_kv_head, max_seq, nsplit, scale, qkv_nslabs, glocal, tk, yo, mo, mask_tau)
+#define TEAL_ATTG(BF, HDV, REPV) hipLaunchKernelGGL((decode_attention_gqa_kernel<BF, HDV, GNT, REPV>), ggrid, gblock, glds, st, pos, qkv_slabs, kc, vc, q, pw, r, n_head, n_kv_head, max_seq, nsplit, scale, qkv_nslabs, glocal)
 #define TEAL_ATTG_R(BF, HDV) do { if (rep == 8) TEAL_ATTG(BF, HDV, 8); else TEAL_ATTG(BF, HDV, 4); } while (0)
             if (dtype == TEAL_BF16) { if (head_dim == 128) TEAL_ATTG_R(true, 128); else TEAL_ATTG_R(true, 64); }
             else { if (head_dim == 128) TEAL_ATTG_R(false, 128); else TEAL_ATTG_R(false, 64); }
@@ -1616,7 +1553,7 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
     }
     if (!gqa) {
         if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
-#define TEAL_ATTS_R(BF, HDV, NTV, RP) hipLaunchKernelGGL((decode_attention_split_kernel<BF, HDV, NTV, RP>), grid2, block, lds, st, pos, kc, vc, q, max_seq, nsplit, rep, qkv_nslabs, qkv_slabs, pw, r, n_head, n_kv_head, scale, ph, g_exp, tk, yo, mo, mask_tau)
+#define TEAL_ATTS_R(BF, HDV, NTV, RP) hipLaunchKernelGGL((decode_attention_split_kernel<BF, HDV, NTV, RP>), grid2, block, lds, st, pos, kc, vc, q, max_seq, nsplit, rep, qkv_nslabs, qkv_slabs, pw, r, n_head, n_kv_head, scale, ph)
 #define TEAL_ATTS(BF, HDV, NTV) do { if (roped) TEAL_ATTS_R(BF, HDV, NTV, true); else TEAL_ATTS_R(BF, HDV, NTV, false); } while (0)
 #define TEAL_ATTS_NT(BF, HDV) do { if (nt == 1024) TEAL_ATTS(BF, HDV, 1024); else TEAL_ATTS(BF, HDV, 256); } while (0)
     if (dtype == TEAL_BF16) { if (head_dim == 128) TEAL_ATTS_NT(true, 128); else TEAL_ATTS_NT(true, 64); }
@@ -1626,7 +1563,7 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
 #undef TEAL_ATTS_R
     }
     if (hipGetLastError() != hipSuccess) return TEAL_ERR_LAUNCH;
-    if (!y || tk) return TEAL_OK;  // partials only: the consumer merges (TEAL_IN_ATTN_MERGE) — or merged inside the launch
+    if (!y) return TEAL_OK;  // partials only: the consumer merges (TEAL_IN_ATTN_MERGE)
     if (dtype == TEAL_BF16)
         hipLaunchKernelGGL((decode_attention_merge_kernel<true>), dim3(n_head), dim3(128), 0, st, pw, yo, mo, mask_tau, head_dim, nsplit);
     else
@@ -1694,7 +1631,7 @@ int teal_sample_topk_ws(const void* logits, int vocab, int dtype, int top_k, flo
 #define TEAL_SAMPLE(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len)
 #define TEAL_SAMPLE_W(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len, g_phase_stride ? nullptr : g_phase)
     const bool bf = dtype == TEAL_BF16;
-    if ((vocab & 7) == 0 && vocab > 8192 && vocab <= kSampMaxGroups * 8192 && top_k > 0 && top_k < vocab && ws_prepared(ws, ws_bytes) && !(g_exp & 16)) {
+    if ((vocab & 7) == 0 && vocab > 8192 && vocab <= kSampMaxGroups * 8192 && top_k > 0 && top_k < vocab && ws_prepared(ws, ws_bytes)) {
         // one workgroup per 8192 logits + the last arriver (sample_topk_multi_kernel)
         unsigned char* slot = ws_sampler(ws);  // scratch of the caller's prepared workspace (one per stream)
         const dim3 grid((vocab / 8 + 1023) / 1024), block(1024);

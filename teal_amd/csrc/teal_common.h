@@ -62,7 +62,6 @@ struct Params {
     int ws_ld;
     int cap;       // LDS list capacity (entries)
     int to_ws;     // 1: always write fp32 slabs (an epilogue kernel follows)
-    int swizzle;   // 1: XOR-swizzle tiles inside aligned groups of 8 (XCD decorrelation)
     int sl;        // wave-local + element-wise producer: the register cache holds only this slice's rounds
     int krt;       // wave-local: register-cache depth to launch (4, 8 or 16)
     int wl;        // 1: wave-local compaction (no cross-wave list, no barriers before the stream); cap = per-wave capacity
@@ -106,9 +105,7 @@ extern Config g_override;
 extern unsigned long long* g_phase;
 extern size_t g_phase_stride;
 extern int g_phase_seq;
-extern int g_swizzle;
 extern int g_wave_local;
-extern int g_exp;
 extern char g_last_desc[160];  // template instantiation + grid of the most recent GEMV launch (teal_last_launch_desc)
 
 // ---- caller-owned workspace --------------------------------------------------------------------------------------

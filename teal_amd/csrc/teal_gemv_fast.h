@@ -30,7 +30,7 @@ namespace teal {
     asm volatile("" ::"s"((a).w0), "s"((a).w1), "s"((a).y), "s"((a).ws), "s"((a).mask_out), "s"((a).resid_out),          \
                  "s"((a).phase), "s"((a).ticket), "s"((a).ld0), "s"((a).ld1), "s"((a).seg_tile1), "s"((a).seg_tile2), "s"((a).tau0),       \
                  "s"((a).tau1), "s"((a).tau2), "s"((a).mask_tau), "s"((a).ws_stride), "s"((a).att_hd), "s"((a).att_ns),  \
-                 "s"((a).cap), "s"((a).exp), "s"((a).w1_tile), "s"((a).scale0), "s"((a).scale1))
+                 "s"((a).cap), "s"((a).w1_tile), "s"((a).scale0), "s"((a).scale1))
 
 
 // LPR lanes x 16 B = BN columns per tile; KR = register-cached 64-element chunks per wave; U = 16-byte loads a lane has
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
                 if ((mask >> lane) & 1ull) list[nloc + lane_rank(mask)] = (((uint32_t)cidx[k] * 64u + lane) << 16) | xr[k];
                 nloc += __popcll(mask);
             }
-            if (k == 0 && KR > 1 && !(a.exp & 1)) {  // exp bit 0: no early issue (A/B)
+            if (k == 0 && KR > 1) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
         // with the wave index.  Measured, not derived: the arbiter serves the oldest wave first, and with only a few
         // batches per wave letting the youngest go first is worth 1.0 % of a Llama-2-7B token (0.7 % on Llama-3-8B),
         // while long lists lose 0.3-0.7 % (every row kept, or 8192-wide models) and keep the default.  Timing only.
-        prio_set = nloc < 6 * 4 * RPW && !(a.exp & 32);  // exp bit 5: off (A/B)
+        prio_set = nloc < 6 * 4 * RPW;
         if (prio_set) {
             switch (wave >> 2) {  // (oldest first made explicit: -1.2 %; interleaved, wave & 3: -0.8 % against this ramp)
                 case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -423,28 +423,18 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
     if constexpr (PHASE) { if (a.phase && lane == 0) a.phase[(size_t)bid * kPhaseRow + 16 + wave] = wall_clock64(); }
 
     // ---- reduce: row groups of the wave (shuffles), then waves in fixed order through LDS -------------------
-    if (a.exp & 4) {  // A/B: shuffles (ds_bpermute) for every butterfly step, as in round 1
+    // lane ^ 8 as a DPP row rotate, lane ^ 16 as a ds_swizzle swap, lane ^ 32 a shuffle (round 2: +0.7 % tokens/s over shuffles for
+    // every step; same pairs, same order: bit-identical)
 #pragma unroll
-        for (int off = LPR; off < 64; off <<= 1) {
+    for (int j = 0; j < CPL; ++j) {
+        if constexpr (LPR <= 8) acc[j] = xor_add<8>(acc[j]);
+        acc[j] = xor_add<32>(xor_add<16>(acc[j]));
+    }
+    if constexpr (PAIR) {
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) acc[j] += __shfl_xor(acc[j], off);
-            if constexpr (PAIR) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc2[j] += __shfl_xor(acc2[j], off);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-            if constexpr (LPR <= 8) acc[j] = xor_add<8>(acc[j]);
-            acc[j] = xor_add<32>(xor_add<16>(acc[j]));
-        }
-        if constexpr (PAIR) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if constexpr (LPR <= 8) acc2[j] = xor_add<8>(acc2[j]);
-                acc2[j] = xor_add<32>(xor_add<16>(acc2[j]));
-            }
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (LPR <= 8) acc2[j] = xor_add<8>(acc2[j]);
+            acc2[j] = xor_add<32>(xor_add<16>(acc2[j]));
         }
     }
     if (lane < LPR) {
@@ -567,6 +557,13 @@ hipError_t launch_fast_e(const FastLaunch& f, hipStream_t st) {
     const dim3 grid(f.ntiles, f.split), block(1024);
     if constexpr (!W8) {
         if (f.a.phase) {  // stamped instantiations (diagnostics: teal_set_phase_buffer), both activation dtypes
+            if constexpr (MODE == 1 && !PAIR) {
+                if (f.a.rope) {  // the stamped form of the RoPE / KV-append epilogue: a rope request never runs unrotated
+                    hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, true, 4, false, true>), grid, block, f.lds, st,
+                                       f.in0, f.in1, f.in2, f.row_index, f.Z, f.nslabs, f.eps, f.split, f.a);
+                    return hipGetLastError();
+                }
+            }
             hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, true>), grid, block, f.lds, st, f.in0, f.in1,
                                f.in2, f.row_index, f.Z, f.nslabs, f.eps, f.split, f.a);
             return hipGetLastError();

@@ -24,7 +24,6 @@ struct FastArgs {
     const uint16_t* scale0;         // int8 weights: per-column scales of image 0 / image 1 (element 0 = first column of the image)
     const uint16_t* scale1;
     int w1_tile;                    // not PAIR: first tile that streams the second image w1 / ld1 (INT_MAX: one image)
-    int exp;                        // experiment switches (teal_set_experiment; 0 in production): A/B inside one process
     // ROPE instantiations (TEAL_OUT_QKV_ROPE: the fused wqkv projection with split == 1): RoPE of q and of the new k row and
     // the KV-cache append happen in the epilogue (gpt-fast/model.py:170-178), so the attention launch starts from finished rows
     const uint16_t* rope;           // (cos, sin) table [max_seq][head_dim / 2][2]

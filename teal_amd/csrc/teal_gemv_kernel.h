@@ -111,13 +111,11 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_gemv_kernel(const Params p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // Column tiles are interleaved over hardware blocks (block b runs on XCD b % 8, so every XCD
     // walks the whole row range).  An XCD-contiguous tile range was measured 10-25 % slower.
-    int tile = blockIdx.x % p.ntiles;
+    const int tile = blockIdx.x % p.ntiles;
     const int slice = blockIdx.x / p.ntiles;
-    // Block b runs on XCD b % 8, so with tile = b % ntiles every XCD would only ever touch one
-    // residue class (mod 8) of column tiles, i.e. of DRAM channels; XOR-ing the low 3 tile bits with
-    // the next 3 keeps the set of tiles in flight identical but spreads each XCD over all residues.
-    if (p.swizzle == 1 && tile < (p.ntiles & ~7)) tile = (tile & ~7) | ((tile ^ (tile >> 3)) & 7);
-    if (p.swizzle >= 8 && tile < (p.ntiles & ~7)) tile = (tile & ~7) | ((tile + (p.swizzle - 8)) & 7);  // diagnostic rotation
+    // (Block b runs on XCD b % 8, so every XCD only ever touches one residue class mod 8 of column tiles; an XOR swizzle of the
+    // low tile bits that spreads each XCD over all residues measured neutral once the row stride is padded — DESIGN.md 3.1 — and is
+    // gone since round 5.)
 
     int s = 0;
     if (p.nseg > 1 && tile >= p.seg[1].tile0) s = 1;

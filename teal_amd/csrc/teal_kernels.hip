@@ -129,13 +129,8 @@ Config g_override = {0, 0, 0, 0};
 unsigned long long* g_phase = nullptr;
 size_t g_phase_stride = 0;  // > 0: consecutive GEMV launches stamp consecutive regions of this many uint64
 int g_phase_seq = 0;
-int g_swizzle = 0;
 int g_wave_local = 1;
 int g_fast = 1;  // lean kernel (teal_gemv_fast.h) where the shape qualifies
-static bool g_rope_taken = false;  // the most recent run_gemv launched a ROPE instantiation (TEAL_OUT_QKV_ROPE bookkeeping)
-// experiment switches handed to the lean kernel (teal_set_experiment); TEAL_EXPERIMENT=<mask> presets them for a whole
-// process (running the test suite under an experiment)
-int g_exp = getenv("TEAL_EXPERIMENT") ? atoi(getenv("TEAL_EXPERIMENT")) : 0;
 
 // ---- per-device properties (immutable once cached) ---------------------------------------------------------------
 constexpr int kMaxDevices = 64;
@@ -249,7 +244,7 @@ Config pick_config(int Z, int ncols_total, int nseg_tiles_hint) {
 // the gate|up pair, or gate | up as two unpaired segments), interleaved slabs or a single rounded output, wave-local
 // lists that fit; 16-bit weights, or int8 images in 128-column tiles (never paired).
 bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes, FastLaunch& f) {
-    if (!g_fast || c.waves != 16 || c.unroll != 4 || (c.lpr != 8 && c.lpr != 16) || p.swizzle) return false;
+    if (!g_fast || c.waves != 16 || c.unroll != 4 || (c.lpr != 8 && c.lpr != 16)) return false;
     if (p.w8 && (c.lpr != 16 || p.pair)) return false;
     if ((p.Z & 63) || p.Z > 65536 || !p.wl) return false;
     const int mode = p.in.mode;
@@ -327,7 +322,6 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
     f.a.tau0 = p.seg[0].tau; f.a.tau1 = p.seg[1].tau; f.a.tau2 = p.seg[2].tau;
     f.a.seg_tile1 = (!p.pair && p.nseg > 1) ? p.seg[1].tile0 : INT_MAX;
     f.a.seg_tile2 = (!p.pair && p.nseg > 2) ? p.seg[2].tile0 : INT_MAX;
-    f.a.exp = g_exp;
     f.a.act0 = p.act0;
     f.a.gate_act = p.in.gate_act;
     f.a.ws_stride = (to_ws || ticketed) ? ((c.split + 3) & ~3) : 0;
@@ -351,7 +345,9 @@ inline hipError_t launch_gemv(const Params& p, int dtype, size_t lds, const Conf
 // Common driver: fills geometry fields of `p` (segments' w/y/tau/ld/col0/ncols are set by the
 // caller), launches the GEMV and, if needed, the ordered slab reduce.
 int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStream_t st,
-             Config* used, bool few_slabs = false, bool interleave = false, bool caller_ws = true) {
+             Config* used, bool few_slabs = false, bool interleave = false, bool caller_ws = true, bool* rope_taken = nullptr) {
+    // *rope_taken: the launch ran a ROPE instantiation of the lean kernel (TEAL_OUT_QKV_ROPE bookkeeping; per call, no global)
+    if (rope_taken) *rope_taken = false;
     // caller_ws: `ws` is the caller's workspace (as opposed to an explicit slab destination, TEAL_OUT_SLABS).  A workspace
     // prepared by teal_workspace_init() starts with the header that holds the arrival counters: slabs go behind it.
     p.tickets = nullptr;
@@ -391,6 +387,11 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
         const int tiles = (total_cols + 63) / 64;
         int split = ncu / tiles;
         if (split > 8) split = 8;
+        // a slice of the wave-local compaction is a set of 16-chunk rounds: no more slices than rounds, or the launch falls
+        // back to the workgroup-wide list of the general kernel (round 5: the rank-local shapes of tensor parallelism — wo
+        // 2048 -> 4096 has two rounds, Llama-3-8B's wqkv / 2 four — ran 7.9-9.2 us that way, profiles/r05_tp_rank_local_launches.txt)
+        const int rounds = (((p.Z + 63) >> 6) + c.waves - 1) / c.waves;
+        if (g_wave_local && c.waves == 16 && split > rounds) split = rounds;
         if (split < 1) split = 1;
         c.split = split;
         while ((size_t)((p.Z + c.split - 1) / c.split) * 4 > 40 * 1024 && c.split < kMaxSplit) ++c.split;
@@ -483,7 +484,6 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
     p.ws = reinterpret_cast<float*>(ws);
     p.phase = g_phase ? g_phase + (size_t)g_phase_seq * g_phase_stride : nullptr;
     if (g_phase && g_phase_stride) ++g_phase_seq;
-    p.swizzle = g_swizzle;
     const size_t lds = lds_bytes(p.Z, p.wl ? p.cap * c.waves : p.cap, c.waves, c.lpr, p.pair != 0);
     if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
     p.ws_il = (interleave && to_ws && c.split <= 8) ? 1 : 0;
@@ -498,7 +498,7 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
         const bool lean = fast_eligible(p, c, to_ws, ws_bytes, f);
         if (p.rope && !lean) return TEAL_ERR_CONFIG;  // the RoPE epilogue exists in the lean kernel only: never fall through unrotated
         if (lean) {
-            g_rope_taken = f.a.rope != nullptr;
+            if (rope_taken) *rope_taken = f.a.rope != nullptr;
             // (the instantiation as rocprofv3 prints it: BF16, MODE, PAIR, LPR, KR, EXACT, PHASE, U, W8, ROPE)
             snprintf(g_last_desc, sizeof g_last_desc, "gemv_fast_kernel<%s,%d,%s,%d,%d,%s,%s%s,%s> grid (%d,%d) x 1024",
                      dtype == TEAL_BF16 ? "true" : "false", f.mode, f.pair ? "true" : "false", f.lpr, f.kr,
@@ -619,11 +619,6 @@ int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll) {
 
 const char* teal_last_launch_desc(void) { return g_last_desc; }
 
-int teal_set_experiment(int mask) {
-    g_exp = mask;
-    return TEAL_OK;
-}
-
 int teal_set_fast(int on) {
     g_fast = on ? 1 : 0;
     return TEAL_OK;
@@ -631,11 +626,6 @@ int teal_set_fast(int on) {
 
 int teal_set_wave_local(int on) {
     g_wave_local = on ? 1 : 0;
-    return TEAL_OK;
-}
-
-int teal_set_swizzle(int on) {
-    g_swizzle = on;
     return TEAL_OK;
 }
 
@@ -880,13 +870,13 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
         const Config c0 = pick_config(Z, total_cols, 3);
         bool fused = false;
         // (a 70B-class projection hands over row-sliced slabs of 128-column tiles instead — run_gemv's wide_sliced geometry,
-        //  measured faster there; experiment bit 10 takes the epilogue anyway, for A/B)
-        const bool sliced = (size_t)Z * total_cols >= (size_t)8192 * 8192 && !(g_exp & 1024);
+        //  measured faster there, profiles/r04_layer_experiments.txt)
+        const bool sliced = (size_t)Z * total_cols >= (size_t)8192 * 8192;
         if (c0.split == 1 && !sliced && g_fast && !g_override.split && !g_override.lpr) {
-            g_rope_taken = false;
-            rc = run_gemv(q, dtype, ws, ws_bytes, false, st, &used, false);
+            bool taken = false;
+            rc = run_gemv(q, dtype, ws, ws_bytes, false, st, &used, false, false, true, &taken);
             if (rc != TEAL_OK && rc != TEAL_ERR_CONFIG) return rc;  // TEAL_ERR_CONFIG: not a lean-kernel shape, nothing was launched
-            fused = rc == TEAL_OK && g_rope_taken;
+            fused = rc == TEAL_OK && taken;
             if (rc == TEAL_OK && !fused) return TEAL_ERR_LAUNCH;    // (unreachable: run_gemv refuses to launch a rope request unrotated)
         }
         if (fused) { *nslabs_out = 0; return TEAL_OK; }

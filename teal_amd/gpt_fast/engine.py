@@ -374,9 +374,7 @@ class DecodeEngine:
                                                           self.att_split, self.att_ws.data_ptr(), self.att_ws.numel() * 4,
                                                           self.code, self.ws.data_ptr(), self.ws.numel() * 4, self._stream)
         elif self.att_split:
-            # (with y requested — long contexts / grouped-query shapes — a merge launch follows the split launch; folding the
-            # merge into the split launch through the workspace's arrival counters is opt-in, teal_set_experiment bit 9:
-            # measured no faster, profiles/r03_attention_context_sweep.txt)
+            # (with y requested — long contexts / grouped-query shapes — a merge launch follows the split launch)
             rc = self.L.teal_decode_attention_split_ws(None, self.s_qkv.data_ptr(), self.n_qkv.value, self.rope.data_ptr(), pos_ptr,
                                                        kc.data_ptr(), vc.data_ptr(),
                                                        None if self.att_fused_merge else self.y_attn.data_ptr(), ymask, tau_o,

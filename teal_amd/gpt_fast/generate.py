@@ -398,6 +398,17 @@ class EngineDecoder:
         return self._engine
 
 
+def relayout_for_engine(model: Transformer) -> None:
+    """The fused engine re-lays every projection (and lm_head) out column-major when it is built — lazily, after the first
+    prefill.  Do it up front so that a prefill graph never captures pointers to storage that is freed later."""
+    from teal_amd.monkeypatch import UP_SHIFT_BYTES, to_column_major
+    for layer in model.layers:
+        for lin in (layer.attention.wqkv, layer.attention.wo, layer.feed_forward.w1, layer.feed_forward.w3, layer.feed_forward.w2):
+            if not hasattr(lin, "scales_and_zeros"):  # (an int4 image is packed column-gathered already)
+                to_column_major(lin, shift_bytes=UP_SHIFT_BYTES if lin is layer.feed_forward.w3 else 0)
+    to_column_major(model.output)
+
+
 @torch.no_grad()
 def generate(model: Transformer, prompt: torch.Tensor, max_new_tokens: int, decoder: GraphedDecoder,
              temperature: float = 0.8, top_k: Optional[int] = 200, prefill: Optional[GraphedPrefill] = None) -> torch.Tensor:
@@ -490,15 +501,13 @@ def main(args) -> Dict:
     if use_engine:
         assert thresholds is not None, "--engine needs thresholds (--hist_path or --synthetic)"
         decoder = EngineDecoder(model, thresholds, use_graph, args.temperature, args.top_k)
-        # the engine re-lays every projection (and lm_head) out column-major when it is built, lazily, after the first
-        # prefill: do it NOW so that a --compile_prefill graph never captures pointers to storage that is freed later
-        from teal_amd.monkeypatch import UP_SHIFT_BYTES, to_column_major
-        for layer in model.layers:
-            for lin in (layer.attention.wqkv, layer.attention.wo, layer.feed_forward.w1, layer.feed_forward.w3, layer.feed_forward.w2):
-                if not hasattr(lin, "scales_and_zeros"):  # (an int4 image is packed column-gathered already)
-                    to_column_major(lin, shift_bytes=UP_SHIFT_BYTES if lin is layer.feed_forward.w3 else 0)
-        to_column_major(model.output)
-    prefill = GraphedPrefill(model) if getattr(args, "compile_prefill", False) else None
+        relayout_for_engine(model)
+    # --compile captures the prompt pass as well (one hipGraph per prompt length; the reference compiles `prefill` only under
+    # --compile_prefill, generate.py:423-425 — its Inductor compile takes minutes, a capture here takes milliseconds, and the
+    # eager pass is ~400 launches = nine decode steps' worth for a 6-token prompt).  The prefill stays DENSE
+    # (kernels/sparse_gemv.py:271,298).  --eager_prefill keeps the op-by-op pass; a host-staged TP all-reduce cannot be captured.
+    want_graph_prefill = (getattr(args, "compile_prefill", False) or args.compile) and not getattr(args, "eager_prefill", False)
+    prefill = GraphedPrefill(model) if (want_graph_prefill and use_graph) else None
     tps, seqs = [], []
     start = -1 if args.compile else 0
     for i in range(start, args.num_samples):
@@ -555,7 +564,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--checkpoint_path", type=Path, default=Path("checkpoints/meta-llama/Llama-2-7b-chat-hf/model.pth"))
     p.add_argument("--compile", action="store_true", help="capture the decode step into a hipGraph")
     p.add_argument("--compile_prefill", action="store_true", help="capture the prompt pass into a hipGraph too "
-                   "(the reference's flag of the same name, generate.py:540)")
+                   "(the reference's flag of the same name, generate.py:540); implied by --compile here")
+    p.add_argument("--eager_prefill", action="store_true", help="with --compile: keep the prompt pass op by op (no prefill graph)")
     p.add_argument("--profile", type=Path, default=None)
     p.add_argument("--speculate_k", type=int, default=5, help="accepted for command-line compatibility; only read with a draft model")
     p.add_argument("--draft_checkpoint_path", type=Path, default=None, help="speculative decoding is outside this build (the "

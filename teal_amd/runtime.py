@@ -88,8 +88,12 @@ def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
         ws = _workspaces[key]
         # bound the per-stream entries of this device (each keeps ~ 8 x 2 x N x 4 bytes): oldest first, never the capture one
         mine = [k for k in _workspaces if k[0] == idx and k[1] != -1]
-        for k in mine[: max(0, len(mine) - _MAX_STREAM_WORKSPACES)]:
-            if k != key:
+        drop = [k for k in mine[: max(0, len(mine) - _MAX_STREAM_WORKSPACES)] if k != key]
+        if drop:
+            # launches queued on the evicted entries' streams may still write slabs / tickets into them: let the device drain
+            # before the allocator can hand the memory to anything else (eviction is rare: the ninth stream of a device)
+            torch.cuda.synchronize(idx)
+            for k in drop:
                 del _workspaces[k]
     return ws
 

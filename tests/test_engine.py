@@ -433,20 +433,17 @@ def test_decode_attention_split_long_context(dtype):
         bits = (y2.float().abs() > 0.02).view(-1, 64)
         got = torch.stack([(m2 >> i) & 1 for i in range(64)], dim=1).bool()
         assert torch.equal(bits, got)
-        # merge FOLDED into the split launch (arrival tickets in a prepared workspace; teal_decode_attention_split_ws): the same
-        # y and masks, bit for bit, as split + merge launch — three times over, so that the re-armed counters are exercised
+        # the general entry point (teal_decode_attention_split_ws; its workspace arguments are accepted and unused since round 5):
+        # the same y, masks and cache rows as teal_decode_attention_split
         wsp = runtime.reserve_workspace(64, 64)
-        L.teal_set_experiment(512)  # bit 9: fold on (not the default: measured no faster than split + merge)
-        for it in range(3):
-            kc3, vc3 = kc.clone(), vc.clone()
-            y3, m3 = torch.zeros_like(y1), torch.zeros_like(m1)
-            ws3 = torch.full_like(ws, float("nan"))
-            assert L.teal_decode_attention_split_ws(qkv.data_ptr(), None, 0, rope.data_ptr(), p.data_ptr(), kc3.data_ptr(), vc3.data_ptr(),
-                                                    y3.data_ptr(), m3.data_ptr(), 0.02, n_head, n_kv, hd, S, nsplit, ws3.data_ptr(),
-                                                    ws3.numel() * 4, code, wsp.data_ptr(), wsp.numel() * 4, runtime.stream_ptr()) == 0
-            assert torch.equal(y3.view(torch.int16), y2.view(torch.int16)) and torch.equal(m3, m2), (n_head, n_kv, hd, pos, nsplit, it)
-            assert torch.equal(kc3, kc2) and torch.equal(vc3, vc2)
-        L.teal_set_experiment(0)
+        kc3, vc3 = kc.clone(), vc.clone()
+        y3, m3 = torch.zeros_like(y1), torch.zeros_like(m1)
+        ws3 = torch.full_like(ws, float("nan"))
+        assert L.teal_decode_attention_split_ws(qkv.data_ptr(), None, 0, rope.data_ptr(), p.data_ptr(), kc3.data_ptr(), vc3.data_ptr(),
+                                                y3.data_ptr(), m3.data_ptr(), 0.02, n_head, n_kv, hd, S, nsplit, ws3.data_ptr(),
+                                                ws3.numel() * 4, code, wsp.data_ptr(), wsp.numel() * 4, runtime.stream_ptr()) == 0
+        assert torch.equal(y3.view(torch.int16), y2.view(torch.int16)) and torch.equal(m3, m2), (n_head, n_kv, hd, pos, nsplit)
+        assert torch.equal(kc3, kc2) and torch.equal(vc3, vc2)
 
 
 @pytest.mark.parametrize("name,block,plen,fused", [("tiny-test", 4096, 3000, True), ("tiny-test", 8192, 5000, False),
@@ -602,20 +599,24 @@ def test_sampler_window_and_radix_kernels_pick_the_same_tokens(dtype, V, law):
     ws = runtime.reserve_workspace(64, 64)  # prepared (teal_workspace_init): its header holds the multi-workgroup scratch
     for top_k, temp in ((200, 0.8), (20, 1.0), (1, 1.0), (0, 1.0), (5000, 2.0), (V - 1, 1.5)):
         outs = []
-        # multi-workgroup kernel (8192 < V <= 131072, filter on), single-workgroup window kernel, generic radix kernel
-        for logits, n, exp in ((base, V, 0), (padded, V + 4, 0), (base, V, 16)):
-            L.teal_set_experiment(exp)
+        # multi-workgroup kernel (8192 < V <= 131072, filter on, prepared workspace), generic radix kernel (padded vocabulary), and
+        # the single-workgroup window kernel (the same logits without a workspace: teal_sample_topk)
+        for logits, n, use_ws in ((base, V, True), (padded, V + 4, True), (base, V, False)):
             state = torch.tensor([1234, 0], dtype=torch.int64, device=DEV)
             pos = torch.tensor([11], dtype=torch.int32, device=DEV)
             hist = torch.full((64,), -1, dtype=torch.int32, device=DEV)
             seq = []
             for _ in range(24):
-                assert L.teal_sample_topk_ws(logits.data_ptr(), n, code, top_k, temp, state.data_ptr(), tok.data_ptr(), pos.data_ptr(),
-                                             hist.data_ptr(), 64, ws.data_ptr(), ws.numel() * 4, runtime.stream_ptr()) == 0
+                if use_ws:
+                    rc = L.teal_sample_topk_ws(logits.data_ptr(), n, code, top_k, temp, state.data_ptr(), tok.data_ptr(), pos.data_ptr(),
+                                               hist.data_ptr(), 64, ws.data_ptr(), ws.numel() * 4, runtime.stream_ptr())
+                else:
+                    rc = L.teal_sample_topk(logits.data_ptr(), n, code, top_k, temp, state.data_ptr(), tok.data_ptr(), pos.data_ptr(),
+                                            hist.data_ptr(), 64, runtime.stream_ptr())
+                assert rc == 0
                 seq.append(int(tok.item()))
             assert int(state[1]) == 24 and int(pos[0]) == 11 + 24 and hist[:24].tolist() == seq
             outs.append(seq)
-        L.teal_set_experiment(0)
         assert outs[0] == outs[1], (top_k, outs[0][:8], outs[1][:8])
         assert outs[0] == outs[2], (top_k, outs[0][:8], outs[2][:8])
         assert max(outs[0]) < V
