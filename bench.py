@@ -339,6 +339,41 @@ def roofline_engine_gateup(eng, a):
                       "per-launch time includes the same-stream launch boundary, like rocprofv3's per-dispatch duration"}
 
 
+def floor_model(st_sparse, st_dense, n_layer):
+    """Why the ratio is what it is, from numbers measured in this run (DecodeEngine.stage_times on the sparse and on the dense
+    engine): each GEMV launch type fitted as t = fixed + bytes / stream_rate through its two measured points (kept rows at the
+    configured sparsity, every row kept).  `fixed_us` is everything a launch pays whatever it streams — the launch boundary,
+    entry skew, the producer's round trip, list build, the memory pipeline's fill and drain, the tail (phase-stamp breakdown:
+    profiles/r04_layer_experiments.txt) — and is the same for the dense comparator, which is why the layer ratio sits near
+    (F + D) / (F + D / 2) and not near 2."""
+    gemv = ("qkv", "wo", "gate_up", "down")
+    out = {"launch": {}, "unit": "us per launch (hipGraph of that stage over all layers, HIP events, incl. the launch boundary)"}
+    F = 0.0
+    for k in gemv:
+        ts, td, bs, bd = st_sparse[k], st_dense[k], st_sparse["bytes"][k], st_dense["bytes"][k]
+        rate = (bd - bs) / (td - ts) if td > ts else float("nan")   # bytes per us = MB/s
+        fixed = ts - bs / rate
+        F += fixed
+        out["launch"][k] = {"us_sparse": round(ts, 2), "us_dense": round(td, 2), "MB_sparse": round(bs / 1e6, 2), "MB_dense": round(bd / 1e6, 2),
+                            "stream_TBps": round(rate / 1e6, 2), "fixed_us": round(fixed, 2),
+                            "of_8TBps_sparse": round(bs / ts / 8e6, 3), "of_8TBps_dense": round(bd / td / 8e6, 3)}
+    att_s, att_d = st_sparse["attn"], st_dense["attn"]
+    Ds = sum(st_sparse[k] - out["launch"][k]["fixed_us"] for k in gemv)
+    Dd = sum(st_dense[k] - out["launch"][k]["fixed_us"] for k in gemv)
+    out["attention_us"] = {"sparse": round(att_s, 2), "dense": round(att_d, 2)}
+    out["layer_us"] = {"sparse_measured": round(st_sparse["layer"], 2), "dense_measured": round(st_dense["layer"], 2),
+                       "sparse_sum_of_launches": round(sum(st_sparse[k] for k in gemv) + att_s, 2),
+                       "dense_sum_of_launches": round(sum(st_dense[k] for k in gemv) + att_d, 2)}
+    out["fixed_us_per_layer"] = round(F, 2)
+    out["streaming_us_per_layer"] = {"sparse": round(Ds, 2), "dense": round(Dd, 2)}
+    out["layer_ratio"] = {"measured": round(st_dense["layer"] / st_sparse["layer"], 3),
+                          "model (fixed + attention + streaming)": round((F + att_d + Dd) / (F + att_s + Ds), 3),
+                          "if the fixed per-launch cost and the attention launch were free": round(Dd / Ds, 3)}
+    out["note"] = ("fixed_us = launch boundary + entry + producer + list + memory-pipeline fill/drain + tail, paid per launch by sparse and "
+                   "dense alike; stream_TBps = the slope between the two measured points of a launch type")
+    return out
+
+
 def pmc_traffic_live(cfg, a, kernel_desc, pair=False, timeout_s=150):
     """HBM read bytes per launch of the dominant kernel, measured IN THIS RUN: scripts/pmc_gateup.py (the same launch on its
     own: same entry point, geometry and kept fraction) as a subprocess under `rocprofv3 --kernel-trace --pmc FETCH_SIZE`
@@ -583,8 +618,11 @@ def main():
         if t_pf:
             out["tokens_per_sec_reference_definition"] = 200.0 / (t_pf + 200.0 * t / a.steps)
             out["prefill_ms"] = t_pf * 1e3
+    st_sparse = None
     if rank == 0 and world == 1:
         out["roofline"] = roofline_engine_gateup(info["engine"], a) if mode == "engine" else roofline_dominant_kernel(model, a)
+        if mode == "engine" and not a.no_dense and info["engine"].att_fused_merge:
+            st_sparse = info["engine"].stage_times()
         if not a.no_dense:
             # dense comparator on the same harness: same kernels with every row kept (threshold < 0)
             a_d = argparse.Namespace(**vars(a))
@@ -592,10 +630,12 @@ def main():
             dmodel = model
             if mode == "engine":
                 from teal_amd.gpt_fast.engine import make_engine_stepper
-                dstep, _ = make_engine_stepper(dmodel, a_d)
+                dstep, dinfo = make_engine_stepper(dmodel, a_d)
             else:
-                dstep, _ = make_stepper(dmodel, a_d)
+                dstep, dinfo = make_stepper(dmodel, a_d)
             td = timed_decode(dstep, max(20, a.steps // 2), max(5, a.warmup // 2), 1)
+            if st_sparse is not None:
+                out["floor_model"] = floor_model(st_sparse, dinfo["engine"].stage_times(), cfg.n_layer)
             dense_tps = max(20, a.steps // 2) / td
             out["dense_tokens_per_sec"] = dense_tps
             out["speedup_vs_dense"] = tps / dense_tps

@@ -350,11 +350,14 @@ class DecodeEngine:
         local = (((max_seq + step - 1) // step + nsplit - 1) // nsplit) * step
         return ((rep + 2) * (hd // 2) + 2 * rep * nw + rep * max(local, nw * hd)) * 4
 
-    def _layer(self, i: int, tok_ptr: int, pos_ptr: int, hook=None):
-        """The five launches of layer i (module docstring)."""
+    def _layer(self, i: int, tok_ptr: int, pos_ptr: int, hook=None, only=None):
+        """The five launches of layer i (module docstring).  `only` (measurements: stage_times): launch just these stages, on
+        whatever the buffers hold from the last full step."""
         cfg = self.cfg
         k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out, tau_o = self.stages[i]
         cb = hook if hook else (lambda *a: None)
+        if only is not None:
+            return self._layer_only(i, tok_ptr, pos_ptr, only)
         if i == 0:
             k1_in.row_index = tok_ptr
         else:
@@ -403,6 +406,112 @@ class DecodeEngine:
             self._reduce_slabs(self.s_down, self.n_down.value)
         cb("after", "down", i)
 
+    def _layer_only(self, i: int, tok_ptr: int, pos_ptr: int, only):
+        cfg = self.cfg
+        k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out, tau_o = self.stages[i]
+        if "qkv" in only:
+            if i == 0:
+                k1_in.row_index = tok_ptr
+            else:
+                k1_in.nslabs = self.n_down.value
+            if self.rope_epilogue:
+                k1_out.rope_pos = pos_ptr
+            self._gemv(k1_in, k1_out, self.dim, self.n_qkv if self.att_split else None)
+        if "attn" in only:
+            assert self.att_split and self.att_fused_merge, "stage timing covers the split attention merged by wo"
+            if self.rope_epilogue and self.n_qkv.value == 0:
+                rc = self.L.teal_decode_attention_split_roped(self.qkv.data_ptr(), pos_ptr, kc.data_ptr(), vc.data_ptr(), None, None, tau_o,
+                                                              cfg.n_head, cfg.n_local_heads, cfg.head_dim, self.max_seq, self.att_split,
+                                                              self.att_ws.data_ptr(), self.att_ws.numel() * 4, self.code, self.ws.data_ptr(),
+                                                              self.ws.numel() * 4, self._stream)
+            else:
+                rc = self.L.teal_decode_attention_split_ws(None, self.s_qkv.data_ptr(), self.n_qkv.value, self.rope.data_ptr(), pos_ptr,
+                                                           kc.data_ptr(), vc.data_ptr(), None, None, tau_o, cfg.n_head, cfg.n_local_heads,
+                                                           cfg.head_dim, self.max_seq, self.att_split, self.att_ws.data_ptr(),
+                                                           self.att_ws.numel() * 4, self.code, self.ws.data_ptr(), self.ws.numel() * 4, self._stream)
+            if rc != 0:
+                _lib.check(rc, "teal_decode_attention")
+        if "wo" in only:
+            self._gemv(k3_in, k3_out, self.qdim, self.n_wo)
+        if "gate_up" in only:
+            k4_in.nslabs = self.n_wo.value
+            self._gemv(k4_in, k4_out, self.dim)
+        if "down" in only:
+            self._gemv(k5_in, k5_out, self.inter, self.n_down)
+
+    @torch.no_grad()
+    def stage_times(self, reps: int = 20) -> Dict[str, float]:
+        """Microseconds per launch, by stage: a hipGraph of that ONE stage over every layer (each layer's own weights: far
+        beyond the Infinity Cache), HIP events around the replays, incl. the same-stream launch boundary; "layer" = the five
+        launches of every layer in their real order.  Run after at least one full step (the buffers hold valid hand-overs).
+        Measurement only: the KV row of the current position is rewritten with the same values."""
+        assert self.reduce is None
+        names = ("qkv", "attn", "wo", "gate_up", "down")
+        out = {}
+        tok_ptr, pos_ptr = self.tok_buf.data_ptr(), self.pos_buf.data_ptr()
+        pos0 = self.pos_buf.clone()
+        # algorithmic bytes per launch ON THE STATE THE STAGE'S GRAPH RUNS ON (every layer's launch consumes what the hand-over
+        # buffers hold — a stage's replays do not modify its own inputs — with its own weights and thresholds): kept rows x row
+        # bytes + the vectors in and out
+        ths, wbytes = self.thresholds(), (1 if self.int8 else 2)
+        dim, qd, kv, inter, L_ = self.dim, self.qdim, self.kv, self.inter, len(self.stages)
+
+        def stage_bytes(key):
+            ns_d, ns_w, ns_q = self.n_down.value, self.n_wo.value, self.n_qkv.value
+            if key == "attn":
+                return 2 * self.cfg.n_local_heads * (int(pos0.item()) + 1) * self.cfg.head_dim * 2
+            tot = 0
+            for i in range(L_):
+                x = self._site_from_buffers(key, i, int(self.tok_buf.view(-1)[0]))
+                if key == "qkv":
+                    tot += sum(int((x > ths[i][p]).sum()) * n for p, n in (("q", qd), ("k", kv), ("v", kv))) * wbytes
+                elif key == "gate_up":
+                    tot += (int((x > ths[i]["gate"]).sum()) + int((x > ths[i]["up"]).sum())) * inter * wbytes
+                else:
+                    tot += int((x > ths[i]["o" if key == "wo" else "down"]).sum()) * dim * wbytes
+            vec = {"qkv": dim * 2 + ns_d * dim * 4 + dim * 2 + (max(ns_q, 1) * self.nqkv * (4 if ns_q else 2)),
+                   "wo": self.cfg.n_head * self.att_split * (self.cfg.head_dim + 2) * 4 + ns_w * dim * 4,
+                   "gate_up": dim * 2 + ns_w * dim * 4 + dim * 2 + 2 * inter * 2,
+                   "down": 2 * inter * 2 + ns_d * dim * 4}[key]
+            return tot / L_ + vec
+
+        out["bytes"] = {}
+        for key in names + ("layer",):
+            only = set(names) if key == "layer" else {key}
+
+            def run():
+                self._stream = runtime.stream_ptr()
+                for i in range(len(self.stages)):
+                    self._layer(i, tok_ptr, pos_ptr, only=only)
+
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                run()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            if key != "layer":
+                out["bytes"][key] = stage_bytes(key)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                run()
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                g.replay()
+                e1.record()
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3 / len(self.stages))
+            ts.sort()
+            out[key] = ts[len(ts) // 2]
+            del g
+        self.pos_buf.copy_(pos0)
+        return out
+
     def _reduce_slabs(self, slabs: torch.Tensor, n: int):
         """Tensor parallelism: the ONE sum over the ranks per attention and per MLP (gpt-fast/tp.py:120-121, 139-140), taken on
         the fp32 split-K slabs of the row-wise projection [dim][(n + 3) & ~3] before anything is rounded: the consumer's
@@ -416,9 +525,25 @@ class DecodeEngine:
         """|activation| every projection of every layer consumes in ONE decode step, restated with torch ops from the
         engine's own buffers while the step runs (sites as in the reference: q/k/v <- attention input, o <- attention
         output, gate/up <- MLP input, down <- silu(gate) * up).  Measurement / calibration only."""
-        dt, dim, inter = self.dtype, self.dim, self.inter
         out: List[Dict[str, torch.Tensor]] = [dict() for _ in self.stages]
+
+        def hook(when, stage, i):
+            if i < 0 or when != "before":
+                return
+            site = {"qkv": "attn_in", "wo": "attn_out", "gate_up": "mlp_in", "down": "mlp_mid"}.get(stage)
+            if site is not None:
+                out[i][site] = self._site_from_buffers(stage, i, int(idx.view(-1)[0]))
+
+        self(idx, input_pos, hook=hook)
+        return out
+
+    @torch.no_grad()
+    def _site_from_buffers(self, stage: str, i: int, token: int = 0) -> torch.Tensor:
+        """|activation| the launch `stage` of layer i would consume from what the hand-over buffers hold RIGHT NOW, restated
+        with torch ops (residual + slabs -> RMSNorm; the split-KV merge; silu(gate) * up)."""
+        dt, dim, inter = self.dtype, self.dim, self.inter
         A, B = self.resid
+        layer = self.model.layers[i]
 
         def slab_sum(slabs, n, ncols):
             st = (n + 3) & ~3
@@ -433,37 +558,28 @@ class DecodeEngine:
             hf = h.float()
             return ((hf * torch.rsqrt(hf.pow(2).mean() + self.eps)).to(dt) * w).float().abs()
 
-        def hook(when, stage, i):
-            if i < 0 or when != "before":
-                return
-            layer = self.model.layers[i]
-            if stage == "qkv":
-                if i == 0:
-                    resid, y = self.model.tok_embeddings.weight[int(idx.view(-1)[0])], None
-                else:
-                    resid, y = A, slab_sum(self.s_down, self.n_down.value, dim)
-                out[i]["attn_in"] = normed(resid, y, layer.attention_norm.weight)
-            elif stage == "wo":
-                if self.att_fused_merge:
-                    ns, hd = self.att_split, self.cfg.head_dim
-                    p = self.att_ws[: self.cfg.n_head * ns * (hd + 2)].view(self.cfg.n_head, ns, hd + 2)
-                    m, l, o = p[:, :, 0], p[:, :, 1], p[:, :, 2:]
-                    f = torch.where(l > 0, torch.exp(m - m.max(dim=1, keepdim=True).values), torch.zeros_like(m))
-                    out[i]["attn_out"] = ((o * f[:, :, None]).sum(1) / (l * f).sum(1, keepdim=True)).reshape(-1).to(dt).float().abs()
-                else:
-                    out[i]["attn_out"] = self.y_attn.float().abs().clone()
-            elif stage == "gate_up":
-                out[i]["mlp_in"] = normed(B, slab_sum(self.s_wo, self.n_wo.value, dim), layer.ffn_norm.weight)
-            elif stage == "down":
-                if self.pair:
-                    out[i]["mlp_mid"] = self.h_mlp.float().abs().clone()
-                else:
-                    g, u = self.gu[:inter].float(), self.gu[inter:]
-                    sg = self.gu[:inter] if self.gate_act else torch.nn.functional.silu(g).to(dt)  # (act_seg0: silu already applied)
-                    out[i]["mlp_mid"] = (sg * u).float().abs()
-
-        self(idx, input_pos, hook=hook)
-        return out
+        if stage == "qkv":
+            if i == 0:
+                resid, y = self.model.tok_embeddings.weight[token], None
+            else:
+                resid, y = A, slab_sum(self.s_down, self.n_down.value, dim)
+            return normed(resid, y, layer.attention_norm.weight)
+        if stage == "wo":
+            if self.att_fused_merge:
+                ns, hd = self.att_split, self.cfg.head_dim
+                p = self.att_ws[: self.cfg.n_head * ns * (hd + 2)].view(self.cfg.n_head, ns, hd + 2)
+                m, l, o = p[:, :, 0], p[:, :, 1], p[:, :, 2:]
+                f = torch.where(l > 0, torch.exp(m - m.max(dim=1, keepdim=True).values), torch.zeros_like(m))
+                return ((o * f[:, :, None]).sum(1) / (l * f).sum(1, keepdim=True)).reshape(-1).to(dt).float().abs()
+            return self.y_attn.float().abs().clone()
+        if stage == "gate_up":
+            return normed(B, slab_sum(self.s_wo, self.n_wo.value, dim), layer.ffn_norm.weight)
+        assert stage == "down"
+        if self.pair:
+            return self.h_mlp.float().abs().clone()
+        g, u = self.gu[:inter].float(), self.gu[inter:]
+        sg = self.gu[:inter] if self.gate_act else torch.nn.functional.silu(g).to(dt)  # (act_seg0: silu already applied)
+        return (sg * u).float().abs()
 
     SITE = {"q": "attn_in", "k": "attn_in", "v": "attn_in", "o": "attn_out", "gate": "mlp_in", "up": "mlp_in", "down": "mlp_mid"}
 

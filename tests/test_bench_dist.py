@@ -42,3 +42,23 @@ def test_bench_cli_contract():
         assert (a.gpus, a.steps, a.warmup) == (8, 50, 5)
     finally:
         sys.argv = old
+
+
+def test_floor_model_recovers_fixed_cost_and_stream_rate():
+    """bench.floor_model fits t = fixed + bytes / rate per launch type through the sparse and the dense point; on numbers made
+    from a known model (4 launches, 5.5 us fixed each, 7.7 MB/us, 4.4 us attention) it returns that model and its layer ratio."""
+    import bench
+    fixed, rate, att = 5.5, 7.7e6, 4.4
+    dense_mb = {"qkv": 100.7e6, "wo": 33.6e6, "gate_up": 180.4e6, "down": 90.2e6}
+    mk = lambda frac: dict({k: fixed + frac * v / rate for k, v in dense_mb.items()}, attn=att,  # noqa: E731
+                           bytes={k: frac * v for k, v in dense_mb.items()})
+    s, d = mk(0.5), mk(1.0)
+    s["layer"] = sum(s[k] for k in dense_mb) + att
+    d["layer"] = sum(d[k] for k in dense_mb) + att
+    m = bench.floor_model(s, d, 32)
+    for k in dense_mb:
+        assert abs(m["launch"][k]["fixed_us"] - fixed) < 0.02 and abs(m["launch"][k]["stream_TBps"] - 7.7) < 0.02
+    assert abs(m["fixed_us_per_layer"] - 4 * fixed) < 0.05
+    assert abs(m["layer_ratio"]["measured"] - d["layer"] / s["layer"]) < 1e-3
+    assert abs(m["layer_ratio"]["model (fixed + attention + streaming)"] - m["layer_ratio"]["measured"]) < 2e-3
+    assert abs(m["layer_ratio"]["if the fixed per-launch cost and the attention launch were free"] - 2.0) < 1e-2
