@@ -103,8 +103,10 @@ def test_rank_local_launches_vs_oracle(oracle, name, dtype, world, dim, n_head, 
         one), so the fp32 partial sums may associate differently: within one output ulp of the unsharded launch's columns"""
         a_ = O.from_bits(bits_from_torch(y_loc), dtype).astype(np.float64)
         b_ = O.from_bits(bits_from_torch(y_ref), dtype).astype(np.float64)
-        ulp = np.maximum(O.ulp16(a_, dtype), O.ulp16(b_, dtype))  # (one ulp of the larger binade when the pair straddles a power of two)
-        assert (np.abs(a_ - b_) <= ulp).all(), (name, what, float(np.abs(a_ - b_).max()))
+        # one ulp of the larger binade when the pair straddles a power of two; plus the fp32 reassociation noise itself, which
+        # exceeds the 16-bit spacing for outputs near zero (sums of ~4000 terms with partial sums of order 1: ~2e-6 observed)
+        tol = np.maximum(O.ulp16(a_, dtype), O.ulp16(b_, dtype)) + 1e-5
+        assert (np.abs(a_ - b_) <= tol).all(), (name, what, float((np.abs(a_ - b_) / tol).max()))
 
     def local_geometry(n_local, nseg):
         cfgv = (ctypes.c_int * 5)()

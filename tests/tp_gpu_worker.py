@@ -77,7 +77,11 @@ def main():
             res["reduces_per_step"] = calls["n"] // (1 + 4)  # one forward call + four decode_n steps
             nkv = part.config.n_local_heads
             kc_p = part.layers[1].attention.kv_cache.k_cache[0, :, :P + 1]
-            res["kv_rows_equal"] = bool(torch.allclose(kc_p.float(), kc_f[rank * nkv:(rank + 1) * nkv].float(), atol=2e-2, rtol=2e-2))
+            # (layer 1's rows: its input went through layer 0's 16-bit all-reduce of rounded partials on the module path — a few
+            #  output ulps: 2^-10 relative in fp16, 2^-7 in bf16)
+            tol = 2e-2 if dt == torch.float16 else 1e-1
+            res["kv_rows_equal"] = bool(torch.allclose(kc_p.float(), kc_f[rank * nkv:(rank + 1) * nkv].float(), atol=tol, rtol=tol))
+            res["kv_rows_max_err"] = float((kc_p.float() - kc_f[rank * nkv:(rank + 1) * nkv].float()).abs().max())
         else:
             kf = eng_p.kept_fractions(tok, pos)
             res["kept_o"], res["kept_down"] = kf["o"], kf["down"]
