@@ -202,11 +202,6 @@ typedef struct teal_gemv_in {
                                * act_seg0 = 1 — so x = round(gate * up): the same roundings as the unfused sequence
                                * (model.py:258-259), the activation computed once per column instead of in every consumer
                                * workgroup's prologue.  16-bit and int8 weights (not the int4 kernel) */
-#ifdef TEAL_R05_EXPERIMENTS   /* experiment builds only (scripts/micro/layer_bench; never the product library) */
-    const float* sumsq_in;    /* RESID_NORM without slabs: per-64-column partial sums of h^2 written by the producing launch
-                               * (teal_gemv_out_t.sumsq_out): the consumer skips its cross-wave sum and barrier */
-    int sumsq_n;              /* number of partials (dim / 64) */
-#endif
 } teal_gemv_in_t;
 
 typedef struct teal_gemv_out {
@@ -246,14 +241,6 @@ typedef struct teal_gemv_out {
     int act_seg0;              /* TEAL_OUT_ROUNDED: y[0] = round(silu(round(sum))) for segment 0 (the gate projection of an
                                 * unpaired gate | up launch, model.py:258); the other segments are stored as usual.  16-bit
                                 * and int8 weights (not the int4 kernel) */
-#ifdef TEAL_R05_EXPERIMENTS    /* experiment builds only */
-    const void* resid_add;     /* TEAL_OUT_ROUNDED, one segment, lean kernel: y = round(resid_add + round(sum)) — the residual add
-                                * of model.py:158-161 done by the projection (split-K: by the last slice of a tile to arrive) */
-    float* sumsq_out;          /* with resid_add: [ncols / 64] partial sums of y^2 for the consumer's RMSNorm */
-    int att_fold;              /* TEAL_OUT_QKV_ROPE: the attention of a head runs inside this launch (MHA, head_dim 128, 64-column
-                                * tiles), on the workgroups of the head's q and k tiles once all six tiles of the head arrived */
-    float* att_partials;       /* att_fold: split-KV partials [n_head][4][head_dim + 2], as teal_decode_attention_split writes */
-#endif
 } teal_gemv_out_t;
 
 /* One launch: [fused producer] -> mask + compaction -> gathered GEMV over every segment.
@@ -351,11 +338,6 @@ int teal_set_wave_local(int on);
 /* Diagnostics: kernel template instantiation and grid of the most recent GEMV launch of this process (host-side
  * string; e.g. for naming the kernel in a benchmark record). */
 const char* teal_last_launch_desc(void);
-
-#ifdef TEAL_R05_EXPERIMENTS
-/* experiment builds only: bit mask read at launch time (round-5 levers, scripts/micro/layer_bench LB_EXP / LB_AB) */
-int teal_r05_experiment(int mask);
-#endif
 
 /* Lean kernel for qualifying shapes (default on; 0 forces the general kernel everywhere: A/B and parity tests). */
 int teal_set_fast(int on);

@@ -90,13 +90,6 @@ int main(int argc, char** argv) {
     int use_rope = getenv("LB_ROPE") ? atoi(getenv("LB_ROPE")) : 1;  // RoPE + KV append in the qkv launch's epilogue (TEAL_OUT_QKV_ROPE)
     float sparsity = 0.5f;
     bool phase = false, dense = false, bf = false;
-#ifdef TEAL_R05_EXPERIMENTS
-    // round-5 lever (b): wo / down add the residual themselves (tickets) and hand the consumers h (16 bit); LB_SLIM=2: plus the
-    // per-64-column sums of h^2, so that the RESID_NORM consumers skip their cross-wave sum and barrier
-    int slim = getenv("LB_SLIM") ? atoi(getenv("LB_SLIM")) : 0;
-    // round-5 lever (a): the attention of a head runs inside the qkv launch (no attention launch)
-    int fold = getenv("LB_FOLD") ? atoi(getenv("LB_FOLD")) : 0;
-#endif
     std::string model = "7b";
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -135,9 +128,10 @@ int main(int argc, char** argv) {
     if (ncu <= 0) { fprintf(stderr, "no device\n"); return 1; }
     hipStream_t st; CK(hipStreamCreate(&st));
     g_st = st; g_trace = getenv("LB_TRACE") != nullptr;
-    // experiment builds only (-DTEAL_R05_EXPERIMENTS, teal_amd/_lib.py TEAL_EXTRA_FLAGS): the switch is absent from the product library
+    // a library built for an experiment may export a switch (`teal_experiment(mask)`; the product library has none): LB_EXP runs the
+    // whole benchmark under a mask, LB_AB times the token step without and with it in one process
     typedef int (*exp_fn_t)(int);
-    exp_fn_t set_exp = (exp_fn_t)dlsym(RTLD_DEFAULT, "teal_r05_experiment");
+    exp_fn_t set_exp = (exp_fn_t)dlsym(RTLD_DEFAULT, "teal_experiment");
     if (getenv("LB_EXP")) { if (!set_exp) { fprintf(stderr, "LB_EXP: this libteal_hip.so has no experiment switch\n"); return 2; } TK(set_exp(atoi(getenv("LB_EXP")))); }
     hipStream_t st2; CK(hipStreamCreate(&st2));
     hipStream_t ls = st;  // the stream the k_* launch helpers use
@@ -206,9 +200,6 @@ int main(int argc, char** argv) {
     { int32_t p = pos0, t = 3; CK(hipMemcpy(pos, &p, 4, hipMemcpyHostToDevice)); CK(hipMemcpy(tok, &t, 4, hipMemcpyHostToDevice));
       unsigned long long r[2] = {1234, 0}; CK(hipMemcpy(rng, r, 16, hipMemcpyHostToDevice)); }
     const bool fused_merge = (att_split == 4 && qd <= 16384) || (att_split == 8 && qd <= 8192);
-#ifdef TEAL_R05_EXPERIMENTS
-    float* sumsq = (float*)allocz(256 * 4);
-#endif
     const float NEG = -INFINITY, eps = 1e-5f;
     int n_qkv = 0, n_wo = 0, n_down = 0;
 
@@ -236,20 +227,12 @@ int main(int argc, char** argv) {
             o.mode = TEAL_OUT_QKV_ROPE; o.y[0] = q_rot; o.rope = rope; o.rope_pos = pos; o.k_cache = l.kc; o.v_cache = l.vc;
             o.rope_head_dim = hd; o.rope_max_seq = max_seq;
         }
-#ifdef TEAL_R05_EXPERIMENTS
-        if (slim && i > 0) { in.resid_in = B; in.slabs = nullptr; in.nslabs = 0; in.resid_out = nullptr;  // down left h in B
-                             if (slim > 1) { in.sumsq_in = sumsq; in.sumsq_n = dim / 64; } }
-        if (fold && use_rope) { o.att_fold = 1; o.att_partials = att_ws; }
-#endif
         apply_tune("qkv");
         TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, &n_qkv, ls));
     };
     auto k_attn = [&](int i, bool to_y, float tau_o) {
         Layer& l = Ls[i];
         apply_tune("attn");
-#ifdef TEAL_R05_EXPERIMENTS
-        if (fold && use_rope && n_qkv == 0 && !to_y) return;  // the qkv launch wrote the partials
-#endif
         if (n_qkv == 0)
             TK(teal_decode_attention_split_roped(q_rot, pos, l.kc, l.vc, to_y ? y_attn : nullptr, y_mask, tau_o, S.n_head, S.n_kv, hd, max_seq,
                                                  att_split, att_ws, att_bytes, dt, nullptr, 0, ls));
@@ -264,9 +247,6 @@ int main(int argc, char** argv) {
         else { in.mode = TEAL_IN_MASKED; in.x = y_attn; in.masks = y_mask; }
         const void* w[1] = {l.wo}; const int ld[1] = {ldo}; const int c0[1] = {0}; const int nc[1] = {dim}; const float tau[1] = {to};
         teal_gemv_out_t o = mk_out(1, w, ld, c0, nc, tau, nullptr, TEAL_OUT_SLABS, s_wo);
-#ifdef TEAL_R05_EXPERIMENTS
-        if (slim) { o.mode = TEAL_OUT_ROUNDED; o.slabs = nullptr; o.y[0] = A; o.resid_add = B; if (slim > 1) o.sumsq_out = sumsq; }  // A = B + wo(y)
-#endif
         apply_tune("wo");
         TK(teal_fused_gemv(&in, &o, qd, dt, ws, ws_bytes, &n_wo, ls));
     };
@@ -277,9 +257,6 @@ int main(int argc, char** argv) {
         in.norm_weight = l.norm2; in.eps = eps; in.resid_out = A;
         const void* w[2] = {l.w1, l.w3}; const int ld[2] = {ldi, ldi}; const int c0[2] = {0, 0}; const int nc[2] = {inter, inter};
         const float tau[2] = {tg, tg};
-#ifdef TEAL_R05_EXPERIMENTS
-        if (slim) { in.resid_in = A; in.slabs = nullptr; in.nslabs = 0; in.resid_out = nullptr; if (slim > 1) { in.sumsq_in = sumsq; in.sumsq_n = dim / 64; } }
-#endif
         apply_tune("gu");
         if (pair) {
             void* y[2] = {h_mlp, nullptr};
@@ -300,9 +277,6 @@ int main(int argc, char** argv) {
         else { in.mode = TEAL_IN_SILU_MUL; in.x = gu; in.gate_activated = gate_act; }
         const void* w[1] = {l.w2}; const int ld[1] = {ldd}; const int c0[1] = {0}; const int nc[1] = {dim}; const float tau[1] = {td};
         teal_gemv_out_t o = mk_out(1, w, ld, c0, nc, tau, nullptr, TEAL_OUT_SLABS, s_down);
-#ifdef TEAL_R05_EXPERIMENTS
-        if (slim) { o.mode = TEAL_OUT_ROUNDED; o.slabs = nullptr; o.y[0] = B; o.resid_add = A; if (slim > 1) o.sumsq_out = sumsq; }  // B = A + down(h)
-#endif
         apply_tune("down");
         TK(teal_fused_gemv(&in, &o, inter, dt, ws, ws_bytes, &n_down, ls));
     };
@@ -313,9 +287,6 @@ int main(int argc, char** argv) {
         const void* w[1] = {wout}; const int ld[1] = {ldv}; const int c0[1] = {0}; const int nc[1] = {S.vocab}; const float tau[1] = {NEG};
         void* y[1] = {logits};
         teal_gemv_out_t o = mk_out(1, w, ld, c0, nc, tau, y, TEAL_OUT_ROUNDED, nullptr);
-#ifdef TEAL_R05_EXPERIMENTS
-        if (slim) { in.resid_in = B; in.slabs = nullptr; in.nslabs = 0; if (slim > 1) { in.sumsq_in = sumsq; in.sumsq_n = dim / 64; } }
-#endif
         apply_tune("head");
         TK(teal_fused_gemv(&in, &o, dim, dt, ws, ws_bytes, nullptr, ls));
     };
@@ -584,57 +555,6 @@ int main(int argc, char** argv) {
                sb / (rounds - 1), (sb / sa - 1.0) * 100.0);
         return 0;
     }
-#ifdef TEAL_R05_EXPERIMENTS
-    if (getenv("LB_SLIMAB") || getenv("LB_FOLDAB")) {
-        // in-process A/B of a round-5 lever: the token step captured without and with it, timed alternately
-        const bool is_slim = getenv("LB_SLIMAB") != nullptr;
-        int& sw = is_slim ? slim : fold;
-        const int on = atoi(getenv(is_slim ? "LB_SLIMAB" : "LB_FOLDAB")), s0 = sw;
-        {   // same bits either way: what the lever hands to the next launch
-            auto snap = [&](const void* d, size_t bytes) { std::vector<unsigned char> h(bytes); CK(hipStreamSynchronize(st)); CK(hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost)); return h; };
-            int bad = 0;
-            for (int i : {0, 1, n_layer - 2}) {
-                Layer& l = Ls[i];
-                std::vector<unsigned char> ref[4];
-                for (int pass = 0; pass < 2; ++pass) {
-                    sw = pass ? on : 0;
-                    for (int e = 0; e < i; ++e) { Layer& q = Ls[e]; k_qkv(e, q.tq); k_attn(e, !fused_merge, q.to); k_wo(e, q.to); k_gu(e, q.tg, q.td); k_down(e, q.td); }
-                    k_qkv(i, l.tq); k_attn(i, !fused_merge, l.to);
-                    auto a0 = snap(att_ws, att_bytes);
-                    k_wo(i, l.to); k_gu(i, l.tg, l.td);
-                    auto g0 = snap(gu, (size_t)2 * inter * 2);
-                    k_down(i, l.td);
-                    if (i + 1 < n_layer) k_qkv(i + 1, Ls[i + 1].tq);
-                    auto q0 = snap(q_rot, (size_t)nqkv * 2);
-                    auto r0 = snap(B, dim * 2);
-                    if (!pass) { ref[0] = a0; ref[1] = g0; ref[2] = q0; ref[3] = r0; }
-                    else {
-                        auto df = [&](const std::vector<unsigned char>& x, const std::vector<unsigned char>& y) { size_t n = 0; for (size_t k = 0; k < x.size(); ++k) n += x[k] != y[k]; return n; };
-                        const size_t d0 = df(ref[0], a0), d1 = df(ref[1], g0), d2 = df(ref[2], q0), d3 = df(ref[3], r0);
-                        printf("  lever verify layer %d: attention partials %zu, gate|up %zu, next q (rotated) %zu, residual B %zu bytes differ\n", i, d0, d1, d2, d3);
-                        bad += (d3 != 0) + ((is_slim && on > 1) ? 0 : (d0 != 0) + (d1 != 0) + (d2 != 0));
-                    }
-                }
-            }
-            sw = s0;
-            // (slim = 2 hands over sum h^2 summed in another order: rstd may differ in the last place, so gate|up / q may; the
-            //  residual stream and, for the fold, everything must be bit-identical)
-            if (bad) { printf("lever verify FAILED\n"); if (!getenv("LB_VERIFY_SOFT")) return 3; }
-        }
-        sw = 0; token_step(); CK(hipStreamSynchronize(st)); hipGraphExec_t ga = capture(token_step);
-        sw = on; token_step(); CK(hipStreamSynchronize(st)); hipGraphExec_t gb = capture(token_step);
-        sw = s0;
-        double sa = 0, sb = 0; const int rounds = 6;
-        for (int r = 0; r < rounds; ++r) {
-            const double ta = time_graph(ga, steps, true), tb = time_graph(gb, steps, true);
-            printf("  %s A/B round %d: base %.1f us  lever(%d) %.1f us\n", is_slim ? "slim" : "fold", r, ta, on, tb);
-            if (r) { sa += ta; sb += tb; }
-        }
-        printf("%s A/B mean (rounds 1..): base %.1f us/token, lever(%d) %.1f us/token  -> %+.2f %%  (%+.2f us per layer)\n", is_slim ? "slim" : "fold",
-               sa / (rounds - 1), on, sb / (rounds - 1), (sb / sa - 1.0) * 100.0, (sb - sa) / (rounds - 1) / n_layer);
-        return 0;
-    }
-#endif
     if (getenv("LB_PAIRAB")) {
         // A/B inside one process: gate|up as ONE paired launch (silu * up + masks in its epilogue, MODE 3 down) against two
         // unpaired threshold segments of 128-column tiles (256-byte row segments) + a silu * up producer in down (MODE 2)

@@ -49,9 +49,6 @@ struct InSpec {
     const unsigned long long* masks;  // mode 3: keep masks (one per 64 activations) emitted by the producer
     float eps;
     int gate_act;              // mode 2: the gate half already holds round(silu(gate)): x = round(gate * up)
-#ifdef TEAL_R05_EXPERIMENTS
-    const float* sumsq_in; int sumsq_n;
-#endif
 };
 
 struct Params {
@@ -79,9 +76,6 @@ struct Params {
     const uint16_t* rope; const int* rope_pos; uint16_t* kc; uint16_t* vc;
     int rope_hd, rope_max_seq;
     int act0;                   // rounded output of segment 0 goes through silu (and is rounded again)
-#ifdef TEAL_R05_EXPERIMENTS
-    const uint16_t* resid_add; float* sumsq_out; float* att_out;
-#endif
     Seg seg[kMaxSeg];
 };
 
@@ -112,9 +106,6 @@ extern unsigned long long* g_phase;
 extern size_t g_phase_stride;
 extern int g_phase_seq;
 extern int g_wave_local;
-#ifdef TEAL_R05_EXPERIMENTS
-extern int g_r05;
-#endif
 extern char g_last_desc[160];  // template instantiation + grid of the most recent GEMV launch (teal_last_launch_desc)
 
 // ---- caller-owned workspace --------------------------------------------------------------------------------------

@@ -40,16 +40,12 @@ namespace teal {
 //   masks (in0 x, in1 masks); 4 split-KV attention partials (in0).  Element-wise modes (0, 2, 3, 4) cache the rounds of
 //   the workgroup's own slice only: register k <-> chunk slice + split * (wave + 16 k).
 //   EXACT (MODE 1): Z == 1024 * KR, every cached chunk exists — no clamps, no guards.
-//   ATT (round-5 experiment builds, lever (a)): the ROPE launch also runs the decode attention of every head, on the workgroups
-//   of the head's q and k tiles, once the head's six tiles have arrived (no attention launch).
-template <bool BF16, int MODE, bool PAIR, int LPR, int KR, bool EXACT, bool PHASE, int U = 4, bool W8 = false, bool ROPE = false,
-          bool ATT = false>
+template <bool BF16, int MODE, bool PAIR, int LPR, int KR, bool EXACT, bool PHASE, int U = 4, bool W8 = false, bool ROPE = false>
 __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const void* in1, const void* in2,
                                                          const int* row_index, const int Z, const int nslabs,
                                                          const float eps, const int split_p, const FastArgs a) {
     static_assert(!(W8 && PAIR), "int8 gate|up runs unpaired (two images of 128-byte row segments)");
     static_assert(!ROPE || (MODE == 1 && !PAIR && !W8), "the RoPE / KV-append epilogue belongs to the fused wqkv projection");
-    static_assert(!ATT || (ROPE && LPR == 8 && !PHASE), "the folded attention rides on the ROPE launch with 64-column tiles");
     constexpr int WAVES = 16;
     constexpr int RPW = 64 / LPR;
     // a lane owns 8 columns: 16 bytes of 16-bit weights, 8 bytes of int8 weights (the same lane <-> row mapping, hence the
@@ -84,9 +80,6 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
     float sumsq_part = 0.0f;
     int rope_p = 0;            // ROPE: clamped position of the token
     uint32_t rope_cs = 0u;     // ROPE: (cos | sin << 16) of this thread's column pair
-    [[maybe_unused]] bool fold_el = false;   // ATT: this workgroup attends (q / k tile of its head)
-    [[maybe_unused]] int fold_h = 0, fold_sp = 0;
-    [[maybe_unused]] u32x4 fold_k[ATT ? 4 : 1], fold_v[ATT ? 4 : 1];
     float rv[MODE == 1 ? KR : 1];
     uint32_t wb[MODE == 1 ? KR : 1];
     unsigned long long mk[MODE == 3 ? KR : 1];
@@ -127,14 +120,6 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
             for (int k = 0; k < KR; ++k) v1[k] = *reinterpret_cast<const f32x4*>(slabs + mel[k] * stride + 4);
         }
         TEAL_FAST_ARGS_BATCH(a);
-#ifdef TEAL_R05_EXPERIMENTS
-        // lever (b): per-64-column partial sums of h^2 handed over by the producing launch: every wave sums them itself
-        float sq_part = 0.0f;
-        if (a.sumsq_in) {
-            sq_part = lane < a.sumsq_n ? a.sumsq_in[lane] : 0.0f;
-            if (a.sumsq_n > 64) sq_part += lane + 64 < a.sumsq_n ? a.sumsq_in[lane + 64] : 0.0f;
-        }
-#endif
         if constexpr (ROPE) {
             // position and the (cos, sin) pair of this thread's output column: requested now, used in the epilogue.  Issued by
             // EVERY thread (unconditional: the compiler's vmcnt bookkeeping stays exact), the same 4 bytes per column pair
@@ -145,27 +130,6 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
             const uint32_t jj = (cc & (uint32_t)(a.rope_hd - 1)) >> 1;  // head_dim is 64 or 128
             rope_cs = *reinterpret_cast<const uint32_t*>(a.rope + ((size_t)rope_p * (size_t)(a.rope_hd >> 1) + jj) * 2);
         }
-#ifdef TEAL_R05_EXPERIMENTS
-        if constexpr (ATT) {
-            // lever (a): which head this tile belongs to and which quarter of the head's cached positions this workgroup will
-            // attend over (sp: q tiles 0 / 1, k tiles 2 / 3; the v tiles only publish).  The K / V rows of positions < pos do
-            // not depend on this launch: the four row groups of the blind range (positions < 256) are requested NOW, by every
-            // wave alike (waves 4..15 and the v tiles repeat addresses of waves 0..3: an unconditional issue keeps the
-            // compiler's vmcnt bookkeeping exact), and sit in registers through the stream.
-            const int c0 = tile * BN;
-            if (c0 < a.rope_dim) { fold_el = true; fold_h = c0 >> 7; fold_sp = (c0 >> 6) & 1; }
-            else if (c0 < a.rope_dim + a.rope_kv) { fold_el = true; fold_h = (c0 - a.rope_dim) >> 7; fold_sp = 2 + (((c0 - a.rope_dim) >> 6) & 1); }
-            else { fold_h = (c0 - a.rope_dim - a.rope_kv) >> 7; }
-            const uint16_t* kcb = a.kc + (size_t)fold_h * (size_t)a.rope_max_seq * 128u + (lane & 15) * 8;
-            const uint16_t* vcb = a.vc + (size_t)fold_h * (size_t)a.rope_max_seq * 128u + (lane & 15) * 8;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = min((fold_sp + 4 * i) * 16 + (wave & 3) * 4 + (lane >> 4), a.rope_max_seq - 1);
-                fold_k[i] = *reinterpret_cast<const u32x4*>(kcb + (size_t)r * 128u);
-                fold_v[i] = *reinterpret_cast<const u32x4*>(vcb + (size_t)r * 128u);
-            }
-        }
-#endif
         stamp(1);
         // slab order 0, 1, 2, ... (the order of the ordered reduce launch); adding an absent slab as 0.0f is exact
         float ysum[KR];
@@ -198,21 +162,12 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
         }
         stamp(8);
         float* sumsq = reinterpret_cast<float*>(smem);
-        float tot;
-#ifdef TEAL_R05_EXPERIMENTS
-        if (a.sumsq_in) {
-            tot = wave_sum_f(sq_part);  // no LDS, no barrier
-            stamp(9);
-        } else
-#endif
-        {
         const float ssw = wave_sum_f(sumsq_part);
         if (lane == 0) sumsq[wave] = ssw;
         __syncthreads();
         stamp(9);
-        tot = (lane < WAVES) ? sumsq[lane] : 0.0f;
+        float tot = (lane < WAVES) ? sumsq[lane] : 0.0f;
         tot = wave_sum_f(tot);
-        }
         const float rstd = rsqrtf(tot / (float)Z + eps);
         uint16_t* rout = reinterpret_cast<uint16_t*>(a.resid_out);
         const bool writer = rout && blockIdx.x == 0 && blockIdx.y == 0;  // (not via bid: gridDim.x is a scalar load)
@@ -539,24 +494,6 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
                 const float cs = bits_to_float(rope_cs & 0xFFFFu, BF16), sn = bits_to_float(rope_cs >> 16, BF16);
                 const uint16_t rb = float_to_bits<BF16>((tid & 1) ? rope_odd(pr, f, cs, sn) : rope_even(f, pr, cs, sn));
                 const uint32_t dimq = (uint32_t)a.rope_dim, kvw = (uint32_t)a.rope_kv, hdm = (uint32_t)a.rope_hd;
-#ifdef TEAL_R05_EXPERIMENTS
-                if constexpr (ATT) {
-                    // published write-through (agent-scope relaxed atomic store = global_store ... sc1), two columns per store:
-                    // the attending workgroups of the head read them past their XCD's L2
-                    const bool isq = c < dimq, isk = !isq && c < dimq + kvw;
-                    const uint32_t mine = (isq || isk) ? rb : b16;
-                    const uint32_t pk = mine | ((uint32_t)__shfl_xor((int)mine, 1) << 16);
-                    if (!(tid & 1)) {
-                        uint16_t* dst;
-                        if (isq) dst = reinterpret_cast<uint16_t*>(a.y) + c;
-                        else {
-                            const uint32_t cc = c - dimq - (isk ? 0u : kvw);
-                            dst = (isk ? a.kc : a.vc) + ((size_t)(cc / hdm) * (size_t)a.rope_max_seq + (size_t)rope_p) * hdm + (cc & (hdm - 1u));
-                        }
-                        __hip_atomic_store(reinterpret_cast<uint32_t*>(dst), pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                } else
-#endif
                 if (c < dimq) {
                     reinterpret_cast<uint16_t*>(a.y)[c] = rb;
                 } else {
@@ -567,17 +504,6 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
                 }
             } else if (a.act0 && s == 0) {  // the gate tiles of gate | up: activation applied here (model.py:258)
                 reinterpret_cast<uint16_t*>(a.y)[c] = silu_bits<BF16>(gs);
-#ifdef TEAL_R05_EXPERIMENTS
-            } else if (a.resid_add) {
-                const float yv = bits_to_float(float_to_bits<BF16>(gs), BF16);
-                const uint16_t hb = float_to_bits<BF16>(bits_to_float(a.resid_add[c], BF16) + yv);
-                reinterpret_cast<uint16_t*>(a.y)[c] = hb;
-                if (a.sumsq_out) {
-                    const float hv = bits_to_float(hb, BF16);
-                    const float sq = wave_sum_f(hv * hv);
-                    if (lane == 0) a.sumsq_out[c >> 6] = sq;
-                }
-#endif
             } else {
                 reinterpret_cast<uint16_t*>(a.y)[c] = float_to_bits<BF16>(gs);
             }
@@ -607,162 +533,11 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
                 float sum = 0.0f;
                 for (int sl = 0; sl < split; ++sl)
                     sum += __hip_atomic_load(&a.ws[c * (uint32_t)a.ws_stride + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                uint16_t ob = (a.act0 && s == 0) ? silu_bits<BF16>(sum) : float_to_bits<BF16>(sum);
-#ifdef TEAL_R05_EXPERIMENTS
-                if (a.resid_add) {
-                    ob = float_to_bits<BF16>(bits_to_float(a.resid_add[c], BF16) + bits_to_float(ob, BF16));
-                    if (a.sumsq_out) {
-                        const float hv = bits_to_float(ob, BF16);
-                        const float sq = wave_sum_f(hv * hv);
-                        if (lane == 0) a.sumsq_out[c >> 6] = sq;
-                    }
-                }
-#endif
-                reinterpret_cast<uint16_t*>(a.y)[c] = ob;
+                reinterpret_cast<uint16_t*>(a.y)[c] = (a.act0 && s == 0) ? silu_bits<BF16>(sum) : float_to_bits<BF16>(sum);
                 if (tid == 0) __hip_atomic_store(&a.ticket[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
-#ifdef TEAL_R05_EXPERIMENTS
-    if constexpr (ATT) {
-        // ---- lever (a): the head's attention, after all six tiles of the head have published ----------------------------------
-        constexpr int NWA = 4, HD = 128, SLA = 16, RWA = 4, STEPA = NWA * RWA, NSP = 4;  // the 4-wave split kernel's geometry
-        unsigned* tk = a.att_ticket + 2 * fold_h;
-        float* fl = reinterpret_cast<float*>(smem);          // [0]: spin result; then red[2 * NWA] | part[NWA][HD] | sc[...]
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(&tk[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!fold_el) return;                                 // (workgroup-uniform: the v tiles are done)
-        if (tid == 0) {
-            // bounded spin: all 192 workgroups of the launch are resident at once (one 16-wave workgroup per CU, 256 CUs)
-            unsigned spins = 0;
-            while (__hip_atomic_load(&tk[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 6u) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 22)) __builtin_trap();  // never hang the device: fail loudly
-            }
-            const unsigned d = __hip_atomic_fetch_add(&tk[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (d == 3u) {  // the last of the head's four attending workgroups past its spin re-arms both counters
-                __hip_atomic_store(&tk[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&tk[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        __syncthreads();
-        const bool act = wave < NWA;
-        const int ds = lane & 15, rw = lane >> 4, rbase = (wave & 3) * RWA + rw;
-        const int pos = rope_p, n = pos + 1, sp = fold_sp;
-        auto row_of = [&](const int i) { return (sp + i * NSP) * STEPA + rbase; };
-        float* red = fl + 4;
-        float* part = red + 2 * NWA;
-        float* sc = part + NWA * HD;
-        float* out = a.att_out + (size_t)(fold_h * NSP + sp) * (HD + 2);
-        const uint16_t* kcb = a.kc + (size_t)fold_h * (size_t)a.rope_max_seq * HD;
-        const uint16_t* vcb = a.vc + (size_t)fold_h * (size_t)a.rope_max_seq * HD;
-        auto ld4 = [&](const uint16_t* p) {  // 16 bytes past this XCD's L2 (written by another workgroup of this launch)
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
-            u32x4 r;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = __hip_atomic_load(q + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return r;
-        };
-        if (sp * STEPA >= n) {  // no row group in range yet (workgroup-uniform)
-            if (tid < HD) out[2 + tid] = 0.0f;
-            if (tid == 0) { out[0] = -INFINITY; out[1] = 0.0f; }
-            return;
-        }
-        const int nsteps = ((n + STEPA - 1) / STEPA - sp + NSP - 1) / NSP;
-        float qv[8];
-        float lmax = -INFINITY;
-        if (act) {
-            const u32x4 qraw = ld4(reinterpret_cast<const uint16_t*>(a.y) + (size_t)fold_h * HD + ds * 8);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {  // the token's own row: published by the head's k / v tiles a moment ago
-                if (row_of(i) == pos) { fold_k[i] = ld4(kcb + (size_t)pos * HD + ds * 8); fold_v[i] = ld4(vcb + (size_t)pos * HD + ds * 8); }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                qv[2 * j] = bits_to_float(qraw[j] & 0xFFFFu, BF16);
-                qv[2 * j + 1] = bits_to_float(qraw[j] >> 16, BF16);
-            }
-            auto score_row = [&](const int i, const u32x4 w) {
-                const int t = row_of(i);
-                float s_ = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {  // explicit FMAs: the attention unit compiles with contraction on, this one with it off
-                    s_ = fmaf(qv[2 * j], bits_to_float(w[j] & 0xFFFFu, BF16), s_);
-                    s_ = fmaf(qv[2 * j + 1], bits_to_float(w[j] >> 16, BF16), s_);
-                }
-                s_ = row_slices_sum<SLA>(s_);
-                const float sv = bits_to_float(float_to_bits<BF16>(s_ * a.att_scale), BF16);
-                if (t < n) {
-                    if (ds == 0) sc[i * STEPA + rbase] = sv;
-                    lmax = fmaxf(lmax, sv);
-                }
-            };
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < nsteps) score_row(i, fold_k[i]);
-            for (int i = 4; i < nsteps; ++i)  // past the blind range (positions >= 256): one row group per round trip
-                score_row(i, *reinterpret_cast<const u32x4*>(kcb + (size_t)min(row_of(i), n - 1) * HD + ds * 8));
-            lmax = wave_max_f(lmax);
-            if (lane == 0) red[wave] = lmax;
-        }
-        __syncthreads();
-        float mx = red[0];
-#pragma unroll
-        for (int w = 1; w < NWA; ++w) mx = fmaxf(mx, red[w]);
-        float lsum = 0.0f;
-        if (act) {
-            for (int e = tid; e < nsteps * STEPA; e += NWA * 64) {
-                const int t = (sp + (e / STEPA) * NSP) * STEPA + (e % STEPA);
-                if (t < n) {
-                    const float ex = expf(sc[e] - mx);
-                    sc[e] = ex;
-                    lsum += ex;
-                }
-            }
-            lsum = wave_sum_f(lsum);
-            if (lane == 0) red[NWA + wave] = lsum;
-        }
-        __syncthreads();
-        float tot = 0.0f;
-#pragma unroll
-        for (int w = 0; w < NWA; ++w) tot += red[NWA + w];
-        if (act) {
-            float o[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = 0.0f;
-            auto pv_row = [&](const int i, const u32x4 w) {
-                const int t = row_of(i);
-                if (t >= n) return;
-                const float pr = sc[i * STEPA + rbase];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    o[2 * j] = fmaf(pr, bits_to_float(w[j] & 0xFFFFu, BF16), o[2 * j]);
-                    o[2 * j + 1] = fmaf(pr, bits_to_float(w[j] >> 16, BF16), o[2 * j + 1]);
-                }
-            };
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < nsteps) pv_row(i, fold_v[i]);
-            for (int i = 4; i < nsteps; ++i)
-                pv_row(i, *reinterpret_cast<const u32x4*>(vcb + (size_t)min(row_of(i), n - 1) * HD + ds * 8));
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = xor_add<32>(xor_add<16>(o[j]));
-            if (lane < SLA) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) part[wave * HD + lane * 8 + j] = o[j];
-            }
-        }
-        __syncthreads();
-        if (tid < HD) {
-            float acc_ = 0.0f;
-#pragma unroll
-            for (int w = 0; w < NWA; ++w) acc_ += part[w * HD + tid];
-            out[2 + tid] = acc_;
-        }
-        if (tid == 0) { out[0] = mx; out[1] = tot; }
-    }
-#endif
     stamp(7);
     if constexpr (PHASE) {
         if (a.phase && tid == 0) {
@@ -794,15 +569,6 @@ hipError_t launch_fast_e(const FastLaunch& f, hipStream_t st) {
             return hipGetLastError();
         }
     }
-#ifdef TEAL_R05_EXPERIMENTS
-    if constexpr (MODE == 1 && !PAIR && !W8 && LPR == 8 && KR == 4) {
-        if (f.a.rope && f.a.att_out) {  // lever (a): the attention folded into the qkv launch
-            hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, false, 4, W8, true, true>), grid, block, f.lds, st, f.in0,
-                               f.in1, f.in2, f.row_index, f.Z, f.nslabs, f.eps, f.split, f.a);
-            return hipGetLastError();
-        }
-    }
-#endif
     if constexpr (MODE == 1 && !PAIR && !W8) {
         if (f.a.rope) {  // fused wqkv projection, split == 1: RoPE + KV-cache append in the epilogue
             hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, false, 4, W8, true>), grid, block, f.lds, st, f.in0, f.in1,

@@ -33,16 +33,6 @@ struct FastArgs {
     int rope_hd, rope_dim, rope_kv, rope_max_seq;  // head_dim, n_head * head_dim, n_kv_head * head_dim, cache rows
     int act0;                       // rounded output of threshold segment 0 goes through silu (the gate of gate | up)
     int gate_act;                   // MODE 2: the gate half already holds round(silu(gate))
-#ifdef TEAL_R05_EXPERIMENTS
-    const uint16_t* resid_add;      // rounded output: y = round(resid_add + round(sum))
-    float* sumsq_out;               // ... and per-64-column sums of y^2
-    const float* sumsq_in;          // MODE 1 without slabs: those partials, instead of the cross-wave sum
-    int sumsq_n;
-    float* att_out;                 // ROPE + attention fold: split-KV partials [n_head][4][hd + 2]
-    unsigned* att_ticket;           // ... its arrival / departure counters, two per head (prepared workspace header)
-    float att_scale;                // 1 / sqrt(head_dim)
-    int exp;
-#endif
 };
 
 // Launch description filled by run_gemv when the shape qualifies (teal_kernels.hip: fast_eligible)

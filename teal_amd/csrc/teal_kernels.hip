@@ -131,9 +131,6 @@ size_t g_phase_stride = 0;  // > 0: consecutive GEMV launches stamp consecutive 
 int g_phase_seq = 0;
 int g_wave_local = 1;
 int g_fast = 1;  // lean kernel (teal_gemv_fast.h) where the shape qualifies
-#ifdef TEAL_R05_EXPERIMENTS
-int g_r05 = 0;
-#endif
 
 // ---- per-device properties (immutable once cached) ---------------------------------------------------------------
 constexpr int kMaxDevices = 64;
@@ -327,12 +324,6 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
     f.a.seg_tile2 = (!p.pair && p.nseg > 2) ? p.seg[2].tile0 : INT_MAX;
     f.a.act0 = p.act0;
     f.a.gate_act = p.in.gate_act;
-#ifdef TEAL_R05_EXPERIMENTS
-    f.a.resid_add = p.resid_add; f.a.sumsq_out = p.sumsq_out; f.a.sumsq_in = p.in.sumsq_in; f.a.sumsq_n = p.in.sumsq_n;
-    f.a.att_out = p.att_out; f.a.exp = g_r05;
-    if (p.in.sumsq_in && (mode != 1 || p.in.nslabs != 0 || p.in.sumsq_n > 128)) return false;
-    if (p.resid_add && (to_ws || p.pair || p.nseg != 1 || bn != 64)) return false;
-#endif
     f.a.ws_stride = (to_ws || ticketed) ? ((c.split + 3) & ~3) : 0;
     f.a.ticket = ticketed ? p.tickets : nullptr;
     if (p.rope) {  // RoPE + KV append epilogue: one rounded q|k|v vector, no split-K, tiles inside one head
@@ -341,15 +332,6 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
             return false;
         f.a.rope = p.rope; f.a.rope_pos = p.rope_pos; f.a.kc = p.kc; f.a.vc = p.vc;
         f.a.rope_hd = p.rope_hd; f.a.rope_dim = p.seg[0].ncols; f.a.rope_kv = p.seg[1].ncols; f.a.rope_max_seq = p.rope_max_seq;
-#ifdef TEAL_R05_EXPERIMENTS
-        if (p.att_out) {  // lever (a): MHA, head_dim 128, 64-column tiles (two per head and part), arrival counters available
-            if (p.rope_hd != 128 || bn != 64 || kr != 4 || p.seg[0].ncols != p.seg[1].ncols || !p.tickets ||
-                2 * (p.seg[0].ncols / 128) > kTicketTiles)
-                return false;
-            f.a.att_ticket = p.tickets;
-            f.a.att_scale = 1.0f / sqrtf((float)p.rope_hd);
-        }
-#endif
     }
     return true;
 }
@@ -515,9 +497,6 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
         FastLaunch f;
         const bool lean = fast_eligible(p, c, to_ws, ws_bytes, f);
         if (p.rope && !lean) return TEAL_ERR_CONFIG;  // the RoPE epilogue exists in the lean kernel only: never fall through unrotated
-#ifdef TEAL_R05_EXPERIMENTS
-        if ((p.resid_add || p.in.sumsq_in || p.att_out) && !lean) return TEAL_ERR_CONFIG;
-#endif
         if (lean) {
             if (rope_taken) *rope_taken = f.a.rope != nullptr;
             // (the instantiation as rocprofv3 prints it: BF16, MODE, PAIR, LPR, KR, EXACT, PHASE, U, W8, ROPE)
@@ -639,13 +618,6 @@ int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll) {
 }
 
 const char* teal_last_launch_desc(void) { return g_last_desc; }
-
-#ifdef TEAL_R05_EXPERIMENTS
-int teal_r05_experiment(int mask) {
-    g_r05 = mask;
-    return TEAL_OK;
-}
-#endif
 
 int teal_set_fast(int on) {
     g_fast = on ? 1 : 0;
@@ -843,9 +815,6 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
             p.in.norm_w = in->norm_weight;
             p.in.resid_out = in->resid_out;
             p.in.eps = in->eps;
-#ifdef TEAL_R05_EXPERIMENTS
-            p.in.sumsq_in = in->sumsq_in; p.in.sumsq_n = in->sumsq_n;
-#endif
             break;
         default: return TEAL_ERR_ARG;
     }
@@ -881,9 +850,6 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
         if (rc == TEAL_OK && out->slabs_interleaved && !p.ws_il) return TEAL_ERR_CONFIG;  // > 8 slices cannot interleave
     } else if (out->mode == TEAL_OUT_ROUNDED) {
         p.act0 = out->act_seg0 ? 1 : 0;
-#ifdef TEAL_R05_EXPERIMENTS
-        p.resid_add = reinterpret_cast<const uint16_t*>(out->resid_add); p.sumsq_out = out->sumsq_out;
-#endif
         rc = run_gemv(p, dtype, ws, ws_bytes, false, st, &used, false);
     } else if (out->mode == TEAL_OUT_QKV_ROPE) {
         if (out->nseg != 3 || in->mode != TEAL_IN_RESID_NORM || !out->y[0] || !out->rope || !out->rope_pos || !out->k_cache ||
@@ -899,9 +865,6 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
         q.vc = reinterpret_cast<uint16_t*>(out->v_cache);
         q.rope_hd = out->rope_head_dim;
         q.rope_max_seq = out->rope_max_seq;
-#ifdef TEAL_R05_EXPERIMENTS
-        q.att_out = out->att_fold ? out->att_partials : nullptr;
-#endif
         q.seg[1].y = reinterpret_cast<uint16_t*>(out->y[0]) + out->ncols[0];                   // (k, v land in the caches; the
         q.seg[2].y = reinterpret_cast<uint16_t*>(out->y[0]) + out->ncols[0] + out->ncols[1];   //  lean kernel wants one vector)
         const Config c0 = pick_config(Z, total_cols, 3);
