@@ -618,6 +618,8 @@ def main():
         if t_pf:
             out["tokens_per_sec_reference_definition"] = 200.0 / (t_pf + 200.0 * t / a.steps)
             out["prefill_ms"] = t_pf * 1e3
+            out["prefill_path"] = {"hip": "hand-fused HIP prompt pass (teal_amd/gpt_fast/prefill.py), hipGraph replay",
+                                   "fallback": "module path"}.get(info.get("prefill_path"), info.get("prefill_path"))
     st_sparse = None
     if rank == 0 and world == 1:
         out["roofline"] = roofline_engine_gateup(info["engine"], a) if mode == "engine" else roofline_dominant_kernel(model, a)

@@ -39,7 +39,9 @@ def main():
     def timed(fn):
         sync(); t0 = time.perf_counter(); r = fn(); sync(); return r, (time.perf_counter() - t0) * 1e3
 
-    for label, pre in (("eager prefill", None), ("graphed prefill", G.GraphedPrefill(model))):
+    from teal_amd.gpt_fast.prefill import FusedPrefill
+    for label, pre in (("eager module prefill", None), ("graphed module prefill", G.GraphedPrefill(model)),
+                       ("hand-fused HIP prompt pass, graphed", FusedPrefill(model, graph=True))):
         for _ in range(2):  # capture + warm-up
             G.generate(model, prompt, a.max_new_tokens, dec, prefill=pre)
         walls = []

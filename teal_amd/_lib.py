@@ -19,7 +19,7 @@ CSRC = os.path.join(_PKG, "csrc")
 # (weight width, activation dtype) so that they compile in parallel
 SOURCES = ("teal_kernels.hip", "teal_attention.hip", "teal_gemv_w16_f16.hip", "teal_gemv_w16_bf16.hip",
            "teal_gemv_w8_f16.hip", "teal_gemv_w8_bf16.hip", "teal_gemv_fast_f16.hip", "teal_gemv_fast_bf16.hip", "teal_gemv_int4.hip",
-           "teal_gemv_fast_w8_f16.hip", "teal_gemv_fast_w8_bf16.hip", "teal_comparators.hip")
+           "teal_gemv_fast_w8_f16.hip", "teal_gemv_fast_w8_bf16.hip", "teal_comparators.hip", "teal_prefill.hip")
 # translation units whose kernels take their hot arguments as scalar parameters: the command processor preloads the
 # first 11 dwords into SGPRs at wave launch (no scalar-cache miss before the first activation load)
 PRELOAD = {"teal_gemv_fast_f16.hip": 12, "teal_gemv_fast_bf16.hip": 12, "teal_gemv_fast_w8_f16.hip": 12,
@@ -31,7 +31,8 @@ LIB_PATH = os.path.join(_PKG, "libteal_hip.so")  # the in-tree library: what bui
 # writes there (an override pointing at an older build must not be overwritten by the current tree), and symbols that build
 # lacks are tolerated (OPTIONAL_WITH_OVERRIDE).
 LIB_OVERRIDE = os.environ.get("TEAL_LIB_PATH") or None
-OPTIONAL_WITH_OVERRIDE = ("teal_decode_attention_split_roped",)
+OPTIONAL_WITH_OVERRIDE = ("teal_decode_attention_split_roped", "teal_prefill_gemm", "teal_prefill_resid_norm", "teal_prefill_silu_mul",
+                          "teal_prefill_attention")
 
 # every symbol include/teal_hip.h declares
 EXPORTS = (
@@ -40,6 +41,7 @@ EXPORTS = (
     "teal_set_tuning", "teal_get_config", "teal_set_phase_buffer", "teal_fused_gemv", "teal_decode_attention", "teal_sample_topk", "teal_set_wave_local", "teal_sparse_qkv_gemv_ld", "teal_decode_attention_masked", "teal_decode_attention_split", "teal_sparse_qkv_gemv_i8", "teal_decode_attention_split_slabs", "teal_set_phase_stride", "teal_set_fast", "teal_last_launch_desc", "teal_sparse_qkv_gemv_i4",
     "teal_workspace_init", "teal_workspace_release", "teal_sample_topk_ws", "teal_decode_attention_split_ws", "teal_cmp_flag_gemv",
     "teal_decode_attention_split_roped",
+    "teal_prefill_gemm", "teal_prefill_resid_norm", "teal_prefill_silu_mul", "teal_prefill_attention",
 )
 
 _lib = None
@@ -143,6 +145,11 @@ def load() -> ctypes.CDLL:
         L.teal_decode_attention_split_roped.argtypes = [vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, ci, vp, sz, ci, vp, sz, vp]
     L.teal_decode_attention.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
     L.teal_get_config.argtypes = [ci, ci, ci, ctypes.POINTER(ci)]
+    if hasattr(L, "teal_prefill_gemm"):
+        L.teal_prefill_gemm.argtypes = [vp, vp, ci, ci, vp, ci, ci, vp, sz, ci, ci, ci, ctypes.POINTER(ci), vp]
+        L.teal_prefill_resid_norm.argtypes = [vp, vp, ci, vp, vp, ci, vp, cf, ci, vp, vp, vp, ci, vp]
+        L.teal_prefill_silu_mul.argtypes = [vp, ci, ci, ci, vp, ci, vp]
+        L.teal_prefill_attention.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     for name in EXPORTS:
         if LIB_OVERRIDE and name in OPTIONAL_WITH_OVERRIDE and not hasattr(L, name):
             continue  # an older build loaded for A/B: callers of this entry point fail with AttributeError when they reach it

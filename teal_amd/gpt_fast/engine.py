@@ -753,12 +753,19 @@ def make_engine_stepper(model: Transformer, a, ths: Optional[List[Dict[str, floa
     model.setup_caches(max_batch_size=1, max_seq_length=min(total, model.config.block_size))
     with torch.no_grad():
         import time
-        logits = model(prompt.view(1, -1), torch.arange(0, npr, device=dev))  # prefill fills the shared KV caches
+        # the prompt pass as generate() runs it under --compile (prefill.FusedPrefill: the hand-fused HIP pass from a hipGraph for
+        # prompts of up to 8 tokens, the module path otherwise); it fills the shared KV caches
+        from .prefill import FusedPrefill
+        G.relayout_for_engine(model)
+        pre = FusedPrefill(model, graph=True)
+        for _ in range(2):
+            logits = pre(prompt)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()  # timed once more, warm (the reference's tok/s definition includes the prefill)
-        logits = model(prompt.view(1, -1), torch.arange(0, npr, device=dev))
+        t0 = time.perf_counter()  # timed warm (the reference's tok/s definition includes the prefill)
+        logits = pre(prompt)
         torch.cuda.synchronize()
         prefill_s = time.perf_counter() - t0
+        logits = logits.clone()
         tok = G.sample(logits, temperature=0.8, top_k=200)[0]
         cls, why = pick_engine(model)
         if cls is None:
@@ -800,8 +807,8 @@ def make_engine_stepper(model: Transformer, a, ths: Optional[List[Dict[str, floa
                 n -= 1
 
     step.run = run
-    return step, {"thresholds": ths, "engine": eng, "prefill_s": prefill_s, "first_token": tok, "pos0": npr, "span": span,
-                  "graph_tokens": U}
+    return step, {"thresholds": ths, "engine": eng, "prefill_s": prefill_s, "prefill_path": pre.used, "first_token": tok, "pos0": npr,
+                  "span": span, "graph_tokens": U}
 
 
 def pick_engine(model: Transformer, need_caches: bool = True):

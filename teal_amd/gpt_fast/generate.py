@@ -508,6 +508,11 @@ def main(args) -> Dict:
     # (kernels/sparse_gemv.py:271,298).  --eager_prefill keeps the op-by-op pass; a host-staged TP all-reduce cannot be captured.
     want_graph_prefill = (getattr(args, "compile_prefill", False) or args.compile) and not getattr(args, "eager_prefill", False)
     prefill = GraphedPrefill(model) if (want_graph_prefill and use_graph) else None
+    if thresholds is not None and want_graph_prefill and not getattr(args, "module_prefill", False):
+        # prompts of up to 8 tokens: the hand-fused HIP prompt pass (teal_amd/gpt_fast/prefill.py: eight launches per layer over
+        # the decode step's weight images, dense); longer prompts, quantised or sharded models: the pass above
+        from teal_amd.gpt_fast.prefill import FusedPrefill
+        prefill = FusedPrefill(model, graph=use_graph, fallback=prefill)
     tps, seqs = [], []
     start = -1 if args.compile else 0
     for i in range(start, args.num_samples):
@@ -548,8 +553,9 @@ def main(args) -> Dict:
     mean = sum(tps) / max(1, len(tps))
     print(f"Average tokens/sec: {mean:.2f}")
     print(f"Memory used: {torch.cuda.max_memory_reserved() / 1e9:.02f} GB")
+    pre_name = None if prefill is None else type(prefill).__name__ + (f":{prefill.used}" if getattr(prefill, "used", None) else "")
     return {"tokens_per_sec": tps, "mean_tokens_per_sec": mean, "thresholds": thresholds, "decoder": type(decoder).__name__,
-            "sequences": seqs}
+            "sequences": seqs, "prefill": pre_name}
 
 
 def build_parser() -> argparse.ArgumentParser:
@@ -566,6 +572,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--compile_prefill", action="store_true", help="capture the prompt pass into a hipGraph too "
                    "(the reference's flag of the same name, generate.py:540); implied by --compile here")
     p.add_argument("--eager_prefill", action="store_true", help="with --compile: keep the prompt pass op by op (no prefill graph)")
+    p.add_argument("--module_prefill", action="store_true", help="with --compile: the prompt pass through the patched modules (under a "
+                   "hipGraph) also for prompts of up to 8 tokens, instead of the hand-fused HIP prompt pass")
     p.add_argument("--profile", type=Path, default=None)
     p.add_argument("--speculate_k", type=int, default=5, help="accepted for command-line compatibility; only read with a draft model")
     p.add_argument("--draft_checkpoint_path", type=Path, default=None, help="speculative decoding is outside this build (the "
