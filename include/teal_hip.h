@@ -322,25 +322,43 @@ int teal_sample_topk_ws(const void* logits, int vocab, int dtype, int top_k, flo
 
 /* The reference's prefill is dense (its ops run torch.matmul when the sequence is longer than one token,
  * kernels/sparse_gemv.py:271,298; the rest is the stock model, gpt-fast/model.py:107-121,158-186,258-259,289-291) and its
- * tokens/sec counts it (gpt-fast/generate.py:458,487-496).  These four launches make one layer of that pass eight launches over
+ * tokens/sec counts it (gpt-fast/generate.py:458,487-496).  These entry points make one layer of that pass seven launches over
  * the decode step's own weight images.  Every hand-over is TRANSPOSED, [feature][8]: the up to eight tokens of a feature in one
  * 16-byte word (16-bit activations: xt, ht, yt) or one 32-byte pair (fp32 slabs [slice][feature][8]); token slots >= T of the
  * 16-bit vectors are written as zero, of the slabs left untouched (consumers ignore them).  1 <= T <= 8.  Floating-point
  * results: fp32 sums, the rounding points of the module path's 16-bit tensors. */
 
-/* slabs[slice][n][s] = sum over the slice's rows m of W^T[m][n] * xt[m][s]: w0T [Z][ld0] (n0 columns) and, optionally, w1T [Z][ld1]
- * (n1 columns, output columns n0 ..: gate | up in one launch).  Z % 64 == 0, n0 / n1 multiples of 64.  *split_out = slices written
- * (the consumer sums them in slice order and rounds once); slabs must hold 8 * (n0 + n1) * 8 floats. */
-int teal_prefill_gemm(const void* xt, const void* w0T, int ld0, int n0, const void* w1T, int ld1, int n1, float* slabs,
+/* What a GEMM launch builds its activations from (every workgroup builds the rows of its own slice, once, while staging them) */
+#define TEAL_PREFILL_IN_XT 0        /* xt [Z][8] as given */
+#define TEAL_PREFILL_IN_NORM 1      /* x = RMSNorm(h) * norm_w from the residual rows xt = ht [Z][8] and the per-workgroup sums of squares
+                                     * sumsq [nwg][8] a teal_prefill_resid_norm call left in its scratch (nwg = Z / 256 rounded up) */
+#define TEAL_PREFILL_IN_SILU_MUL 2  /* x = round(round(silu(round(gate))) * round(up)) from the slabs [gu_split][2 Z][8] of a gate | up launch */
+typedef struct teal_prefill_in {
+    int mode;
+    const void* xt;
+    const float* sumsq;
+    int nwg;
+    const void* norm_w;
+    float eps;
+    const float* gu_slabs;
+    int gu_split;
+} teal_prefill_in_t;
+
+/* slabs[slice][n][s] = sum over the slice's rows m of W^T[m][n] * x[m][s]: w0T [Z][ld0] (n0 columns) and, optionally, w1T [Z][ld1]
+ * (n1 columns, output columns n0 ..: gate | up in one launch).  Z, n0, n1 multiples of 256.  *split_out = slices written (<= 16;
+ * the consumer sums them in slice order and rounds once); slabs must hold 16 * (n0 + n1) * 8 floats and must not be the buffer a
+ * TEAL_PREFILL_IN_SILU_MUL launch reads. */
+int teal_prefill_gemm(const teal_prefill_in_t* in, const void* w0T, int ld0, int n0, const void* w1T, int ld1, int n1, float* slabs,
                       size_t slabs_bytes, int Z, int T, int dtype, int* split_out, void* stream);
 /* h = (embedding rows of tokens[0..T) | ht_in) + round(sum of `split` slabs) (split 0: nothing to add); x = RMSNorm(h) * norm_w.
- * Exactly one of tokens (+ emb [vocab][dim]) / ht_in is given.  Outputs: ht_out [dim][8] (required; must not alias ht_in's
+ * Exactly one of tokens (+ emb [vocab][dim]) / ht_in is given; with neither xt_out nor x_last only the first of the two launches runs
+ * (h and the sums of squares: a TEAL_PREFILL_IN_NORM GEMM normalises while it stages).  Outputs: ht_out [dim][8] (required; must not alias ht_in's
  * words of other columns — the same buffer is fine), xt_out [dim][8] and x_last [dim] (optional) = the normalised vector of
- * token T - 1 as a plain vector (input of the lm_head GEMV).  dim <= 16384. */
+ * token T - 1 as a plain vector (input of the lm_head GEMV).  sumsq_scratch: (dim / 256 rounded up) * 8 floats of caller memory
+ * (the per-workgroup sums of squares between the two launches this call makes).  dim <= 16384. */
 int teal_prefill_resid_norm(const void* emb, const int32_t* tokens, int T, const void* ht_in, const float* slabs, int split,
-                            const void* norm_w, float eps, int dim, void* ht_out, void* xt_out, void* x_last, int dtype, void* stream);
-/* xt[col][s] = round(round(silu(round(gate))) * round(up)) from the slabs [split][2 * inter][8] of a gate | up launch */
-int teal_prefill_silu_mul(const float* gu_slabs, int split, int inter, int T, void* xt, int dtype, void* stream);
+                            const void* norm_w, float eps, int dim, void* ht_out, void* xt_out, void* x_last, float* sumsq_scratch,
+                            int dtype, void* stream);
 /* q | k | v from the slabs [split][(n_head + 2 n_kv_head) * head_dim][8] of the wqkv launch: RoPE(q, k) at positions 0 .. T-1,
  * cache rows 0 .. T-1 written, causal softmax(q K^T / sqrt(d)) V -> yt [n_head * head_dim][8].  head_dim 64 or 128. */
 int teal_prefill_attention(const float* qkv_slabs, int split, const void* rope, void* k_cache, void* v_cache, void* yt, int T, int n_head,

@@ -31,8 +31,7 @@ LIB_PATH = os.path.join(_PKG, "libteal_hip.so")  # the in-tree library: what bui
 # writes there (an override pointing at an older build must not be overwritten by the current tree), and symbols that build
 # lacks are tolerated (OPTIONAL_WITH_OVERRIDE).
 LIB_OVERRIDE = os.environ.get("TEAL_LIB_PATH") or None
-OPTIONAL_WITH_OVERRIDE = ("teal_decode_attention_split_roped", "teal_prefill_gemm", "teal_prefill_resid_norm", "teal_prefill_silu_mul",
-                          "teal_prefill_attention")
+OPTIONAL_WITH_OVERRIDE = ("teal_decode_attention_split_roped", "teal_prefill_gemm", "teal_prefill_resid_norm", "teal_prefill_attention")
 
 # every symbol include/teal_hip.h declares
 EXPORTS = (
@@ -41,7 +40,7 @@ EXPORTS = (
     "teal_set_tuning", "teal_get_config", "teal_set_phase_buffer", "teal_fused_gemv", "teal_decode_attention", "teal_sample_topk", "teal_set_wave_local", "teal_sparse_qkv_gemv_ld", "teal_decode_attention_masked", "teal_decode_attention_split", "teal_sparse_qkv_gemv_i8", "teal_decode_attention_split_slabs", "teal_set_phase_stride", "teal_set_fast", "teal_last_launch_desc", "teal_sparse_qkv_gemv_i4",
     "teal_workspace_init", "teal_workspace_release", "teal_sample_topk_ws", "teal_decode_attention_split_ws", "teal_cmp_flag_gemv",
     "teal_decode_attention_split_roped",
-    "teal_prefill_gemm", "teal_prefill_resid_norm", "teal_prefill_silu_mul", "teal_prefill_attention",
+    "teal_prefill_gemm", "teal_prefill_resid_norm", "teal_prefill_attention",
 )
 
 _lib = None
@@ -146,9 +145,8 @@ def load() -> ctypes.CDLL:
     L.teal_decode_attention.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
     L.teal_get_config.argtypes = [ci, ci, ci, ctypes.POINTER(ci)]
     if hasattr(L, "teal_prefill_gemm"):
-        L.teal_prefill_gemm.argtypes = [vp, vp, ci, ci, vp, ci, ci, vp, sz, ci, ci, ci, ctypes.POINTER(ci), vp]
-        L.teal_prefill_resid_norm.argtypes = [vp, vp, ci, vp, vp, ci, vp, cf, ci, vp, vp, vp, ci, vp]
-        L.teal_prefill_silu_mul.argtypes = [vp, ci, ci, ci, vp, ci, vp]
+        L.teal_prefill_gemm.argtypes = [vp, vp, ci, ci, vp, ci, ci, vp, sz, ci, ci, ci, ctypes.POINTER(ci), vp]  # (teal_prefill_in_t*, ...)
+        L.teal_prefill_resid_norm.argtypes = [vp, vp, ci, vp, vp, ci, vp, cf, ci, vp, vp, vp, vp, ci, vp]
         L.teal_prefill_attention.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     for name in EXPORTS:
         if LIB_OVERRIDE and name in OPTIONAL_WITH_OVERRIDE and not hasattr(L, name):

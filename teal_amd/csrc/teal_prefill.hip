@@ -5,10 +5,10 @@
 // 107-121 forward, 158-161 block, 170-186 attention, 258-259 feed-forward, 289-291 RMSNorm).  The reference's tokens/sec
 // counts that pass (gpt-fast/generate.py:458,487-496), and on MI355X an op-by-op prompt pass of a 6-token prompt costs as much
 // as nine decode steps (~400 launches of a few microseconds each; profiles/r05_generate_breakdown_before.txt: 20 ms eager,
-// 10 ms replayed from a hipGraph).  Here one layer is eight launches over the SAME weight images the decode step streams:
+// 10 ms replayed from a hipGraph).  Here one layer is seven launches over the SAME weight images the decode step streams:
 //
-//   gemm(wqkv) -> attention (RoPE, cache rows 0..T-1, causal softmax) -> gemm(wo) -> resid_norm -> gemm(w1 | w3) ->
-//   silu_mul -> gemm(w2) -> resid_norm
+//   gemm(wqkv) [RMSNorm while staging] -> attention (RoPE, cache rows 0..T-1, causal softmax) -> gemm(wo) -> resid ->
+//   gemm(w1 | w3) [RMSNorm while staging] -> gemm(w2) [silu * up while staging] -> resid
 //
 // Every hand-over between launches is TRANSPOSED: [feature][8] — the up to eight tokens of a feature are one 16-byte word
 // (16-bit activations) or one 32-byte pair (fp32 split-K slabs) — so that a GEMM lane fetches "row m of every token" with one
@@ -19,37 +19,94 @@
 // RMSNorm twice, silu, product); sums are fp32.  Floating-point parity is against the module path, tolerance in the tests.
 #include "teal_common.h"
 
+#include <limits.h>
+
 namespace teal {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kRows = 8;  // tokens per transposed word
+constexpr int kPrefillMaxSplit = 16;
+
+// sum of `split` slabs in slice order, rounded once to the activation dtype: what a projection's 16-bit output tensor holds
+template <bool BF16>
+__device__ __forceinline__ void rounded_row(const float* __restrict__ slabs, const int split, const size_t n_total, const size_t col,
+                                            float (&out)[kRows]) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < split; k0 += 4) {  // four slices' loads in flight (clamped: a repeated slice is not added); slice order kept
+        f32x4 va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* p = slabs + ((size_t)min(k0 + u, split - 1) * n_total + col) * kRows;
+            va[u] = *reinterpret_cast<const f32x4*>(p);
+            vb[u] = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k0 + u < split) { a += va[u]; b += vb[u]; }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        out[s] = bits_to_float(float_to_bits<BF16>(a[s]), BF16);
+        out[4 + s] = bits_to_float(float_to_bits<BF16>(b[s]), BF16);
+    }
+}
+
+template <bool BF16>
+__device__ __forceinline__ u32x4 pack_row(const float (&v)[kRows]) {
+    u32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = (uint32_t)float_to_bits<BF16>(v[2 * j]) | ((uint32_t)float_to_bits<BF16>(v[2 * j + 1]) << 16);
+    return r;
+}
 
 // ------------------------------------------------------------------------------------------------
 // slabs[slice][n][8] (fp32) = sum over the slice's rows m of W^T[m][n] * x[token][m], for up to 2 NP tokens.
 //   xt     [Z][8] 16-bit: xt[m][s] = activation m of token s
 //   w0/w1  one or two W^T images [Z][ld]: column tiles < tiles0 stream w0, the others w1 (gate | up in one launch)
-//   grid (column tiles, row slices); chunk c (64 rows) belongs to slice c mod split, inside the slice to wave (c div split) mod 16
-// A lane owns FOUR columns (one 8-byte weight load per row: with eight, the 16 NP accumulators plus two batches of loads in
-// flight do not fit the 128 registers a 16-wave workgroup leaves a lane) and 2 NP accumulators per column; LPR lanes cover a row
-// segment of BN = 4 LPR columns — 128 or 256 contiguous bytes, what the memory system sees is the GEMV's request — and 64 / LPR
-// rows are in flight per wave step.  Accumulation as packed fp32 pairs over the tokens (v_pk_fma_f32).
+//   grid (256-column tiles, row slices); rows in groups of 16 (one per wave): group q belongs to slice q mod split
+// One WAVE streams one weight row at a time across the whole 256-column tile: 64 lanes x 4 columns = a 512-byte contiguous row
+// segment per load, and the row's activations are WAVE-UNIFORM: the workgroup stages its slice's rows of xt in LDS once and a
+// wave fetches a row's eight tokens with one broadcast LDS read (through scalar loads instead, the loop carried 21 scalar
+// instructions per row — addresses, clamps, selects — and a full `s_waitcnt lgkmcnt(0)` per batch: 3.8 TB/s).  Sixteen rows
+// per wave are in flight (two batches of 8 x 8 bytes per lane: 128 KB per CU, what the GEMV keeps in flight); a lane's sums never
+// leave the lane until the epilogue (no butterflies), where the 16 waves are added in fixed order through LDS, one token pair
+// per round.  Accumulation as packed fp32 pairs over the tokens (v_pk_fma_f32).  First build (row groups inside a wave, the
+// activations through vector loads, 8 rows in flight): 2.1-3.5 TB/s; profiles/r05_prefill_kernel_stats.txt.
 // ------------------------------------------------------------------------------------------------
-template <bool BF16, int LPR, int NP>
-__global__ __launch_bounds__(1024) void prefill_gemm_kernel(const uint16_t* __restrict__ xt, const uint16_t* __restrict__ w0, const int ld0,
+// What the staging loop builds a row's eight activations from (PROD): 0 = xt itself; 1 = RMSNorm of the residual rows ht with the
+// per-workgroup sums of squares the resid launch left (every wave adds them itself) and the norm weight; 2 = silu(gate) * up from
+// the slabs of the gate | up launch.  Folding these into the staging removes a launch each: every workgroup builds only the rows
+// of its own slice (a 16th of the vector in the narrow projections), once.
+struct PrefillProd {
+    const uint16_t* xt;       // PROD 0: [Z][8];  PROD 1: the residual rows ht [Z][8]
+    const float* sumsq;       // PROD 1: [nwg][8]
+    const uint16_t* norm_w;   // PROD 1: [Z]
+    const float* gu;          // PROD 2: slabs [gu_split][2 Z][8] of the gate | up launch
+    float eps;
+    int nwg, gu_split, T;
+};
+
+template <bool BF16, int NP, int PROD>
+__global__ __launch_bounds__(1024) void prefill_gemm_kernel(const PrefillProd pr, const uint16_t* __restrict__ w0, const int ld0,
                                                             const uint16_t* __restrict__ w1, const int ld1, const int tiles0,
                                                             float* __restrict__ slabs, const int Z, const int n_total) {
-    constexpr int WAVES = 16, CPL = 4, RPW = 64 / LPR, BN = LPR * CPL, STEPS = 64 / RPW, U = 4;
-    static_assert(STEPS % (2 * U) == 0, "whole pairs of batches per chunk");
+    const uint16_t* __restrict__ xt = pr.xt;
+    constexpr int WAVES = 16, CPL = 4, BN = 256, U = 8, PHASE_GROUPS = 128;  // 128 groups x 16 rows x 16 bytes = 32 KB of activations
     extern __shared__ __align__(16) unsigned char smem[];
-    float* red = reinterpret_cast<float*>(smem);  // [WAVES][BN][4]: two token pairs per reduction round
+    u32x4* xs = reinterpret_cast<u32x4*>(smem);   // the slice's activation rows of the current phase: xs[j * 16 + wave]
+    float* red = reinterpret_cast<float*>(smem);  // epilogue (after a barrier): [WAVES][BN][2], one token pair per round
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x, slice = blockIdx.y, split = gridDim.y;
-    const int g = lane / LPR, cl = lane % LPR;
     const bool second = tile >= tiles0;
-    const uint16_t* wp = (second ? w1 : w0) + (size_t)(second ? tile - tiles0 : tile) * BN + cl * CPL;
     const uint32_t ld = (uint32_t)(second ? ld1 : ld0);
-    const int nch = Z >> 6;
+    const int ngroups = Z >> 4;
+    const int nj = (ngroups - slice + split - 1) / split;  // row groups of this slice: q = slice + split * j, row = q * 16 + wave
+    // this wave's rows: base + j * stride (elements)
+    // (a UNIFORM row pointer indexed by the lane: the address is an SGPR base + one 32-bit lane offset, not a 64-bit add per load)
+    const uint16_t* wrow = (second ? w1 : w0) + (size_t)(second ? tile - tiles0 : tile) * BN + (size_t)(slice * 16 + wave) * ld;
+    const size_t stride = (size_t)split * 16u * ld;
     f32x2 acc[CPL][NP];
 #pragma unroll
     for (int c = 0; c < CPL; ++c)
@@ -69,113 +126,140 @@ __global__ __launch_bounds__(1024) void prefill_gemm_kernel(const uint16_t* __re
             }
         }
     };
-    auto issue = [&](u32x2 (&w)[U], u32x4 (&x)[U], const uint32_t m0, const int batch) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t m = m0 + (uint32_t)(batch * U + u) * RPW;
-            w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wp + (size_t)m * ld));
-            x[u] = *reinterpret_cast<const u32x4*>(xt + (size_t)m * kRows);
-        }
-    };
-    // the wave's chunks: c = slice + split * (wave + 16 k); two batches of U rows per lane in flight
-    for (int c = slice + split * wave; c < nch; c += split * WAVES) {
-        const uint32_t m0 = (uint32_t)c * 64u + g;
-        u32x2 wa[U], wb[U];
-        u32x4 xa[U], xb[U];
-        issue(wa, xa, m0, 0);
-#pragma unroll
-        for (int b = 0; b < STEPS / U; b += 2) {
-            issue(wb, xb, m0, b + 1);
-#pragma unroll
-            for (int u = 0; u < U; ++u) consume(wa[u], xa[u]);
-            if (b + 2 < STEPS / U) issue(wa, xa, m0, b + 2);
-#pragma unroll
-            for (int u = 0; u < U; ++u) consume(wb[u], xb[u]);
-        }
-    }
-    // row groups of the wave (butterflies), then the 16 waves in fixed order through LDS, two token pairs per round
-#pragma unroll
-    for (int c = 0; c < CPL; ++c)
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                float v = acc[c][p][e];
-                if constexpr (LPR <= 16) v = xor_add<16>(v);
-                v = xor_add<32>(v);
-                acc[c][p][e] = v;
+    for (int jb = 0; jb < nj; jb += PHASE_GROUPS) {
+        const int njp = min(PHASE_GROUPS, nj - jb);  // groups of this phase (one phase for every Llama-2-7B launch)
+        const uint16_t* wph = wrow + (size_t)jb * stride;
+        const int nfull = njp / (2 * U);  // whole pairs of batches
+        // (requesting the first batch of weight rows ahead of the staging — nothing in it depends on the activations — was
+        //  measured: the 16 registers it keeps live through the producers push the kernel to 126-128 registers with spills, and
+        //  the gate | up launch went 41 -> 48 us; profiles/r05_prefill_kernel_stats.txt)
+        if (jb) __syncthreads();
+        [[maybe_unused]] float rstd[kRows];
+        if constexpr (PROD == 1) {  // lane = producing workgroup of the resid launch (nwg <= 64); the total in workgroup order
+            f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
+            if (lane < pr.nwg) {
+                pa = *reinterpret_cast<const f32x4*>(pr.sumsq + (size_t)lane * kRows);
+                pb = *reinterpret_cast<const f32x4*>(pr.sumsq + (size_t)lane * kRows + 4);
             }
-    const uint32_t col_base = (uint32_t)tile * BN;
 #pragma unroll
-    for (int p0 = 0; p0 < NP; p0 += 2) {
-        if (p0) __syncthreads();
-        if (lane < LPR) {
+            for (int s_ = 0; s_ < kRows; ++s_) rstd[s_] = rsqrtf(wave_sum_f(s_ < 4 ? pa[s_ & 3] : pb[s_ & 3]) / (float)Z + pr.eps);
+        }
+        for (int r = tid; r < njp * 16; r += 1024) {
+            const uint32_t m = (uint32_t)(slice + split * (jb + (r >> 4))) * 16u + (uint32_t)(r & 15);
+            if constexpr (PROD == 0) {
+                xs[r] = *reinterpret_cast<const u32x4*>(xt + (size_t)m * kRows);
+            } else if constexpr (PROD == 1) {  // x = round(round(h * rstd) * w)  (gpt-fast/model.py:289-291)
+                const u32x4 v = *reinterpret_cast<const u32x4*>(xt + (size_t)m * kRows);
+                const float nw = bits_to_float(pr.norm_w[m], BF16);
+                float x[kRows];
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                f32x4 v = {acc[c][p0][0], acc[c][p0][1], 0.0f, 0.0f};
-                if (p0 + 1 < NP) { v[2] = acc[c][p0 + 1][0]; v[3] = acc[c][p0 + 1][1]; }
-                *reinterpret_cast<f32x4*>(red + ((size_t)wave * BN + lane * CPL + c) * 4) = v;
+                for (int j = 0; j < 4; ++j) { x[2 * j] = bits_to_float(v[j] & 0xFFFFu, BF16); x[2 * j + 1] = bits_to_float(v[j] >> 16, BF16); }
+#pragma unroll
+                for (int s_ = 0; s_ < kRows; ++s_) {
+                    const float xn = bits_to_float(float_to_bits<BF16>(x[s_] * rstd[s_]), BF16);
+                    x[s_] = s_ < pr.T ? bits_to_float(float_to_bits<BF16>(xn * nw), BF16) : 0.0f;
+                }
+                xs[r] = pack_row<BF16>(x);
+            } else {  // x = round(round(silu(round(gate))) * round(up))  (gpt-fast/model.py:258-259)
+                float gv[kRows], uv[kRows], x[kRows];
+                rounded_row<BF16>(pr.gu, pr.gu_split, (size_t)2 * Z, (size_t)m, gv);
+                rounded_row<BF16>(pr.gu, pr.gu_split, (size_t)2 * Z, (size_t)Z + m, uv);
+#pragma unroll
+                for (int s_ = 0; s_ < kRows; ++s_) {
+                    const float sl = bits_to_float(float_to_bits<BF16>(gv[s_] / (1.0f + expf(-gv[s_]))), BF16);
+                    x[s_] = s_ < pr.T ? bits_to_float(float_to_bits<BF16>(sl * uv[s_]), BF16) : 0.0f;
+                }
+                xs[r] = pack_row<BF16>(x);
             }
         }
         __syncthreads();
-        if (tid < BN * 4) {
-            const int col = tid >> 2, sv = tid & 3;
-            float s = 0.0f;
+        // rows past the phase's last group (GUARD: only the last, partial pair of batches) repeat it; their activations read as zero
+        auto issue = [&](u32x2 (&w)[U], const int j0, auto guard) {
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w) s += red[((size_t)w * BN + col) * 4 + sv];
-            if (2 * p0 + sv < 2 * NP) slabs[((size_t)slice * n_total + col_base + col) * kRows + 2 * p0 + sv] = s;
+            for (int u = 0; u < U; ++u) {
+                const int j = decltype(guard)::value ? min(j0 + u, njp - 1) : j0 + u;
+                w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(wph + (size_t)j * stride) + (uint32_t)lane);
+            }
+        };
+        auto consume_batch = [&](const u32x2 (&w)[U], const int j0, auto guard) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = decltype(guard)::value ? min(j0 + u, njp - 1) : j0 + u;
+                u32x4 xv = xs[j * 16 + wave];  // wave-uniform address: one LDS broadcast read
+                if (decltype(guard)::value && j0 + u >= njp) xv = (u32x4){0u, 0u, 0u, 0u};
+                consume(w[u], xv);
+            }
+        };
+        // software pipeline, two batches of U rows in flight (scheduling barriers: left alone, the machine scheduler sinks every
+        // load to just above its first use to save registers — one load in flight per wave and an `s_waitcnt vmcnt(0)` per row)
+        constexpr std::false_type full{};
+        constexpr std::true_type guarded{};
+        u32x2 wa[U], wb[U];
+        int j0 = 0;
+        if (nfull > 0) {
+            issue(wa, 0, full);
+            __builtin_amdgcn_sched_barrier(0);
+            for (int it = 0; it < nfull; ++it, j0 += 2 * U) {
+                issue(wb, j0 + U, full);
+                __builtin_amdgcn_sched_barrier(0);
+                consume_batch(wa, j0, full);
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + 1 < nfull) issue(wa, j0 + 2 * U, full);
+                __builtin_amdgcn_sched_barrier(0);
+                consume_batch(wb, j0 + U, full);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (j0 < njp) {  // the partial pair: one guarded batch if eight rows or fewer remain, else two
+            issue(wa, j0, guarded);
+            const bool two = j0 + U < njp;
+            if (two) issue(wb, j0 + U, guarded);
+            __builtin_amdgcn_sched_barrier(0);
+            consume_batch(wa, j0, guarded);
+            if (two) consume_batch(wb, j0 + U, guarded);
         }
     }
-}
-
-// sum of `split` slabs in slice order, rounded once to the activation dtype: what a projection's 16-bit output tensor holds
-template <bool BF16>
-__device__ __forceinline__ void rounded_row(const float* __restrict__ slabs, const int split, const size_t n_total, const size_t col,
-                                            float (&out)[kRows]) {
-    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < split; ++k) {
-        const float* p = slabs + ((size_t)k * n_total + col) * kRows;
-        a += *reinterpret_cast<const f32x4*>(p);
-        b += *reinterpret_cast<const f32x4*>(p + 4);
-    }
+    // the 16 waves in fixed order through LDS, one token pair per round
+    const uint32_t col_base = (uint32_t)tile * BN;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        out[s] = bits_to_float(float_to_bits<BF16>(a[s]), BF16);
-        out[4 + s] = bits_to_float(float_to_bits<BF16>(b[s]), BF16);
-    }
-}
-
-template <bool BF16>
-__device__ __forceinline__ u32x4 pack_row(const float (&v)[kRows]) {
-    u32x4 r;
+    for (int p = 0; p < NP; ++p) {
+        __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = (uint32_t)float_to_bits<BF16>(v[2 * j]) | ((uint32_t)float_to_bits<BF16>(v[2 * j + 1]) << 16);
-    return r;
+        for (int c = 0; c < CPL; ++c) *reinterpret_cast<f32x2*>(red + ((size_t)wave * BN + lane * CPL + c) * 2) = acc[c][p];
+        __syncthreads();
+        if (tid < BN * 2) {
+            const int col = tid >> 1, e = tid & 1;
+            float sum = 0.0f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) sum += red[((size_t)w * BN + col) * 2 + e];
+            slabs[((size_t)slice * n_total + col_base + col) * kRows + 2 * p + e] = sum;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // h = [embedding rows of the tokens | ht_in] (+ round(sum slabs));  x = RMSNorm(h) * w  (gpt-fast/model.py:158-161, 289-291).
-// One workgroup: thread t owns columns t, t + 1024, ... for all eight tokens.  Writes ht_out [dim][8], xt_out [dim][8] and,
-// optionally, the normalised vector of token `last` as a plain [dim] vector (the lm_head of the prompt's last token).
+// Two launches of dim / 256 workgroups, one column per thread (a single workgroup pulls the 2 MB of a 16-slice projection's slabs
+// through ONE CU: 30 us, first build):
+//   prefill_resid_kernel  h -> ht_out [dim][8], and each workgroup's sums of h^2 per token -> sumsq[workgroup][8]
+//   prefill_norm_kernel   every wave adds the workgroups' sums itself (lane = workgroup), x -> xt_out [dim][8] and, optionally,
+//                         the normalised vector of token `last` as a plain [dim] vector (the lm_head of the prompt's last token)
 // ------------------------------------------------------------------------------------------------
 template <bool BF16>
-__global__ __launch_bounds__(1024) void prefill_resid_norm_kernel(const uint16_t* __restrict__ emb, const int32_t* __restrict__ tokens,
-                                                                  const int T, const uint16_t* __restrict__ ht_in,
-                                                                  const float* __restrict__ slabs, const int split,
-                                                                  const uint16_t* __restrict__ norm_w, const float eps, const int dim,
-                                                                  uint16_t* __restrict__ ht_out, uint16_t* __restrict__ xt_out,
-                                                                  uint16_t* __restrict__ x_last, const int last) {
-    __shared__ float part[16][kRows];
+__global__ __launch_bounds__(256) void prefill_resid_kernel(const uint16_t* __restrict__ emb, const int32_t* __restrict__ tokens, const int T,
+                                                            const uint16_t* __restrict__ ht_in, const float* __restrict__ slabs,
+                                                            const int split, const int dim, uint16_t* __restrict__ ht_out,
+                                                            float* __restrict__ sumsq) {
+    __shared__ float part[4][kRows];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float ss[kRows];
+    const int col = blockIdx.x * 256 + tid;
+    float h[kRows];
 #pragma unroll
-    for (int s = 0; s < kRows; ++s) ss[s] = 0.0f;
-    // pass 1: h, stored (the second pass reads this thread's own words back), and the sums of squares
-    for (int col = tid; col < dim; col += 1024) {
-        float h[kRows];
+    for (int s = 0; s < kRows; ++s) h[s] = 0.0f;
+    if (col < dim) {
         if (tokens) {
 #pragma unroll
-            for (int s = 0; s < kRows; ++s) h[s] = s < T ? bits_to_float(emb[(size_t)tokens[s] * dim + col], BF16) : 0.0f;
+            for (int s = 0; s < kRows; ++s) h[s] = bits_to_float(emb[(size_t)tokens[min(s, T - 1)] * dim + col], BF16);
         } else {
             const u32x4 v = *reinterpret_cast<const u32x4*>(ht_in + (size_t)col * kRows);
 #pragma unroll
@@ -188,59 +272,51 @@ __global__ __launch_bounds__(1024) void prefill_resid_norm_kernel(const uint16_t
             for (int s = 0; s < kRows; ++s) h[s] = bits_to_float(float_to_bits<BF16>(h[s] + y[s]), BF16);
         }
 #pragma unroll
-        for (int s = 0; s < kRows; ++s) { if (s >= T) h[s] = 0.0f; ss[s] = fmaf(h[s], h[s], ss[s]); }
+        for (int s = 0; s < kRows; ++s) h[s] = s < T ? h[s] : 0.0f;
         *reinterpret_cast<u32x4*>(ht_out + (size_t)col * kRows) = pack_row<BF16>(h);
     }
 #pragma unroll
     for (int s = 0; s < kRows; ++s) {
-        const float w = wave_sum_f(ss[s]);
+        const float w = wave_sum_f(h[s] * h[s]);
         if (lane == 0) part[wave][s] = w;
     }
     __syncthreads();
-    float rstd[kRows];
-#pragma unroll
-    for (int s = 0; s < kRows; ++s) {
-        float t = 0.0f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) t += part[w][s];
-        rstd[s] = rsqrtf(t / (float)dim + eps);
-    }
-    for (int col = tid; col < dim; col += 1024) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(ht_out + (size_t)col * kRows);
-        const float nw = bits_to_float(norm_w[col], BF16);
-        float x[kRows];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { x[2 * j] = bits_to_float(v[j] & 0xFFFFu, BF16); x[2 * j + 1] = bits_to_float(v[j] >> 16, BF16); }
-#pragma unroll
-        for (int s = 0; s < kRows; ++s) {
-            const float xn = bits_to_float(float_to_bits<BF16>(x[s] * rstd[s]), BF16);
-            x[s] = s < T ? bits_to_float(float_to_bits<BF16>(xn * nw), BF16) : 0.0f;
-        }
-        if (xt_out) *reinterpret_cast<u32x4*>(xt_out + (size_t)col * kRows) = pack_row<BF16>(x);
-        if (x_last) {
-            float xl = 0.0f;
-#pragma unroll
-            for (int s = 0; s < kRows; ++s) xl = s == last ? x[s] : xl;
-            x_last[col] = float_to_bits<BF16>(xl);
-        }
-    }
+    if (tid < kRows) sumsq[(size_t)blockIdx.x * kRows + tid] = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
 }
 
-// xt[col][s] = round(round(silu(round(gate))) * round(up))  (gpt-fast/model.py:258-259) from the slabs of the gate | up launch
 template <bool BF16>
-__global__ __launch_bounds__(256) void prefill_silu_mul_kernel(const float* __restrict__ slabs, const int split, const int inter,
-                                                               const int T, uint16_t* __restrict__ xt) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= inter) return;
-    float gv[kRows], uv[kRows], x[kRows];
-    rounded_row<BF16>(slabs, split, (size_t)2 * inter, (size_t)col, gv);
-    rounded_row<BF16>(slabs, split, (size_t)2 * inter, (size_t)inter + col, uv);
+__global__ __launch_bounds__(256) void prefill_norm_kernel(const uint16_t* __restrict__ ht, const float* __restrict__ sumsq, const int nwg,
+                                                           const uint16_t* __restrict__ norm_w, const float eps, const int dim, const int T,
+                                                           uint16_t* __restrict__ xt_out, uint16_t* __restrict__ x_last, const int last) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int col = blockIdx.x * 256 + tid;
+    // lane = producing workgroup (nwg = dim / 256 <= 64): its eight sums are two 16-byte loads; the total in workgroup order
+    f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
+    if (lane < nwg) {
+        pa = *reinterpret_cast<const f32x4*>(sumsq + (size_t)lane * kRows);
+        pb = *reinterpret_cast<const f32x4*>(sumsq + (size_t)lane * kRows + 4);
+    }
+    float rstd[kRows];
+#pragma unroll
+    for (int s = 0; s < kRows; ++s) rstd[s] = rsqrtf(wave_sum_f(s < 4 ? pa[s & 3] : pb[s & 3]) / (float)dim + eps);
+    if (col >= dim) return;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(ht + (size_t)col * kRows);
+    const float nw = bits_to_float(norm_w[col], BF16);
+    float x[kRows];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { x[2 * j] = bits_to_float(v[j] & 0xFFFFu, BF16); x[2 * j + 1] = bits_to_float(v[j] >> 16, BF16); }
 #pragma unroll
     for (int s = 0; s < kRows; ++s) {
-        const float sl = bits_to_float(float_to_bits<BF16>(gv[s] / (1.0f + expf(-gv[s]))), BF16);
-        x[s] = s < T ? bits_to_float(float_to_bits<BF16>(sl * uv[s]), BF16) : 0.0f;
+        const float xn = bits_to_float(float_to_bits<BF16>(x[s] * rstd[s]), BF16);
+        x[s] = s < T ? bits_to_float(float_to_bits<BF16>(xn * nw), BF16) : 0.0f;
     }
-    *reinterpret_cast<u32x4*>(xt + (size_t)col * kRows) = pack_row<BF16>(x);
+    if (xt_out) *reinterpret_cast<u32x4*>(xt_out + (size_t)col * kRows) = pack_row<BF16>(x);
+    if (x_last) {
+        float xl = 0.0f;
+#pragma unroll
+        for (int s = 0; s < kRows; ++s) xl = s == last ? x[s] : xl;
+        x_last[col] = float_to_bits<BF16>(xl);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -257,9 +333,35 @@ __global__ __launch_bounds__(HD) void prefill_attention_kernel(const float* __re
     const int h = blockIdx.x, d = threadIdx.x, rep = n_head / n_kv, kvh = h / rep;
     const size_t nq = (size_t)n_head * HD, nkv = (size_t)n_kv * HD, ntot = nq + 2 * nkv;
     float q[kRows], k[kRows], v[kRows];
-    rounded_row<BF16>(slabs, split, ntot, (size_t)h * HD + d, q);
-    rounded_row<BF16>(slabs, split, ntot, nq + (size_t)kvh * HD + d, k);
-    rounded_row<BF16>(slabs, split, ntot, nq + nkv + (size_t)kvh * HD + d, v);
+    {   // the three columns' slabs together: four slices x three columns of loads in flight per round, slice order kept
+        const size_t cols[3] = {(size_t)h * HD + d, nq + (size_t)kvh * HD + d, nq + nkv + (size_t)kvh * HD + d};
+        f32x4 sa[3], sb[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { sa[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; sb[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int k0 = 0; k0 < split; k0 += 4) {
+            f32x4 va[4][3], vb[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float* p = slabs + ((size_t)min(k0 + u, split - 1) * ntot + cols[c]) * kRows;
+                    va[u][c] = *reinterpret_cast<const f32x4*>(p);
+                    vb[u][c] = *reinterpret_cast<const f32x4*>(p + 4);
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k0 + u < split) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { sa[c] += va[u][c]; sb[c] += vb[u][c]; }
+                }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            q[s] = bits_to_float(float_to_bits<BF16>(sa[0][s]), BF16); q[4 + s] = bits_to_float(float_to_bits<BF16>(sb[0][s]), BF16);
+            k[s] = bits_to_float(float_to_bits<BF16>(sa[1][s]), BF16); k[4 + s] = bits_to_float(float_to_bits<BF16>(sb[1][s]), BF16);
+            v[s] = bits_to_float(float_to_bits<BF16>(sa[2][s]), BF16); v[4 + s] = bits_to_float(float_to_bits<BF16>(sb[2][s]), BF16);
+        }
+    }
 #pragma unroll
     for (int s = 0; s < kRows; ++s) {  // (token slots past T hold whatever the slabs held: keep them out of every sum)
         q[s] = s < T ? q[s] : 0.0f;
@@ -320,68 +422,90 @@ using namespace teal;
 
 extern "C" {
 
-int teal_prefill_gemm(const void* xt, const void* w0T, int ld0, int n0, const void* w1T, int ld1, int n1, float* slabs,
+int teal_prefill_gemm(const teal_prefill_in_t* in, const void* w0T, int ld0, int n0, const void* w1T, int ld1, int n1, float* slabs,
                       size_t slabs_bytes, int Z, int T, int dtype, int* split_out, void* stream) {
-    if (!xt || !w0T || !slabs || !split_out || Z <= 0 || n0 <= 0 || n1 < 0 || (n1 > 0 && !w1T)) return TEAL_ERR_ARG;
+    if (!in || !w0T || !slabs || !split_out || Z <= 0 || n0 <= 0 || n1 < 0 || (n1 > 0 && !w1T)) return TEAL_ERR_ARG;
     if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
-    if (T < 1 || T > kRows || (Z & 63) || Z > 65536 || (ld0 & 7) || (ld1 & 7) || ld0 < n0 || (n1 > 0 && ld1 < n1)) return TEAL_ERR_SHAPE;
-    if (!aligned16(xt) || !aligned16(w0T) || (w1T && !aligned16(w1T)) || !aligned16(slabs)) return TEAL_ERR_ALIGN;
+    if (T < 1 || T > kRows || (Z & 255) || Z > 65536 || (ld0 & 7) || (ld1 & 7) || ld0 < n0 || (n1 > 0 && ld1 < n1)) return TEAL_ERR_SHAPE;
+    PrefillProd pr = {};
+    pr.T = T;
+    switch (in->mode) {
+        case TEAL_PREFILL_IN_XT:
+            if (!in->xt || !aligned16(in->xt)) return TEAL_ERR_ARG;
+            pr.xt = reinterpret_cast<const uint16_t*>(in->xt);
+            break;
+        case TEAL_PREFILL_IN_NORM:
+            if (!in->xt || !aligned16(in->xt) || !in->sumsq || !aligned16(in->sumsq) || !in->norm_w || in->nwg < 1 || in->nwg > 64) return TEAL_ERR_ARG;
+            pr.xt = reinterpret_cast<const uint16_t*>(in->xt);
+            pr.sumsq = in->sumsq; pr.nwg = in->nwg; pr.norm_w = reinterpret_cast<const uint16_t*>(in->norm_w); pr.eps = in->eps;
+            break;
+        case TEAL_PREFILL_IN_SILU_MUL:
+            if (!in->gu_slabs || !aligned16(in->gu_slabs) || in->gu_split < 1 || in->gu_split > kPrefillMaxSplit) return TEAL_ERR_ARG;
+            pr.gu = in->gu_slabs; pr.gu_split = in->gu_split;
+            if (in->gu_slabs == slabs) return TEAL_ERR_ARG;  // the launch reads its producer's slabs while it writes its own
+            break;
+        default: return TEAL_ERR_ARG;
+    }
+    if (!aligned16(w0T) || (w1T && !aligned16(w1T)) || !aligned16(slabs)) return TEAL_ERR_ALIGN;
     DeviceCtx* ctx = device_ctx();
     if (!ctx) return TEAL_ERR_NO_DEVICE;
     const int ncu = ctx->num_cu, ntot = n0 + n1;
-    // 128-column tiles (256-byte row segments) when they still cover two thirds of the CUs, else 64-column tiles; the rows are
-    // sliced (fp32 slabs, summed by the consumer in slice order) until tiles x slices ~ the CU count
-    int lpr = 32;
-    if (n0 % 128 || n1 % 128 || (ntot / 128) * 3 < ncu * 2) lpr = 16;
-    const int bn = lpr * 4;
+    // 256-column tiles; the 16-row groups are dealt to `split` slices: never more workgroups than CUs (a 16-wave workgroup owns its
+    // CU: 86 tiles x 3 = 258 workgroups ran 62 us, x 2 = 172 run 38), every wave keeping at least one full pair of batches
+    // (split <= Z / 256), and among the candidates the one whose waves stream the fewest 8-row batches (ties: the fewer slabs)
+    constexpr int bn = 256;
     if (n0 % bn || n1 % bn) return TEAL_ERR_SHAPE;
-    const int tiles = ntot / bn, nch = Z >> 6;
-    int split = ncu / tiles;
-    if (split > nch / 16) split = nch / 16;
-    if (split > 8) split = 8;
-    if (split < 1) split = 1;
+    const int tiles = ntot / bn, ngroups = Z >> 4;
+    int smax = ncu / tiles;
+    if (smax > Z / 256) smax = Z / 256;
+    if (smax > kPrefillMaxSplit) smax = kPrefillMaxSplit;
+    if (smax < 1) smax = 1;
+    int split = 1, best = INT_MAX;
+    for (int c = 1; c <= smax; ++c) {
+        const int batches = ((ngroups + c - 1) / c + 7) / 8;
+        if (batches < best) { best = batches; split = c; }
+    }
     if (slabs_bytes < (size_t)split * ntot * kRows * sizeof(float)) return TEAL_ERR_WORKSPACE;
     const dim3 grid(tiles, split), block(1024);
-    const size_t lds = (size_t)16 * bn * 4 * sizeof(float);
+    const size_t lds = (size_t)16 * bn * 2 * sizeof(float);  // 32 KB: the activation rows of a phase, then the reduction tile
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int np = (T + 1) / 2, tiles0 = n0 / bn;
-    auto* x = reinterpret_cast<const uint16_t*>(xt);
     auto* a = reinterpret_cast<const uint16_t*>(w0T);
     auto* b = reinterpret_cast<const uint16_t*>(w1T);
-#define TEAL_PG(BF, LP, NPV) hipLaunchKernelGGL((prefill_gemm_kernel<BF, LP, NPV>), grid, block, lds, st, x, a, ld0, b, ld1, tiles0, slabs, Z, ntot)
-#define TEAL_PG_NP(BF, LP) do { switch (np) { case 1: TEAL_PG(BF, LP, 1); break; case 2: TEAL_PG(BF, LP, 2); break; case 3: TEAL_PG(BF, LP, 3); break; default: TEAL_PG(BF, LP, 4); } } while (0)
-#define TEAL_PG_L(BF) do { if (lpr == 32) TEAL_PG_NP(BF, 32); else TEAL_PG_NP(BF, 16); } while (0)
-    if (dtype == TEAL_BF16) TEAL_PG_L(true); else TEAL_PG_L(false);
-#undef TEAL_PG_L
+#define TEAL_PG(BF, NPV, PR) hipLaunchKernelGGL((prefill_gemm_kernel<BF, NPV, PR>), grid, block, lds, st, pr, a, ld0, b, ld1, tiles0, slabs, Z, ntot)
+#define TEAL_PG_PR(BF, NPV) do { if (in->mode == TEAL_PREFILL_IN_NORM) TEAL_PG(BF, NPV, 1); else if (in->mode == TEAL_PREFILL_IN_SILU_MUL) TEAL_PG(BF, NPV, 2); else TEAL_PG(BF, NPV, 0); } while (0)
+#define TEAL_PG_NP(BF) do { switch (np) { case 1: TEAL_PG_PR(BF, 1); break; case 2: TEAL_PG_PR(BF, 2); break; case 3: TEAL_PG_PR(BF, 3); break; default: TEAL_PG_PR(BF, 4); } } while (0)
+    if (dtype == TEAL_BF16) TEAL_PG_NP(true); else TEAL_PG_NP(false);
 #undef TEAL_PG_NP
+#undef TEAL_PG_PR
 #undef TEAL_PG
     *split_out = split;
     return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
 }
 
 int teal_prefill_resid_norm(const void* emb, const int32_t* tokens, int T, const void* ht_in, const float* slabs, int split,
-                            const void* norm_w, float eps, int dim, void* ht_out, void* xt_out, void* x_last, int dtype, void* stream) {
-    if ((!tokens) == (!ht_in) || (tokens && !emb) || !norm_w || !ht_out || dim <= 0 || split < 0 || (split > 0 && !slabs)) return TEAL_ERR_ARG;
+                            const void* norm_w, float eps, int dim, void* ht_out, void* xt_out, void* x_last, float* sumsq_scratch,
+                            int dtype, void* stream) {
+    if ((!tokens) == (!ht_in) || (tokens && !emb) || ((xt_out || x_last) && !norm_w) || !ht_out || !sumsq_scratch || dim <= 0 || split < 0 || (split > 0 && !slabs))
+        return TEAL_ERR_ARG;
     if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
     if (T < 1 || T > kRows || dim > 16384) return TEAL_ERR_SHAPE;
     if (!device_ctx()) return TEAL_ERR_NO_DEVICE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define TEAL_PRN(BF) hipLaunchKernelGGL((prefill_resid_norm_kernel<BF>), dim3(1), dim3(1024), 0, st, reinterpret_cast<const uint16_t*>(emb), tokens, T, \
-    reinterpret_cast<const uint16_t*>(ht_in), slabs, split, reinterpret_cast<const uint16_t*>(norm_w), eps, dim, reinterpret_cast<uint16_t*>(ht_out),        \
-    reinterpret_cast<uint16_t*>(xt_out), reinterpret_cast<uint16_t*>(x_last), T - 1)
-    if (dtype == TEAL_BF16) TEAL_PRN(true); else TEAL_PRN(false);
-#undef TEAL_PRN
-    return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
-}
-
-int teal_prefill_silu_mul(const float* gu_slabs, int split, int inter, int T, void* xt, int dtype, void* stream) {
-    if (!gu_slabs || !xt || split < 1 || inter <= 0) return TEAL_ERR_ARG;
-    if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
-    if (T < 1 || T > kRows) return TEAL_ERR_SHAPE;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid((inter + 255) / 256), block(256);
-    if (dtype == TEAL_BF16) hipLaunchKernelGGL((prefill_silu_mul_kernel<true>), grid, block, 0, st, gu_slabs, split, inter, T, reinterpret_cast<uint16_t*>(xt));
-    else hipLaunchKernelGGL((prefill_silu_mul_kernel<false>), grid, block, 0, st, gu_slabs, split, inter, T, reinterpret_cast<uint16_t*>(xt));
+    const int nwg = (dim + 255) / 256;  // <= 64
+    auto* e = reinterpret_cast<const uint16_t*>(emb);
+    auto* hi = reinterpret_cast<const uint16_t*>(ht_in);
+    auto* ho = reinterpret_cast<uint16_t*>(ht_out);
+    auto* nw = reinterpret_cast<const uint16_t*>(norm_w);
+    auto* xo = reinterpret_cast<uint16_t*>(xt_out);
+    auto* xl = reinterpret_cast<uint16_t*>(x_last);
+    if (dtype == TEAL_BF16) {
+        hipLaunchKernelGGL((prefill_resid_kernel<true>), dim3(nwg), dim3(256), 0, st, e, tokens, T, hi, slabs, split, dim, ho, sumsq_scratch);
+        if (xo || xl) hipLaunchKernelGGL((prefill_norm_kernel<true>), dim3(nwg), dim3(256), 0, st, ho, sumsq_scratch, nwg, nw, eps, dim, T, xo, xl, T - 1);
+    } else {
+        hipLaunchKernelGGL((prefill_resid_kernel<false>), dim3(nwg), dim3(256), 0, st, e, tokens, T, hi, slabs, split, dim, ho, sumsq_scratch);
+        if (xo || xl) hipLaunchKernelGGL((prefill_norm_kernel<false>), dim3(nwg), dim3(256), 0, st, ho, sumsq_scratch, nwg, nw, eps, dim, T, xo, xl, T - 1);
+    }
     return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
 }
 

@@ -4,15 +4,16 @@ The reference's prefill is dense by construction: `SparseGEMV.forward` / `Sparse
 when the sequence is longer than one token (kernels/sparse_gemv.py:271,298) inside the stock gpt-fast forward
 (gpt-fast/model.py:107-121, 158-186, 258-259, 289-291), and its tokens/sec counts that pass (gpt-fast/generate.py:458,487-496).
 Op by op, the 6-token default prompt costs ~400 launches here: 20 ms eager, 10 ms from a hipGraph — six to twelve decode steps'
-worth (profiles/r05_generate_breakdown_before.txt).  `PrefillEngine` runs the same pass as eight launches per layer over the
+worth (profiles/r05_generate_breakdown_before.txt).  `PrefillEngine` runs the same pass as seven launches per layer over the
 decode step's own weight images (teal_amd/csrc/teal_prefill.hip):
 
-    gemm(wqkv) -> attention (RoPE, cache rows 0..T-1, causal softmax) -> gemm(wo) -> resid_norm -> gemm(w1 | w3) -> silu_mul ->
-    gemm(w2) -> resid_norm                                 ... -> lm_head of the LAST token (teal_dense_gemv)
+    gemm(wqkv) [RMSNorm while staging] -> attention (RoPE, cache rows 0..T-1, causal softmax) -> gemm(wo) -> resid ->
+    gemm(w1 | w3) [RMSNorm while staging] -> gemm(w2) [silu * up while staging] -> resid
+                                                           ... -> norm + lm_head of the LAST token (teal_dense_gemv)
 
 and returns logits [1, 1, vocab] of the last prompt token (all `generate()` samples from).  Nothing is sparsified: thresholds
 play no role in the prompt pass.  `FusedPrefill` is what generate() calls: the HIP pass (replayed from a hipGraph per prompt
-length) where it applies — 16-bit weights, one GPU, T <= 8, positions 0..T-1 — and the module path otherwise.
+length) where it applies — 16-bit weights, one GPU, 2 <= T <= 8, positions 0..T-1 — and the module path otherwise.
 """
 from __future__ import annotations
 
@@ -26,6 +27,12 @@ from ..monkeypatch import UP_SHIFT_BYTES, to_column_major
 from .model import Transformer
 
 MAX_T = 8  # tokens per transposed word of the hand-over layout ([feature][8])
+IN_XT, IN_NORM, IN_SILU_MUL = 0, 1, 2
+
+
+class PrefillIn(ctypes.Structure):  # teal_prefill_in_t
+    _fields_ = [("mode", ctypes.c_int), ("xt", ctypes.c_void_p), ("sumsq", ctypes.c_void_p), ("nwg", ctypes.c_int),
+                ("norm_w", ctypes.c_void_p), ("eps", ctypes.c_float), ("gu_slabs", ctypes.c_void_p), ("gu_split", ctypes.c_int)]
 
 
 class PrefillEngine:
@@ -46,8 +53,8 @@ class PrefillEngine:
             return "model is not on a HIP device"
         inter = model.layers[0].feed_forward.w1.out_features
         qd, kv = cfg.n_head * cfg.head_dim, cfg.n_local_heads * cfg.head_dim
-        if cfg.head_dim not in (64, 128) or cfg.dim != qd or cfg.dim % 64 or cfg.dim > 16384 or inter % 64 or (qd + 2 * kv) % 64 or kv % 64:
-            return "shape outside the prompt-pass kernels' contract (head_dim 64 / 128, dim = n_head * head_dim <= 16384, widths % 64)"
+        if cfg.head_dim not in (64, 128) or cfg.dim != qd or cfg.dim % 256 or cfg.dim > 16384 or inter % 256 or (qd + 2 * kv) % 256:
+            return "shape outside the prompt-pass kernels' contract (head_dim 64 / 128, dim = n_head * head_dim <= 16384, widths % 256)"
         if cfg.vocab_size % 8:
             return "vocab_size must be a multiple of 8"
         if model.freqs_cis is None or model.freqs_cis.dtype != dt:
@@ -78,15 +85,18 @@ class PrefillEngine:
         self.max_seq = model.max_seq_length
         z = lambda *shape, dtype=dt: torch.zeros(*shape, device=dev, dtype=dtype)  # noqa: E731
         self.tokens = z(MAX_T, dtype=torch.int32)
-        self.ht, self.xt, self.yt, self.xd = z(self.dim, MAX_T), z(self.dim, MAX_T), z(self.dim, MAX_T), z(self.inter, MAX_T)
-        # one slab buffer for every GEMM of the pass (launches are stream-ordered: the consumer has read it before the next
-        # GEMM writes it): [slices <= 8][columns][8] fp32
-        self.slabs = z(8 * max(self.nqkv, 2 * self.inter, self.dim) * MAX_T, dtype=torch.float32)
+        self.ht, self.yt = z(self.dim, MAX_T), z(self.dim, MAX_T)
+        # two slab buffers [slices <= 16][columns][8] fp32, used alternately (launches are stream-ordered: a consumer has read its
+        # producer's slabs before the next-but-one GEMM overwrites them; the down projection reads gate | up's while writing its own)
+        n = 16 * max(self.nqkv, 2 * self.inter, self.dim) * MAX_T
+        self.slabs = [z(n, dtype=torch.float32), z(n, dtype=torch.float32)]
         self.x_last = z(self.dim)
+        self.sumsq = z(64 * MAX_T, dtype=torch.float32)  # per-workgroup sums of squares: resid launch -> normalising consumer
         self.logits = z(1, 1, cfg.vocab_size)
         self.rope = model.freqs_cis.contiguous()
         self.ws = runtime.new_workspace(self.dim, cfg.vocab_size)
         self.eps = float(cfg.norm_eps)
+        self.nwg = (self.dim + 255) // 256
         self._split = ctypes.c_int(0)
 
     def key(self):
@@ -98,24 +108,29 @@ class PrefillEngine:
                                               layer.feed_forward.w1.weight.data_ptr(), layer.feed_forward.w2.weight.data_ptr(),
                                               layer.feed_forward.w3.weight.data_ptr()))
 
-    def _gemm(self, xt, lin0, lin1, Z, T, st) -> int:
+    def _gemm(self, gin: PrefillIn, lin0, lin1, Z, T, out: torch.Tensor, st) -> int:
         w0 = lin0.weight
         n1 = lin1.weight.shape[0] if lin1 is not None else 0
-        rc = self.L.teal_prefill_gemm(xt.data_ptr(), w0.data_ptr(), w0.stride(1), w0.shape[0],
+        rc = self.L.teal_prefill_gemm(ctypes.byref(gin), w0.data_ptr(), w0.stride(1), w0.shape[0],
                                       lin1.weight.data_ptr() if lin1 is not None else None, lin1.weight.stride(1) if lin1 is not None else 0, n1,
-                                      self.slabs.data_ptr(), self.slabs.numel() * 4, Z, T, self.code, ctypes.byref(self._split), st)
+                                      out.data_ptr(), out.numel() * 4, Z, T, self.code, ctypes.byref(self._split), st)
         if rc != 0:
             _lib.check(rc, "teal_prefill_gemm")
         return self._split.value
 
-    def _norm(self, tokens, slabs_split, norm_w, T, st, last=False):
+    def _resid(self, tokens: bool, slabs: Optional[torch.Tensor], split: int, T, st, final_norm=None):
+        """h (+)= round(sum slabs); leaves the per-workgroup sums of squares for the normalising consumer.  final_norm: also
+        the normalised vector of the LAST token as a plain vector (the lm_head's input)."""
         rc = self.L.teal_prefill_resid_norm(self.model.tok_embeddings.weight.data_ptr() if tokens else None,
                                             self.tokens.data_ptr() if tokens else None, T, None if tokens else self.ht.data_ptr(),
-                                            self.slabs.data_ptr() if slabs_split else None, slabs_split, norm_w.data_ptr(), self.eps,
-                                            self.dim, self.ht.data_ptr(), self.xt.data_ptr(), self.x_last.data_ptr() if last else None,
-                                            self.code, st)
+                                            slabs.data_ptr() if slabs is not None else None, split,
+                                            final_norm.data_ptr() if final_norm is not None else None, self.eps, self.dim, self.ht.data_ptr(),
+                                            None, self.x_last.data_ptr() if final_norm is not None else None, self.sumsq.data_ptr(), self.code, st)
         if rc != 0:
             _lib.check(rc, "teal_prefill_resid_norm")
+
+    def _norm_in(self, norm_w) -> PrefillIn:
+        return PrefillIn(mode=IN_NORM, xt=self.ht.data_ptr(), sumsq=self.sumsq.data_ptr(), nwg=self.nwg, norm_w=norm_w.data_ptr(), eps=self.eps)
 
     @torch.no_grad()
     def __call__(self, prompt: torch.Tensor) -> torch.Tensor:
@@ -126,24 +141,21 @@ class PrefillEngine:
         m, cfg, L, st = self.model, self.model.config, self.L, runtime.stream_ptr()
         self.tokens[:T].copy_(prompt.view(-1))
         layers = list(m.layers)
-        self._norm(True, 0, layers[0].attention_norm.weight, T, st)
+        A, B = self.slabs
+        self._resid(True, None, 0, T, st)
         for i, layer in enumerate(layers):
             at, ff = layer.attention, layer.feed_forward
-            ns = self._gemm(self.xt, at.wqkv, None, self.dim, T, st)
+            ns = self._gemm(self._norm_in(layer.attention_norm.weight), at.wqkv, None, self.dim, T, A, st)
             kc, vc = at.kv_cache.k_cache, at.kv_cache.v_cache
-            rc = L.teal_prefill_attention(self.slabs.data_ptr(), ns, self.rope.data_ptr(), kc.data_ptr(), vc.data_ptr(), self.yt.data_ptr(), T,
+            rc = L.teal_prefill_attention(A.data_ptr(), ns, self.rope.data_ptr(), kc.data_ptr(), vc.data_ptr(), self.yt.data_ptr(), T,
                                           cfg.n_head, cfg.n_local_heads, cfg.head_dim, self.max_seq, self.code, st)
             if rc != 0:
                 _lib.check(rc, "teal_prefill_attention")
-            ns = self._gemm(self.yt, at.wo, None, self.dim, T, st)
-            self._norm(False, ns, layer.ffn_norm.weight, T, st)
-            ns = self._gemm(self.xt, ff.w1, ff.w3, self.dim, T, st)
-            rc = L.teal_prefill_silu_mul(self.slabs.data_ptr(), ns, self.inter, T, self.xd.data_ptr(), self.code, st)
-            if rc != 0:
-                _lib.check(rc, "teal_prefill_silu_mul")
-            ns = self._gemm(self.xd, ff.w2, None, self.inter, T, st)
-            nxt = layers[i + 1].attention_norm.weight if i + 1 < len(layers) else m.norm.weight
-            self._norm(False, ns, nxt, T, st, last=i + 1 == len(layers))
+            ns = self._gemm(PrefillIn(mode=IN_XT, xt=self.yt.data_ptr()), at.wo, None, self.dim, T, B, st)
+            self._resid(False, B, ns, T, st)
+            ns = self._gemm(self._norm_in(layer.ffn_norm.weight), ff.w1, ff.w3, self.dim, T, A, st)
+            ns = self._gemm(PrefillIn(mode=IN_SILU_MUL, gu_slabs=A.data_ptr(), gu_split=ns), ff.w2, None, self.inter, T, B, st)
+            self._resid(False, B, ns, T, st, final_norm=m.norm.weight if i + 1 == len(layers) else None)
         w = m.output.weight
         rc = L.teal_sparse_qkv_gemv_ld(self.x_last.data_ptr(), w.data_ptr(), w.stride(1), self.logits.data_ptr(), float("-inf"), float("-inf"),
                                        float("-inf"), self.dim, cfg.vocab_size, cfg.vocab_size, 0, self.code, self.ws.data_ptr(),
@@ -175,7 +187,9 @@ class FusedPrefill:
 
     def __call__(self, prompt: torch.Tensor) -> torch.Tensor:
         T = int(prompt.numel())
-        eng = self._engine() if T <= MAX_T else None
+        # (a ONE-token prompt is a decode step in the reference too — its ops take the sparse kernel whenever the sequence length
+        #  is 1, kernels/sparse_gemv.py:271,298 — so it goes the way single-token calls go: the fallback / the model's fused step)
+        eng = self._engine() if 2 <= T <= MAX_T else None
         if eng is None:
             self.used = "fallback"
             if self.fallback is not None:

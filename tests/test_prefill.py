@@ -26,9 +26,10 @@ def _image(bits, Z, N, dtype, pad=64):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
-@pytest.mark.parametrize("Z,n0,n1", [(4096, 4096, 0), (4096, 12288, 0), (4096, 11008, 11008), (11008, 4096, 0), (8192, 1280, 0)])
+@pytest.mark.parametrize("Z,n0,n1", [(4096, 4096, 0), (4096, 12288, 0), (4096, 11008, 11008), (11008, 4096, 0), (8192, 10240, 0), (512, 768, 0)])
 def test_prefill_gemm_vs_oracle(oracle, Z, n0, n1, dtype):
     from teal_amd import _lib, runtime
+    from teal_amd.gpt_fast.prefill import IN_XT, PrefillIn
     O = oracle
     L = _lib.load()
     runtime.init()
@@ -37,16 +38,17 @@ def test_prefill_gemm_vs_oracle(oracle, Z, n0, n1, dtype):
     W0 = _image(w0b, Z, n0, dtype)
     W1 = _image(w1b, Z, n1, dtype) if n1 else None
     ntot = n0 + n1
-    slabs = torch.full((8 * ntot * 8,), float("nan"), device=DEV, dtype=torch.float32)
+    slabs = torch.full((16 * ntot * 8,), float("nan"), device=DEV, dtype=torch.float32)
     for T in (1, 6, 8):
         xs = [O.hash_uniform(Z, 500 + 10 * T + s, 2.0, dtype) for s in range(T)]
         xt = torch.zeros(Z, 8, device=DEV, dtype=W0.dtype)
         for s in range(T):
             xt[:, s] = torch_from_bits(xs[s], dtype, DEV)
         split = ctypes.c_int(0)
-        rc = L.teal_prefill_gemm(xt.data_ptr(), W0.data_ptr(), W0.stride(0), n0, W1.data_ptr() if n1 else None, W1.stride(0) if n1 else 0, n1,
+        gin = PrefillIn(mode=IN_XT, xt=xt.data_ptr())
+        rc = L.teal_prefill_gemm(ctypes.byref(gin), W0.data_ptr(), W0.stride(0), n0, W1.data_ptr() if n1 else None, W1.stride(0) if n1 else 0, n1,
                                  slabs.data_ptr(), slabs.numel() * 4, Z, T, dtype, ctypes.byref(split), runtime.stream_ptr())
-        assert rc == 0 and 1 <= split.value <= 8
+        assert rc == 0 and 1 <= split.value <= 16
         torch.cuda.synchronize()
         v = slabs[: split.value * ntot * 8].view(split.value, ntot, 8)
         acc = torch.zeros(ntot, 8, device=DEV, dtype=torch.float32)
@@ -60,15 +62,15 @@ def test_prefill_gemm_vs_oracle(oracle, Z, n0, n1, dtype):
             assert (err <= tolerance(O, truth, dtype)).all(), (Z, n0, n1, dtype, T, s, float(err.max()))
     # argument checks: T out of range, ragged Z, a slab buffer too small
     bad = ctypes.c_int(0)
-    assert L.teal_prefill_gemm(xt.data_ptr(), W0.data_ptr(), W0.stride(0), n0, None, 0, 0, slabs.data_ptr(), slabs.numel() * 4, Z, 9, dtype,
+    assert L.teal_prefill_gemm(ctypes.byref(gin), W0.data_ptr(), W0.stride(0), n0, None, 0, 0, slabs.data_ptr(), slabs.numel() * 4, Z, 9, dtype,
                                ctypes.byref(bad), runtime.stream_ptr()) == -3
-    assert L.teal_prefill_gemm(xt.data_ptr(), W0.data_ptr(), W0.stride(0), n0, None, 0, 0, slabs.data_ptr(), slabs.numel() * 4, Z - 8, 6, dtype,
+    assert L.teal_prefill_gemm(ctypes.byref(gin), W0.data_ptr(), W0.stride(0), n0, None, 0, 0, slabs.data_ptr(), slabs.numel() * 4, Z - 64, 6, dtype,
                                ctypes.byref(bad), runtime.stream_ptr()) == -3
-    assert L.teal_prefill_gemm(xt.data_ptr(), W0.data_ptr(), W0.stride(0), n0, None, 0, 0, slabs.data_ptr(), 64, Z, 6, dtype,
+    assert L.teal_prefill_gemm(ctypes.byref(gin), W0.data_ptr(), W0.stride(0), n0, None, 0, 0, slabs.data_ptr(), 64, Z, 6, dtype,
                                ctypes.byref(bad), runtime.stream_ptr()) == -5
 
 
-@pytest.mark.parametrize("arch,tdt,n_layer,T", [("7B", torch.float16, 2, 6), ("7B", torch.float16, 2, 1), ("7B", torch.float16, 2, 8),
+@pytest.mark.parametrize("arch,tdt,n_layer,T", [("7B", torch.float16, 2, 6), ("7B", torch.float16, 2, 2), ("7B", torch.float16, 2, 8),
                                                  ("llama-3-8b", torch.bfloat16, 2, 6), ("tiny-gqa-test", torch.float16, 2, 5)])
 def test_fused_prompt_pass_equals_module_path(arch, tdt, n_layer, T):
     from teal_amd.gpt_fast import generate as G
@@ -108,6 +110,9 @@ def test_fused_prompt_pass_equals_module_path(arch, tdt, n_layer, T):
             out = FusedPrefill(model, graph=False)
             y = out(long_prompt)
             assert out.used == "fallback" and y.shape == (1, 9, V)
+            # ... and so does a one-token prompt: a decode step in the reference too (its ops run the sparse kernel at S == 1)
+            out(long_prompt[:1])
+            assert out.used == "fallback"
     finally:
         del model
         torch.cuda.empty_cache()
