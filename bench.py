@@ -80,7 +80,6 @@ def parse():
     ap.add_argument("--no-context-sweep", action="store_true", help="skip the value_at_context runs (1000 and 3800 cache positions)")
     ap.add_argument("--block_size", type=int, default=0, help="override the architecture's context length (RoPE table / cache limit) "
                     "for long-context experiments; 0 = the reference's value (2048 for 7B)")
-    ap.add_argument("--wave-local", type=int, default=1, help="wave-local compaction (A/B switch)")
     ap.add_argument("--graph-tokens", type=int, default=1,
                     help="decode steps per hipGraph replay (token, position and RNG counter are device-resident, so a graph can span "
                          "several tokens; the timed region still runs exactly --steps steps, the remainder one token per replay)")
@@ -546,7 +545,6 @@ def main():
     from teal_amd.gpt_fast import generate as G
     runtime.init()
     from teal_amd import _lib
-    _lib.load().teal_set_wave_local(a.wave_local)
     if a.tuning:
         assert _lib.load().teal_set_tuning(*[int(v) for v in a.tuning.split(",")]) == 0
     if a.pair is not None:

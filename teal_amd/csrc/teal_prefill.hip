@@ -130,6 +130,8 @@ __global__ __launch_bounds__(1024) void prefill_gemm_kernel(const PrefillProd pr
         const int njp = min(PHASE_GROUPS, nj - jb);  // groups of this phase (one phase for every Llama-2-7B launch)
         const uint16_t* wph = wrow + (size_t)jb * stride;
         const int nfull = njp / (2 * U);  // whole pairs of batches
+        // (staging the rows as fp32 — no conversion of the activations in the loop: 17 instead of 25 vector instructions per row —
+        //  was measured too: no faster, gate | up 41.3 -> 43.6 us: the loop is not bound by its conversions)
         // (requesting the first batch of weight rows ahead of the staging — nothing in it depends on the activations — was
         //  measured: the 16 registers it keeps live through the producers push the kernel to 126-128 registers with spills, and
         //  the gate | up launch went 41 -> 48 us; profiles/r05_prefill_kernel_stats.txt)

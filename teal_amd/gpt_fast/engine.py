@@ -707,14 +707,27 @@ class DecodeEngine:
         return g
 
     @torch.no_grad()
-    def decode_n(self, first_token: torch.Tensor, pos: int, n: int, temperature: float = 0.8,
-                 top_k: Optional[int] = 200, use_graph: bool = True) -> torch.Tensor:
-        """n decode steps starting from `first_token` at position `pos`; returns the n sampled tokens."""
-        assert n <= self.history.numel() and pos + n <= self.max_seq
-        self.tok_buf.copy_(first_token.view(1, 1))
-        self.pos_buf.fill_(pos)
+    def begin_sequence(self):
+        """a new sample: its own random stream (seed + running count of samples), draw counter 0"""
         self._calls += 1
         self.rng_state.copy_(torch.tensor([self._seed + self._calls, 0], dtype=torch.int64))
+
+    def sample_first(self, logits_row: torch.Tensor, temperature: float = 0.8, top_k: Optional[int] = 200) -> torch.Tensor:
+        """the token after the prompt, drawn by the fused sampler from the prompt pass's last-position logits (one launch where
+        the torch sampler of generate.sample takes ~10): opens the sample's random stream; follow with decode_n(..., drawn=1)"""
+        assert logits_row.is_contiguous() and logits_row.numel() == self.cfg.vocab_size and logits_row.dtype == self.dtype
+        self.begin_sequence()
+        return self.sample_fused(logits_row, temperature, top_k, feed=False)
+
+    def decode_n(self, first_token: torch.Tensor, pos: int, n: int, temperature: float = 0.8,
+                 top_k: Optional[int] = 200, use_graph: bool = True, drawn: int = 0) -> torch.Tensor:
+        """n decode steps starting from `first_token` at position `pos`; returns the n sampled tokens.  drawn: tokens already
+        drawn from this sample's random stream (sample_first: 1) — the loop continues it instead of opening a new one."""
+        assert n + drawn <= self.history.numel() and pos + n <= self.max_seq
+        self.tok_buf.copy_(first_token.view(1, 1))
+        self.pos_buf.fill_(pos)
+        if not drawn:
+            self.begin_sequence()
         if use_graph and self.reduce is not None and not getattr(self.reduce, "capturable", False):
             use_graph = False  # host-staged all-reduce (gloo): the step cannot live in a hipGraph
         if use_graph:
@@ -724,7 +737,7 @@ class DecodeEngine:
         else:
             for _ in range(n):
                 self._self_step(temperature, top_k)
-        return self.history[:n].clone()
+        return self.history[drawn:drawn + n].clone()  # (the sampler files a token under its draw counter)
 
     # nn.Module-ish surface so GraphedDecoder can drive either a Transformer or an engine
     @property

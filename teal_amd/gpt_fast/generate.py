@@ -420,11 +420,21 @@ def generate(model: Transformer, prompt: torch.Tensor, max_new_tokens: int, deco
     seq = torch.empty(T_new, dtype=prompt.dtype, device=dev)
     seq[:T] = prompt
     logits = prefill(prompt) if prefill is not None else model(prompt.view(1, -1), torch.arange(0, T, device=dev))
+    eng = decoder.model if hasattr(decoder.model, "decode_n") else None
+    if eng is not None and logits.dtype == eng.dtype and logits.shape[-1] == eng.cfg.vocab_size:
+        # HIP engine: the token after the prompt comes from the same fused sampler as every later one (gpt-fast/generate.py:
+        # 49-66 is ONE function for both), and the whole loop stays on the device
+        next_token = eng.sample_first(logits[0, -1], decoder.kw["temperature"], decoder.kw["top_k"])
+        seq[T] = next_token.view(())
+        toks = eng.decode_n(next_token, T, max_new_tokens - 1, temperature=decoder.kw["temperature"],
+                            top_k=decoder.kw["top_k"], use_graph=decoder.use_graph, drawn=1)
+        seq[T + 1:] = toks.to(seq.dtype)
+        return seq
     next_token = sample(logits, temperature=temperature, top_k=top_k)[0].clone()
     seq[T] = next_token
-    if hasattr(decoder.model, "decode_n"):  # HIP engine: the whole loop stays on the device
-        toks = decoder.model.decode_n(next_token, T, max_new_tokens - 1, temperature=decoder.kw["temperature"],
-                                      top_k=decoder.kw["top_k"], use_graph=decoder.use_graph)
+    if eng is not None:
+        toks = eng.decode_n(next_token, T, max_new_tokens - 1, temperature=decoder.kw["temperature"],
+                            top_k=decoder.kw["top_k"], use_graph=decoder.use_graph)
         seq[T + 1:] = toks.to(seq.dtype)
         return seq
     input_pos = torch.tensor([T], device=dev, dtype=torch.int)
