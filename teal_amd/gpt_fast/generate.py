@@ -203,7 +203,7 @@ def refine_thresholds_on_decode(model: Transformer, sparsities: Dict[str, List[f
     eng = cls(model, ths)
     ths = eng.calibrate_on_decode(sparsities, toks[-1:].clone(), n_prompt, span)
     from teal_amd.gpt_fast import tp
-    ths = tp.sync_thresholds(ths)
+    ths = tp.sync_thresholds(ths, model)
     for layer, th in zip(model.layers, ths):
         at, ff = layer.attention, layer.feed_forward
         at.thresh_q, at.thresh_k, at.thresh_v, at.thresh_o = th["q"], th["k"], th["v"], th["o"]
@@ -231,7 +231,7 @@ def apply_sparsity(model: Transformer, *, sparsity: float, hist_path: Optional[s
     device = model.output.weight.device.type
     if synthetic or hist_path is None:
         from teal_amd.gpt_fast import tp
-        ths = tp.sync_thresholds(calibrate_thresholds(model, sparsities))  # (one tau per site on every rank; no-op without TP)
+        ths = tp.sync_thresholds(calibrate_thresholds(model, sparsities), model)  # (one tau per site on every rank; no-op without TP)
         for i, layer in enumerate(model.layers):
             monkeypatch_layer(i, layer, sparsity, None, device, thresholds=ths[i])
         if decode_calibration and device == "cuda" and any(float(v) > 0 for vals in sparsities.values() for v in vals):

@@ -96,16 +96,19 @@ def make_reduce(group=None):
     return reduce
 
 
-def sync_thresholds(ths, group=None):
+def sync_thresholds(ths, model, group=None):
     """Synthetic calibration under TP: thresholds are properties of the activation SITES, not of a rank — the row-wise
     projections' sites (attention output, silu(gate) * up) are sliced over the ranks, so a quantile taken on a rank's slice
-    is averaged over the ranks; every rank then masks with the same tau (the rank-local slice of ONE global mask)."""
-    if not dist.is_initialized() or dist.get_world_size(group) < 2:
+    is averaged over the ranks; every rank then masks with the same tau (the rank-local slice of ONE global mask).
+    Only for a model `apply_tp` sharded: independent replicas under one process group (bench.py --gpus N) keep their own."""
+    if int(getattr(model, "tp_world", 1)) < 2 or not dist.is_initialized() or dist.get_world_size(group) < 2:
         return ths
     keys = sorted(ths[0].keys())
     t = torch.tensor([[float(th[k]) for k in keys] for th in ths], dtype=torch.float64)
+    if dist.get_backend(group) == "nccl":  # RCCL reduces device tensors only
+        t = t.to(torch.device("cuda", torch.cuda.current_device()))
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    t /= dist.get_world_size(group)
+    t = t.cpu() / dist.get_world_size(group)
     return [{k: float(t[i, j]) for j, k in enumerate(keys)} for i in range(len(ths))]
 
 

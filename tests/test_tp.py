@@ -37,6 +37,7 @@ def test_sharded_model_equals_unsharded(tp_result):
     assert r["prefill_max_err"] <= 1e-4 * max(1.0, r["prefill_scale"]), r
     assert r["decode_max_err"] <= 1e-4 * max(1.0, r["prefill_scale"]), r
     assert r["collectives"] == {"all_reduce_calls": 4, "elements_each": 256, "bytes_each": 512, "bytes_per_token": 2048}
+    assert r["sync_sharded"] == [{"o": 1.5, "q": 0.5}] and r["sync_replica"] == [{"o": 1.0, "q": 0.5}]  # (rank 0 reports)
 
 
 def test_teal_masks_and_sums_under_tp(tp_result):

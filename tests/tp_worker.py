@@ -51,6 +51,10 @@ def main():
         b1 = sharded(torch.tensor([[5]]), torch.tensor([6]))
         res["decode_max_err"] = float((a1 - b1).abs().max())
     res["collectives"] = tp.collectives_per_token(sharded)
+    # thresholds: averaged over the ranks for a SHARDED model only (replicas under one process group keep their own)
+    mine = [{"o": 1.0 + rank, "q": 0.5}]
+    res["sync_sharded"] = tp.sync_thresholds(mine, sharded)
+    res["sync_replica"] = tp.sync_thresholds(mine, full)
 
     # ---- 2. TEAL under TP, checked with the oracle: colwise gate | up on the replicated x with the SAME threshold, rowwise
     #         down on the rank's slice of h with the SAME threshold; the all-reduced partial sums equal the unsharded truth --
