@@ -621,8 +621,8 @@ def main():
     st_sparse = None
     if rank == 0 and world == 1:
         out["roofline"] = roofline_engine_gateup(info["engine"], a) if mode == "engine" else roofline_dominant_kernel(model, a)
-        if mode == "engine" and not a.no_dense and info["engine"].att_fused_merge:
-            st_sparse = info["engine"].stage_times()
+        if mode == "engine" and not a.no_dense and info["engine"].att_fused_merge and not info["engine"].int4:
+            st_sparse = info["engine"].stage_times()  # (int4: kept PAIRS + dense group parameters — another byte model)
         if not a.no_dense:
             # dense comparator on the same harness: same kernels with every row kept (threshold < 0)
             a_d = argparse.Namespace(**vars(a))

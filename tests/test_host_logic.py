@@ -317,3 +317,32 @@ def test_measurement_scripts_compile():
     assert len(files) >= 10
     for f in files + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]:
         py_compile.compile(f, doraise=True)
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """The Python side hands teal_gemv_in_t / teal_gemv_out_t / teal_prefill_in_t to the C ABI as ctypes structures: every field's
+    offset and each structure's size must be what gcc lays out for include/teal_hip.h (a field added on one side only would shift
+    every pointer behind it silently)."""
+    import ctypes
+    import subprocess
+    from teal_amd.gpt_fast.engine import GemvIn, GemvOut
+    from teal_amd.gpt_fast.prefill import PrefillIn
+    structs = {"teal_gemv_in_t": GemvIn, "teal_gemv_out_t": GemvOut, "teal_prefill_in_t": PrefillIn}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "teal_hip.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = {}
+    for ln in subprocess.check_output([str(exe)], text=True).splitlines():
+        c, f, v = ln.split()
+        got[(c, f)] = int(v)
+    for cname, cls in structs.items():
+        assert got[(cname, "size")] == ctypes.sizeof(cls), (cname, got[(cname, "size")], ctypes.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
