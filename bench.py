@@ -614,7 +614,8 @@ def main():
         # one sample of max_new_tokens = 200 after a prompt of `prompt_tokens`
         t_pf = info.get("prefill_s")
         if t_pf:
-            out["tokens_per_sec_reference_definition"] = 200.0 / (t_pf + 200.0 * t / a.steps)
+            # (max_new_tokens = 200 is the prompt pass — which yields the first new token — plus 199 decode steps: generate.py:380-406)
+            out["tokens_per_sec_reference_definition"] = 200.0 / (t_pf + 199.0 * t / a.steps)
             out["prefill_ms"] = t_pf * 1e3
             out["prefill_path"] = {"hip": "hand-fused HIP prompt pass (teal_amd/gpt_fast/prefill.py), hipGraph replay",
                                    "fallback": "module path"}.get(info.get("prefill_path"), info.get("prefill_path"))
