@@ -11,8 +11,8 @@
 //   gemm(w1 | w3) [RMSNorm while staging] -> gemm(w2) [silu * up while staging] -> resid
 //
 // Every hand-over between launches is TRANSPOSED: [feature][8] — the up to eight tokens of a feature are one 16-byte word
-// (16-bit activations) or one 32-byte pair (fp32 split-K slabs) — so that a GEMM lane fetches "row m of every token" with one
-// load and the GEMM needs no LDS staging and no barrier in its loop.  The GEMM is bound by HBM like the GEMV (every weight
+// (16-bit activations) or one 32-byte pair (fp32 split-K slabs) — so that "row m of every token" is one word: a GEMM workgroup
+// stages its slice's rows in LDS once, and a wave then fetches a row with one broadcast read.  The GEMM is bound by HBM like the GEMV (every weight
 // byte is read once for all tokens: 2 * T flops per byte, far from MFMA territory at T <= 8, and the reduction dimension is
 // the strided one in the W^T image, which rules the matrix cores' operand layout out without a second copy of the weights).
 // Rounding points are those of the module path's 16-bit tensors (projection outputs, RoPE, attention output, residual adds,
