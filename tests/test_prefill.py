@@ -71,7 +71,8 @@ def test_prefill_gemm_vs_oracle(oracle, Z, n0, n1, dtype):
 
 
 @pytest.mark.parametrize("arch,tdt,n_layer,T", [("7B", torch.float16, 2, 6), ("7B", torch.float16, 2, 2), ("7B", torch.float16, 2, 8),
-                                                 ("llama-3-8b", torch.bfloat16, 2, 6), ("tiny-gqa-test", torch.float16, 2, 5)])
+                                                 ("llama-3-8b", torch.bfloat16, 2, 6), ("tiny-gqa-test", torch.float16, 2, 5),
+                                                 ("70B", torch.float16, 1, 6)])
 def test_fused_prompt_pass_equals_module_path(arch, tdt, n_layer, T):
     from teal_amd.gpt_fast import generate as G
     from teal_amd.gpt_fast.prefill import FusedPrefill
