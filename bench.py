@@ -95,15 +95,17 @@ def dist_setup(n):
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     have_gpu = torch.cuda.is_available()
+    ndev = torch.cuda.device_count() if have_gpu else 0
     if have_gpu:
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(local % ndev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if have_gpu:
+        if have_gpu and ndev >= world:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
+        else:  # no GPU (the CPU test), or more ranks than GPUs (replicas sharing a device: RCCL refuses that; the timing
+               # barrier / max are all the collectives there are)
             dist.init_process_group("gloo")
     return rank, world, local
 
@@ -160,7 +162,7 @@ def timed_decode(step_fn, steps, warmup, world, markers=False):
         profile_marker()
     if world > 1:  # the job's time is the slowest replica's
         import torch.distributed as dist
-        tt = torch.tensor([t], device="cuda" if torch.cuda.is_available() else "cpu", dtype=torch.float64)
+        tt = torch.tensor([t], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t = float(tt.item())
     return t

@@ -1,5 +1,7 @@
 """Decode harness: CPU checks of the model/generate plumbing (dense path only — the sparse ops are
 GPU-only) and GPU checks of the monkeypatched model under hipGraph capture."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -333,3 +335,29 @@ def test_fused_decode_follows_replaced_weights_and_caches():
     m.setup_caches(1, 32)  # same size, new cache tensors
     a2 = step()
     assert torch.allclose(a1.float(), a2.float(), atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_bench_replicas_under_torch_distributed_run():
+    """`bench.py --gpus 2` the way the driver launches it (torch.distributed.run, one rank per replica): every rank decodes its
+    own stream, the only collectives are the timing barrier and the max over ranks, rank 0 prints one JSON line whose value is the
+    aggregate.  On a one-GPU box the two replicas share the device (gloo; RCCL refuses two ranks on a GPU) — the flow is the same."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--n_layer", "2",
+           "--no-cpu-baseline", "--no-context-sweep"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 alone prints the line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["warmup"] == 3 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 10 / (d["ms_per_step"] * 10 / 1e3)) < 1e-6 * d["value"]
+    assert d["roofline"] is None and d["cpu_baseline"] is None and "replicas x2" in d["config"]["parallelism"]
