@@ -75,6 +75,8 @@ def parse():
     ap.add_argument("--n_layer", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense comparator run")
+    ap.add_argument("--no-reference-dense", action="store_true",
+                    help="skip the second comparator (the un-patched gpt-fast model under a hipGraph: a second copy of the weights)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="skip the rocprofv3 --pmc subprocess that measures roofline.traffic in this run (the committed pass is reported instead)")
     ap.add_argument("--no-context-sweep", action="store_true", help="skip the value_at_context runs (1000 and 3800 cache positions)")
@@ -89,24 +91,38 @@ def parse():
     return ap.parse_args()
 
 
+def _dist_on():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def dist_setup(n):
     """one process per GPU (torch.distributed.run sets RANK/LOCAL_RANK/WORLD_SIZE).  RCCL ("nccl") on a
-    GPU box; gloo when no GPU is visible (the CPU test of this replica/timing logic)."""
+    GPU box; gloo when no GPU is visible (the CPU test of this replica/timing logic).
+    TEAL_BENCH_FORCE_DIST=nccl|gloo takes the world > 1 branch with ONE rank as well (process group with device_id, barrier,
+    float64 MAX all-reduce on the device): every collective of the N > 1 path executes on the one leased GPU
+    (tests/test_rccl_one_rank.py) before a multi-GPU node runs it."""
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    force = os.environ.get("TEAL_BENCH_FORCE_DIST", "")
     have_gpu = torch.cuda.is_available()
     ndev = torch.cuda.device_count() if have_gpu else 0
     if have_gpu:
         torch.cuda.set_device(local % ndev)
-    if world > 1:
+    if world > 1 or force:
+        import socket
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if have_gpu and ndev >= world:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if "MASTER_PORT" not in os.environ:  # (only without a launcher: the forced one-rank group)
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        if have_gpu and ndev >= world and force != "gloo":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local % ndev))
         else:  # no GPU (the CPU test), or more ranks than GPUs (replicas sharing a device: RCCL refuses that; the timing
                # barrier / max are all the collectives there are)
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     return rank, world, local
 
 
@@ -116,7 +132,7 @@ def _sync():
 
 
 def barrier(world):
-    if world > 1:
+    if world > 1 or _dist_on():
         import torch.distributed as dist
         dist.barrier()
 
@@ -160,7 +176,7 @@ def timed_decode(step_fn, steps, warmup, world, markers=False):
     t = time.perf_counter() - t0
     if markers:
         profile_marker()
-    if world > 1:  # the job's time is the slowest replica's
+    if world > 1 or _dist_on():  # the job's time is the slowest replica's
         import torch.distributed as dist
         tt = torch.tensor([t], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -258,34 +274,51 @@ def roofline_dominant_kernel(model, a):
             "timing": "HIP events around a hipGraph of one launch per layer (distinct weights); includes the same-stream launch boundary"}
 
 
+def gateup_launch_bytes(nnz_gate, nnz_up, Z, N, nslabs, pair=False, wbytes=2, qbytes=0):
+    """Bytes of ONE fused gate|up launch, SURVEY 8(d) to the letter: `algorithmic` = kept rows of both matrices
+    (nnz x N x e each) + Z x 2 (the activation vector the GEMV consumes) + N_out x 2 (gate and up, or h = silu(gate) * up
+    when the launch is paired) [+ the dense quantisation parameters of int8 / int4 images, which every launch reads whatever
+    is kept].  What the fused producer reads to BUILD that vector (residual, fp32 slabs of the previous projection, norm
+    weight) and the keep masks a paired launch emits are overhead and reported apart as `producer`.
+    `kept_fraction` = kept rows / rows over both matrices, on the state the launch ran on."""
+    n_out = N if pair else 2 * N
+    algo = int((nnz_gate + nnz_up) * N * wbytes) + int(qbytes) + Z * 2 + n_out * 2
+    producer = Z * 2 + nslabs * Z * 4 + Z * 2 + ((N // 8) if pair else 0)  # residual + fp32 slabs + norm weight (+ the keep masks out)
+    return {"algorithmic": algo, "producer": producer, "kept_fraction": (nnz_gate + nnz_up) / (2.0 * Z)}
+
+
+def roofline_fields(algorithmic_bytes_per_launch, us_per_launch):
+    """achieved / frac of the roofline object: algorithmic bytes per launch / average launch duration / 8 TB/s"""
+    achieved = algorithmic_bytes_per_launch / (us_per_launch * 1e-6) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
+
+
 def roofline_engine_gateup(eng, a):
-    """Dominant kernel of the fused decode step: the MLP gate|up launch (RESID_NORM producer + two
-    weight matrices, ~92 MB at 50 %).  One launch per layer inside a hipGraph, each layer's own
-    w1/w3 and thresholds (2.9 GB of distinct weights >> 256 MB Infinity Cache), timed with HIP events
-    on the launch stream.  Algorithmic bytes: kept rows of both matrices + the producer's inputs
-    (residual, slabs, norm weight) + the gate|up output."""
+    """Dominant kernel of the fused decode step: the MLP gate|up launch (RESID_NORM producer + two weight matrices, ~90 MB at
+    50 %).  One launch per layer inside a hipGraph, each layer's own w1/w3 and thresholds (2.9 GB of distinct weights >> 256 MB
+    Infinity Cache), timed with HIP events on the launch stream.  Algorithmic bytes: gateup_launch_bytes (kept rows
+    of both matrices + Z x 2 + the output), counted on the state the graph runs on; the producer's inputs are `producer_bytes`."""
     from teal_amd import runtime
     from teal_amd.gpt_fast.engine import GemvIn, TEAL_IN_RESID_NORM
     m, cfg = eng.model, eng.cfg
-    Z, N = cfg.dim, cfg.intermediate_size
+    Z, N = cfg.dim, eng.inter
     ns = eng.n_wo.value
     B = eng.resid[1]
     # the producer's output, recomputed in torch to count kept rows per layer
-    stride = (ns + 3) & ~3  # interleaved slabs: [Z][stride]
-    ssum = eng.s_wo.view(-1)[: Z * stride].view(Z, stride)[:, :ns].sum(1)
+    ssum = eng.handover_sum("wo")  # the fp32 hand-over of wo, added in slice order
     h = (B.float() + ssum.to(B.dtype).float()).to(B.dtype)
     hf = h.float()
     xn = (hf * torch.rsqrt(hf.pow(2).mean() + eng.eps)).to(B.dtype)
-    total_bytes, launches = 0, []
+    total_bytes, producer_bytes, kept, launches = 0, 0, 0.0, []
     for i, st in enumerate(eng.stages):
         k4_in, k4_out = st[6], st[7]
         x = (xn * m.layers[i].ffn_norm.weight).float().abs()
         nnz_g = int((x > k4_out.tau[0]).sum())
         nnz_u = int((x > k4_out.tau[1]).sum())
-        out_bytes = (N * 2 + N // 8) if eng.pair else 2 * N * 2  # h (+ keep masks) vs gate|up
         wbytes = 0.5 if eng.int4 else (1 if eng.int8 else 2)  # int8: + the two scale vectors; int4: + the group parameters
         qbytes = 2 * N * 2 if eng.int8 else (2 * (Z // m.layers[i].feed_forward.w1.groupsize) * N * 4 if eng.int4 else 0)
-        total_bytes += int((nnz_g + nnz_u) * N * wbytes) + qbytes + Z * 2 + ns * Z * 4 + Z * 2 + out_bytes
+        b = gateup_launch_bytes(nnz_g, nnz_u, Z, N, ns, pair=eng.pair, wbytes=wbytes, qbytes=qbytes)
+        total_bytes += b["algorithmic"]; producer_bytes += b["producer"]; kept += b["kept_fraction"]
         gin = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=B.data_ptr(), slabs=eng.s_wo.data_ptr(), nslabs=ns, slabs_interleaved=1,
                      norm_weight=m.layers[i].ffn_norm.weight.data_ptr(), eps=eng.eps, resid_out=None)
         launches.append((gin, k4_out))
@@ -316,7 +349,7 @@ def roofline_engine_gateup(eng, a):
         ts.append(e0.elapsed_time(e1) * 1e-3)
     t = float(np.median(ts))
     n = len(launches)
-    kname = eng.L.teal_last_launch_desc().decode()  # the instantiation run_gemv actually launched
+    kname = eng.describe_launch(launches[0][0], launches[0][1], Z)  # the instantiation run_gemv launches (per call, no global)
     live = False
     traffic, tsrc = (None, "disabled (--no-live-traffic)") if (getattr(a, "no_live_traffic", False) or eng.int8 or eng.int4) else pmc_traffic_live(cfg, a, kname, pair=eng.pair)
     if traffic is not None:
@@ -327,17 +360,23 @@ def roofline_engine_gateup(eng, a):
         if tsrc:
             tsrc = f"{tsrc}; live pass: {why}"
     ceiling = measured_read_ceiling_gbs()
-    return {"bound": "hbm", "achieved": total_bytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": total_bytes / t / 1e9 / HBM_PEAK_GBS, "frac_of_measured_ceiling": total_bytes / t / 1e9 / ceiling,
+    out = roofline_fields(total_bytes / n, t / n * 1e6)
+    out.update({"frac_of_measured_ceiling": out["achieved"] / ceiling,
             "measured_ceiling": ceiling, "measured_ceiling_how": "1 GiB dense GEMV (8192 x 65536 fp16) through teal_dense_gemv in this run, "
             "median of 9 launches incl. the launch boundary", "traffic": traffic, "traffic_source": tsrc,
             "traffic_measured_in_this_run": live,
             "kernel": kname + f" (fused RMSNorm -> mask -> gate|up GEMV{' -> silu*mul' if eng.pair else ''}, Z={Z}, N=2x{N}"
                       + ("; int4: algorithmic bytes count kept ROWS at half a byte per weight + the dense group parameters — the kernel "
                          "fetches row PAIRS, 1.5x those weight bytes at 50 %" if eng.int4 else "") + ")",
-            "algorithmic_bytes": total_bytes / n, "us_per_launch": t / n * 1e6, "launches_timed": n,
+            "algorithmic_bytes": total_bytes / n, "algorithmic_bytes_formula": "sum over gate, up of nnz x N x 2  +  Z x 2  +  N_out x 2 (SURVEY 8(d))",
+            "producer_bytes": producer_bytes / n, "producer_bytes_note": "what the fused producer reads instead of x (residual + fp32 slabs + norm "
+            "weight; + the keep masks a paired launch emits): overhead, NOT in algorithmic_bytes / achieved / frac",
+            "kept_fraction": kept / n, "kept_fraction_note": "kept rows / rows over both matrices, mean over layers, ON THE STATE THE TIMED GRAPH RUNS ON "
+            "(the line's top-level kept_fraction is the mean over three decode positions)",
+            "us_per_launch": t / n * 1e6, "launches_timed": n,
             "timing": "HIP events (launch stream) around a hipGraph of one launch per layer with that layer's weights; "
-                      "per-launch time includes the same-stream launch boundary, like rocprofv3's per-dispatch duration"}
+                      "per-launch time includes the same-stream launch boundary, like rocprofv3's per-dispatch duration"})
+    return out
 
 
 def floor_model(st_sparse, st_dense, n_layer):
@@ -542,6 +581,8 @@ def cpu_baseline(model, a, budget_s=14.0, n_layers_sampled=4):
 
 def main():
     a = parse()
+    if a.tuning:  # a forced launch geometry is a switch of the diagnostics build (libteal_hip_diag.so): the whole run goes through it
+        os.environ["TEAL_LIB_FLAVOR"] = "diag"
     rank, world, local = dist_setup(a.gpus)
     from teal_amd import runtime
     from teal_amd.gpt_fast import generate as G
@@ -603,6 +644,9 @@ def main():
         out["metric"] = out["metric"].replace(a.precision, f"int4-g32-weight/{a.precision}-activation")
         out["dtype"] = out["dtype"] + " activations, int4 group-quantised weights (g32), 16-bit lm_head"
         out["config"]["workload"] += ", int4 group-quantised projections (g32), 16-bit lm_head"
+    if _dist_on():  # which collectives bracketed the timed region (N > 1, or the forced one-rank group)
+        import torch.distributed as dist
+        out["config"]["process_group"] = f"{dist.get_backend()}, world {world}: barrier + max over ranks of the timing"
     out.update(info.get("report", {}))
     if info.get("graph_tokens", 1) > 1:
         out["config"]["graph_tokens"] = info["graph_tokens"]  # decode steps per hipGraph replay (device-resident loop state)
@@ -644,7 +688,7 @@ def main():
             out["speedup_vs_dense"] = tps / dense_tps
             out["dense_comparator"] = ("the same fused engine with every row kept (thresholds < 0: same kernels, same launches) — "
                                        "the strongest dense fp16 path on this box; the reference's own dense path follows")
-            if mode == "engine" and a.weights == "16bit":
+            if mode == "engine" and a.weights == "16bit" and not a.no_reference_dense:
                 # the reference's dense path as it exists here: the un-patched gpt-fast model (torch.matmul / hipBLASLt,
                 # eager glue; no Inductor on this image) under the same hipGraph capture
                 rmodel = G.build_synthetic_model(a.model, "cuda", dt, n_layer=a.n_layer)
@@ -683,7 +727,7 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if _dist_on():
         import torch.distributed as dist
         dist.destroy_process_group()
 

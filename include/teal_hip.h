@@ -28,11 +28,12 @@
  *   - extern "C", plain pointers and sizes, no C++/torch types, no exceptions across the boundary.
  *   - All pointers are DEVICE pointers owned by the caller (PyTorch); the library borrows them for
  *     the duration of the stream-ordered launch and never allocates.  Library state: the properties of each device,
- *     cached the first time it is used (teal_init(); immutable), a host-side registry of the workspaces prepared by
- *     teal_workspace_init() (which device memory holds a valid header), and the diagnostics / tuning switches of the
- *     last section (teal_set_tuning, teal_set_fast, teal_set_wave_local, teal_set_phase_*):
- *     host-side variables read at launch time, NOT thread-safe, meant for benchmarks and tests.  No device memory
- *     belongs to the library: the arrival counters of the single-launch split-K GEMVs and the scratch of the
+ *     cached the first time it is used (teal_init(); immutable), and a host-side registry of the workspaces prepared by
+ *     teal_workspace_init() (which device memory holds a valid header; mutex-protected).  Nothing else: no entry point
+ *     of libteal_hip.so changes how a later call behaves, and what a call did is reported through its own arguments
+ *     (teal_gemv_out_t.desc).  The tuning / phase-stamp switches of the last section exist only in the DIAGNOSTICS
+ *     build of the same sources, libteal_hip_diag.so (-DTEAL_DIAGNOSTICS), which the product path never loads.
+ *     No device memory belongs to the library: the arrival counters of the single-launch split-K GEMVs and the scratch of the
  *     multi-workgroup sampler live in the header of the CALLER's workspace, so two streams, two captured graphs or two
  *     devices can only collide if the caller hands them the same workspace.
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Every call is
@@ -181,6 +182,13 @@ int teal_sparse_gateup_silu(const void* x, const void* w1T, const void* w3T, voi
                               * q [ncols[0]], rounded exactly as teal_decode_attention* would have; follow it with
                               * teal_decode_attention_split_roped.  Otherwise (*nslabs_out >= 1) the launch behaved as
                               * TEAL_OUT_SLABS (slabs required) and teal_decode_attention_split_slabs finishes the job */
+#define TEAL_OUT_SLAB_SUM 4  /* nseg == 1: `slabs` (plain memory, fp32 [ncols]) receives the UNROUNDED sum over the row slices,
+                              * added in slice order by the last slice of each tile to arrive (arrival tickets: `ws` must be a
+                              * prepared workspace when the launch uses split-K) — bit-identical to summing the TEAL_OUT_SLABS
+                              * slabs in slice order.  *nslabs_out = 1; the consumer is a RESID_NORM producer with nslabs = 1,
+                              * slabs_interleaved = 0.  Tensor parallelism: the [ncols] fp32 vector is what the ranks all-reduce
+                              * (gpt-fast/tp.py:120-121,139-140) instead of [ncols][4..8] slabs.  16-bit and int8 weights; shapes
+                              * outside the lean kernel return TEAL_ERR_CONFIG without launching */
 #define TEAL_OUT_PAIR_SILU 2 /* nseg == 2 (gate, up of equal shape): every workgroup streams the same column tile
                               * of both matrices and stores h = silu(gate) * up to y[0] (model.py:258-259); optional
                               * mask_out[ncols/64] = keep masks of h against mask_tau for a TEAL_IN_MASKED consumer */
@@ -243,6 +251,10 @@ typedef struct teal_gemv_out {
     int act_seg0;              /* TEAL_OUT_ROUNDED: y[0] = round(silu(round(sum))) for segment 0 (the gate projection of an
                                 * unpaired gate | up launch, model.py:258); the other segments are stored as usual.  16-bit
                                 * and int8 weights (not the int4 kernel) */
+    char* desc;                /* optional HOST buffer: receives the kernel template instantiation and grid of the launch THIS
+                                * call made, NUL-terminated (as rocprofv3 prints it; e.g. to name the kernel in a benchmark
+                                * record) — per call, no library state */
+    int desc_bytes;            /* capacity of desc (160 is enough) */
 } teal_gemv_out_t;
 
 /* One launch: [fused producer] -> mask + compaction -> gathered GEMV over every segment.
@@ -372,7 +384,10 @@ int teal_prefill_attention(const float* qkv_slabs, int split, const void* rope, 
 int teal_cmp_flag_gemv(const void* x, const void* wT, int ld, float* y32, unsigned char* flags, float tau, int Z, int N,
                        int dtype, void* stream);
 
-/* ---- tuning / introspection ------------------------------------------------------------------ */
+/* ---- diagnostics build only (libteal_hip_diag.so = these sources with -DTEAL_DIAGNOSTICS) ------------------------
+ * Process-global switches, NOT thread-safe, for benchmarks, phase-stamp probes and the parity tests that force the general
+ * kernel or a launch geometry.  libteal_hip.so exports none of them. */
+#ifdef TEAL_DIAGNOSTICS
 
 /* Override the launch geometry picked from (Z, N, CU count): lanes per row segment (8/16/32/64) and split-K factor
  * (>= 1); waves per workgroup and unroll depth are fixed at 16 and 4 (the other values of round 1 were sweep-only
@@ -404,6 +419,9 @@ int teal_set_phase_buffer(void* dev_u64);
  * workgroups, and the buffer must hold u64_per_launch * (launches between two teal_set_phase_stride calls) uint64;
  * 0 (default): every launch stamps the start of the buffer. */
 int teal_set_phase_stride(size_t u64_per_launch);
+#endif /* TEAL_DIAGNOSTICS */
+
+/* ---- introspection (pure function of its arguments and the device's CU count) ------------------ */
 
 /* The geometry a GEMV of this shape would use: out[0..5) = {lanes_per_row, waves, split, unroll,
  * workgroups}. */

@@ -10,6 +10,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("TEAL_LIB_FLAVOR", "diag")  # the tuning / phase-stamp switches exist in libteal_hip_diag.so only
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 from teal_amd import _lib, runtime  # noqa: E402
 from benchmark_gemv import graph_times  # noqa: E402

@@ -16,6 +16,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("TEAL_LIB_FLAVOR", "diag")  # the tuning / phase-stamp switches exist in libteal_hip_diag.so only
 from teal_amd import _lib, runtime  # noqa: E402
 from teal_amd.gpt_fast import generate as G  # noqa: E402
 from teal_amd.gpt_fast.engine import DecodeEngine  # noqa: E402

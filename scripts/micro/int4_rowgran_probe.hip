@@ -12,7 +12,7 @@
 // shapes at 50 % activation sparsity, weights rotating over 8 images.  Checked against a naive fp64 reference kernel.
 // Benchmark utility, not product code.
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include scripts/micro/int4_rowgran_probe.hip -L teal_amd -lteal_hip \
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include scripts/micro/int4_rowgran_probe.hip -DTEAL_DIAGNOSTICS -L teal_amd -lteal_hip_diag \
 //         -Wl,-rpath,'$ORIGIN/../../teal_amd' -o scripts/micro/int4_rowgran_probe
 #include <hip/hip_runtime.h>
 

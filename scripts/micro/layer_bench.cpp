@@ -1,10 +1,11 @@
 // layer_bench — the fused decode step of teal_amd/gpt_fast/engine.py driven straight through the C ABI (no Python, no
 // torch: starts in a second on a fresh GPU box), for kernel experiments on MI355X.  Benchmark utility, not product code.
 //
-//   hipcc --offload-arch=gfx950 -O2 -std=c++17 -I include scripts/micro/layer_bench.cpp -L teal_amd -lteal_hip \
+//   hipcc --offload-arch=gfx950 -O2 -std=c++17 -I include scripts/micro/layer_bench.cpp -DTEAL_DIAGNOSTICS -L teal_amd -lteal_hip_diag \
 //         -Wl,-rpath,'$ORIGIN/../../teal_amd' -o scripts/micro/layer_bench
 //   layer_bench [--layers 32] [--steps 100] [--sparsity 0.5] [--model 7b|8b|70b] [--phase] [--dense] [--pos 64]
 //               [--tune stage:lpr:waves:split:unroll,...]   (stage = qkv|wo|gu|down|head|all)
+//               [--presum] wo / down fold their row slices themselves (TEAL_OUT_SLAB_SUM: one fp32 [dim] hand-over instead of slabs)
 //               [--tp W]   one RANK's launches under W-way tensor parallelism (gpt-fast/tp.py:110-140: the rank's query / KV heads
 //                          and intermediate columns, the residual stream replicated; the two all-reduces per layer are NOT in it)
 //
@@ -86,6 +87,7 @@ struct Layer {
 
 int main(int argc, char** argv) {
     int n_layer = 32, steps = 100, pos0 = 64, warm = 5, att_split = 0, pair = 1, tp = 1;
+    bool presum = false;  // --presum: wo / down hand over ONE fp32 [dim] vector (TEAL_OUT_SLAB_SUM): what TP ranks would all-reduce
     int gate_act = getenv("LB_GATEACT") ? atoi(getenv("LB_GATEACT")) : 1;  // silu in the gate tiles' epilogue (act_seg0)
     int use_rope = getenv("LB_ROPE") ? atoi(getenv("LB_ROPE")) : 1;  // RoPE + KV append in the qkv launch's epilogue (TEAL_OUT_QKV_ROPE)
     float sparsity = 0.5f;
@@ -105,6 +107,7 @@ int main(int argc, char** argv) {
         else if (a == "--att_split") att_split = atoi(nxt().c_str());
         else if (a == "--no_pair") pair = 0;
         else if (a == "--tp") tp = atoi(nxt().c_str());
+        else if (a == "--presum") presum = true;
         else if (a == "--tune") {
             std::string s = nxt();
             size_t p = 0;
@@ -217,7 +220,7 @@ int main(int argc, char** argv) {
         Layer& l = Ls[i];
         teal_gemv_in_t in; memset(&in, 0, sizeof in);
         in.mode = TEAL_IN_RESID_NORM; in.resid_in = i == 0 ? (const void*)emb : (const void*)A; in.row_index = i == 0 ? tok : nullptr;
-        in.slabs = i == 0 ? nullptr : s_down; in.nslabs = i == 0 ? 0 : n_down; in.slabs_interleaved = 1;
+        in.slabs = i == 0 ? nullptr : s_down; in.nslabs = i == 0 ? 0 : n_down; in.slabs_interleaved = presum ? 0 : 1;
         in.norm_weight = l.norm1; in.eps = eps; in.resid_out = B;
         const void* w[3] = {l.wqkv, l.wqkv, l.wqkv}; const int ld[3] = {ldq, ldq, ldq}; const int c0[3] = {0, qd, qd + kv};
         const int nc[3] = {qd, kv, kv}; const float tau[3] = {tq, tq, tq};
@@ -246,14 +249,15 @@ int main(int argc, char** argv) {
         if (fused_merge) { in.mode = TEAL_IN_ATTN_MERGE; in.x = att_ws; in.att_head_dim = hd; in.att_nsplit = att_split; }
         else { in.mode = TEAL_IN_MASKED; in.x = y_attn; in.masks = y_mask; }
         const void* w[1] = {l.wo}; const int ld[1] = {ldo}; const int c0[1] = {0}; const int nc[1] = {dim}; const float tau[1] = {to};
-        teal_gemv_out_t o = mk_out(1, w, ld, c0, nc, tau, nullptr, TEAL_OUT_SLABS, s_wo);
+        teal_gemv_out_t o = mk_out(1, w, ld, c0, nc, tau, nullptr, presum ? TEAL_OUT_SLAB_SUM : TEAL_OUT_SLABS, s_wo);
+        if (presum) o.slabs_interleaved = 0;
         apply_tune("wo");
         TK(teal_fused_gemv(&in, &o, qd, dt, ws, ws_bytes, &n_wo, ls));
     };
     auto k_gu = [&](int i, float tg, float td) {
         Layer& l = Ls[i];
         teal_gemv_in_t in; memset(&in, 0, sizeof in);
-        in.mode = TEAL_IN_RESID_NORM; in.resid_in = B; in.slabs = s_wo; in.nslabs = n_wo; in.slabs_interleaved = 1;
+        in.mode = TEAL_IN_RESID_NORM; in.resid_in = B; in.slabs = s_wo; in.nslabs = n_wo; in.slabs_interleaved = presum ? 0 : 1;
         in.norm_weight = l.norm2; in.eps = eps; in.resid_out = A;
         const void* w[2] = {l.w1, l.w3}; const int ld[2] = {ldi, ldi}; const int c0[2] = {0, 0}; const int nc[2] = {inter, inter};
         const float tau[2] = {tg, tg};
@@ -276,13 +280,14 @@ int main(int argc, char** argv) {
         if (pair) { in.mode = TEAL_IN_MASKED; in.x = h_mlp; in.masks = h_mask; }
         else { in.mode = TEAL_IN_SILU_MUL; in.x = gu; in.gate_activated = gate_act; }
         const void* w[1] = {l.w2}; const int ld[1] = {ldd}; const int c0[1] = {0}; const int nc[1] = {dim}; const float tau[1] = {td};
-        teal_gemv_out_t o = mk_out(1, w, ld, c0, nc, tau, nullptr, TEAL_OUT_SLABS, s_down);
+        teal_gemv_out_t o = mk_out(1, w, ld, c0, nc, tau, nullptr, presum ? TEAL_OUT_SLAB_SUM : TEAL_OUT_SLABS, s_down);
+        if (presum) o.slabs_interleaved = 0;
         apply_tune("down");
         TK(teal_fused_gemv(&in, &o, inter, dt, ws, ws_bytes, &n_down, ls));
     };
     auto k_head = [&]() {
         teal_gemv_in_t in; memset(&in, 0, sizeof in);
-        in.mode = TEAL_IN_RESID_NORM; in.resid_in = A; in.slabs = s_down; in.nslabs = n_down; in.slabs_interleaved = 1;
+        in.mode = TEAL_IN_RESID_NORM; in.resid_in = A; in.slabs = s_down; in.nslabs = n_down; in.slabs_interleaved = presum ? 0 : 1;
         in.norm_weight = normf; in.eps = eps; in.resid_out = nullptr;
         const void* w[1] = {wout}; const int ld[1] = {ldv}; const int c0[1] = {0}; const int nc[1] = {S.vocab}; const float tau[1] = {NEG};
         void* y[1] = {logits};

@@ -57,6 +57,7 @@ def main():
     gin = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=resid.data_ptr(), slabs=slabs.data_ptr(), nslabs=4, slabs_interleaved=1,
                  norm_weight=normw.data_ptr(), eps=1e-5, resid_out=None)
     desc = None
+    dbuf = ctypes.create_string_buffer(160)  # the launch reports its own kernel instantiation + grid (teal_gemv_out_t.desc)
     for _ in range(a.reps):
         for w1, w3 in ws_:
             o = GemvOut()
@@ -66,13 +67,15 @@ def main():
             for i, w in enumerate((w1, w3)):
                 o.w[i], o.ld[i], o.col0[i], o.ncols[i], o.tau[i] = w.data_ptr(), ld, 0, N, tau
                 o.y[i] = gu.data_ptr() + 2 * N * i
+            o.desc, o.desc_bytes = ctypes.cast(dbuf, ctypes.c_char_p), 160
             rc = L.teal_fused_gemv(ctypes.byref(gin), ctypes.byref(o), Z, code, wsb.data_ptr(), wsb.numel() * 4, None, runtime.stream_ptr())
             assert rc == 0, rc
-            desc = L.teal_last_launch_desc().decode()
+            desc = dbuf.value.decode()
     torch.cuda.synchronize()
     nnz = int((x > tau).sum())
     print(json.dumps({"kernel": desc, "launches": a.sets * a.reps, "kept_fraction": kept,
-                      "algorithmic_bytes": 2 * nnz * N * 2 + Z * 2 + 4 * Z * 4 + Z * 2 + 2 * N * 2}))
+                      "algorithmic_bytes": 2 * nnz * N * 2 + Z * 2 + (N if a.pair else 2 * N) * 2,  # kept rows + x + y
+                      "producer_bytes": Z * 2 + 4 * Z * 4 + Z * 2 + ((N // 8) if a.pair else 0)}))
 
 
 if __name__ == "__main__":

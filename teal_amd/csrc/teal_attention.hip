@@ -1482,7 +1482,7 @@ int teal_decode_attention_masked(const void* qkv, const void* rope, const int32_
     auto* vc = reinterpret_cast<uint16_t*>(v_cache);
     auto* yo = reinterpret_cast<uint16_t*>(y);
     auto* mo = reinterpret_cast<unsigned long long*>(mask_out);
-#define TEAL_ATT(BF, NTV, HDV) hipLaunchKernelGGL((decode_attention_kernel<BF, NTV, HDV>), grid, block, lds, st, q, r, pos, kc, vc, yo, mo, mask_tau, n_head, n_kv_head, max_seq, scale, g_phase_stride ? nullptr : g_phase)
+#define TEAL_ATT(BF, NTV, HDV) hipLaunchKernelGGL((decode_attention_kernel<BF, NTV, HDV>), grid, block, lds, st, q, r, pos, kc, vc, yo, mo, mask_tau, n_head, n_kv_head, max_seq, scale, phase_start_only())
 #define TEAL_ATT_HD(BF, NTV) do { if (head_dim == 128) TEAL_ATT(BF, NTV, 128); else TEAL_ATT(BF, NTV, 64); } while (0)
     if (dtype == TEAL_BF16) TEAL_ATT_HD(true, 1024);
     else TEAL_ATT_HD(false, 1024);
@@ -1522,7 +1522,7 @@ static int attention_split_impl(const void* qkv, const float* qkv_slabs, int qkv
     auto* pw = reinterpret_cast<float*>(partials);
     const dim3 grid(n_head * nsplit), block(nt);
     // stride mode (teal_set_phase_stride): the attention launch takes the next region like a GEMV launch does
-    unsigned long long* ph = (g_phase && g_phase_stride) ? g_phase + (size_t)g_phase_seq++ * g_phase_stride : nullptr;
+    unsigned long long* ph = phase_strided_only();
     // grouped-query models at long contexts: one workgroup per (KV head, split) serves all the query heads of the group
     // (the per-query-head kernel is 2-3 us faster below ~2 k positions: scripts/attention_context_sweep.py)
     const int rep = n_head / n_kv_head;
@@ -1629,7 +1629,7 @@ int teal_sample_topk_ws(const void* logits, int vocab, int dtype, int top_k, flo
     auto* lg = reinterpret_cast<const uint16_t*>(logits);
     auto* rs = reinterpret_cast<unsigned long long*>(rng_state);
 #define TEAL_SAMPLE(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len)
-#define TEAL_SAMPLE_W(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len, g_phase_stride ? nullptr : g_phase)
+#define TEAL_SAMPLE_W(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(1), dim3(1024), 0, st, lg, vocab, top_k, inv_temp, rs, token_out, pos_inout, history, history_len, phase_start_only())
     const bool bf = dtype == TEAL_BF16;
     if ((vocab & 7) == 0 && vocab > 8192 && vocab <= kSampMaxGroups * 8192 && top_k > 0 && top_k < vocab && ws_prepared(ws, ws_bytes)) {
         // one workgroup per 8192 logits + the last arriver (sample_topk_multi_kernel)

@@ -76,6 +76,7 @@ struct Params {
     const uint16_t* rope; const int* rope_pos; uint16_t* kc; uint16_t* vc;
     int rope_hd, rope_max_seq;
     int act0;                   // rounded output of segment 0 goes through silu (and is rounded again)
+    int sum32;                  // TEAL_OUT_SLAB_SUM: seg[0].y is fp32 and receives the unrounded slice-order sum (lean kernel only)
     Seg seg[kMaxSeg];
 };
 
@@ -100,13 +101,47 @@ bool attention_device_init();              // teal_attention.hip: per-kernel att
 int fused_gemv_i4(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z, int dtype, void* ws, size_t ws_bytes,
                   int* nslabs_out, hipStream_t st);
 
-// process-global diagnostics / tuning switches (teal_kernels.hip): host-side variables read at launch time
+// Diagnostics / tuning switches.  The PRODUCT library (libteal_hip.so) has none: the values below are compile-time
+// constants, no entry point can change how a launch is configured, and the only host-side state is the per-device
+// properties and the workspace registry (SURVEY 8(b) "Ownership").  libteal_hip_diag.so (the same sources with
+// -DTEAL_DIAGNOSTICS; benchmarks, phase stamps, lean-vs-general and forced-geometry parity tests) turns them into
+// process-global variables behind teal_set_tuning / teal_set_fast / teal_set_wave_local / teal_set_phase_* and keeps
+// teal_last_launch_desc — NOT thread-safe, never loaded by the product path.
+#ifdef TEAL_DIAGNOSTICS
+constexpr bool kDiagnostics = true;
 extern Config g_override;
 extern unsigned long long* g_phase;
 extern size_t g_phase_stride;
 extern int g_phase_seq;
 extern int g_wave_local;
+extern int g_fast;
 extern char g_last_desc[160];  // template instantiation + grid of the most recent GEMV launch (teal_last_launch_desc)
+// stamp buffer of a launch: GEMV launches stamp the start of the buffer or, in stride mode, the next region of it
+inline unsigned long long* phase_next_region() {
+    if (!g_phase) return nullptr;
+    unsigned long long* p = g_phase + (size_t)g_phase_seq * g_phase_stride;
+    if (g_phase_stride) ++g_phase_seq;
+    return p;
+}
+inline unsigned long long* phase_start_only() { return g_phase_stride ? nullptr : g_phase; }              // single-launch probes
+inline unsigned long long* phase_strided_only() { return (g_phase && g_phase_stride) ? phase_next_region() : nullptr; }
+#else
+constexpr bool kDiagnostics = false;
+constexpr Config g_override = {0, 0, 0, 0};
+constexpr int g_wave_local = 1;
+constexpr int g_fast = 1;
+inline unsigned long long* phase_next_region() { return nullptr; }
+inline unsigned long long* phase_start_only() { return nullptr; }
+inline unsigned long long* phase_strided_only() { return nullptr; }
+#endif
+// the description of the launch a call made (kernel instantiation + grid, as rocprofv3 prints it) goes to the CALLER's
+// buffer (teal_gemv_out_t.desc); the diagnostics build also keeps the last one for teal_last_launch_desc
+inline void publish_desc(const char* s, char* dst, int dst_bytes) {
+    if (dst && dst_bytes > 0) snprintf(dst, (size_t)dst_bytes, "%s", s);
+#ifdef TEAL_DIAGNOSTICS
+    snprintf(g_last_desc, sizeof g_last_desc, "%s", s);
+#endif
+}
 
 // ---- caller-owned workspace --------------------------------------------------------------------------------------
 // A workspace prepared by teal_workspace_init() starts with a header the library owns (zeroed once by that call, re-armed

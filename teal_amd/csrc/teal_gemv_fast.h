@@ -30,7 +30,7 @@ namespace teal {
     asm volatile("" ::"s"((a).w0), "s"((a).w1), "s"((a).y), "s"((a).ws), "s"((a).mask_out), "s"((a).resid_out),          \
                  "s"((a).phase), "s"((a).ticket), "s"((a).ld0), "s"((a).ld1), "s"((a).seg_tile1), "s"((a).seg_tile2), "s"((a).tau0),       \
                  "s"((a).tau1), "s"((a).tau2), "s"((a).mask_tau), "s"((a).ws_stride), "s"((a).att_hd), "s"((a).att_ns),  \
-                 "s"((a).cap), "s"((a).w1_tile), "s"((a).scale0), "s"((a).scale1))
+                 "s"((a).cap), "s"((a).w1_tile), "s"((a).scale0), "s"((a).scale1), "s"((a).sum32))
 
 
 // LPR lanes x 16 B = BN columns per tile; KR = register-cached 64-element chunks per wave; U = 16-byte loads a lane has
@@ -103,7 +103,11 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         uint32_t rb[KR];
         f32x4 v0[KR], v1[KR];
-        const uint32_t stride = (uint32_t)(nslabs + 3) & ~3u;
+        // bit 8 of the (preloaded) slab count: ONE planar fp32 vector [Z] — the sum a TEAL_OUT_SLAB_SUM launch left (tensor
+        // parallelism: what the ranks all-reduce) — instead of interleaved slabs [Z][(ns + 3) & ~3]
+        const bool planar1 = (nslabs & 0x100) != 0;
+        const int ns = nslabs & 0xFF;
+        const uint32_t stride = (uint32_t)(ns + 3) & ~3u;
         uint32_t mel[KR];
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
@@ -111,11 +115,14 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
             rb[k] = resid[mel[k]];
             wb[k] = nw[mel[k]];
         }
-        if (nslabs > 0) {
+        if (planar1) {
+#pragma unroll
+            for (int k = 0; k < KR; ++k) v0[k] = f32x4{slabs[mel[k]], 0.0f, 0.0f, 0.0f};
+        } else if (ns > 0) {
 #pragma unroll
             for (int k = 0; k < KR; ++k) v0[k] = *reinterpret_cast<const f32x4*>(slabs + mel[k] * stride);
         }
-        if (nslabs > 4) {
+        if (ns > 4) {
 #pragma unroll
             for (int k = 0; k < KR; ++k) v1[k] = *reinterpret_cast<const f32x4*>(slabs + mel[k] * stride + 4);
         }
@@ -133,18 +140,18 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
         stamp(1);
         // slab order 0, 1, 2, ... (the order of the ordered reduce launch); adding an absent slab as 0.0f is exact
         float ysum[KR];
-        if (nslabs == 4) {
+        if (ns == 4) {
 #pragma unroll
             for (int k = 0; k < KR; ++k) ysum[k] = (((0.0f + v0[k][0]) + v0[k][1]) + v0[k][2]) + v0[k][3];
-        } else if (nslabs > 0) {
+        } else if (ns > 0) {
 #pragma unroll
             for (int k = 0; k < KR; ++k) {
                 float sacc = 0.0f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sacc += (j < nslabs) ? v0[k][j] : 0.0f;
-                if (nslabs > 4) {
+                for (int j = 0; j < 4; ++j) sacc += (j < ns) ? v0[k][j] : 0.0f;
+                if (ns > 4) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) sacc += (4 + j < nslabs) ? v1[k][j] : 0.0f;
+                    for (int j = 0; j < 4; ++j) sacc += (4 + j < ns) ? v1[k][j] : 0.0f;
                 }
                 ysum[k] = sacc;
             }
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
             float r = bits_to_float(rb[k], BF16);
-            if (nslabs > 0) {
+            if (ns > 0) {
                 const float yv = bits_to_float(float_to_bits<BF16>(ysum[k]), BF16);
                 r = bits_to_float(float_to_bits<BF16>(r + yv), BF16);
             }
@@ -504,6 +511,8 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
                 }
             } else if (a.act0 && s == 0) {  // the gate tiles of gate | up: activation applied here (model.py:258)
                 reinterpret_cast<uint16_t*>(a.y)[c] = silu_bits<BF16>(gs);
+            } else if (a.sum32) {           // TEAL_OUT_SLAB_SUM without split-K: the unrounded fp32 sum
+                reinterpret_cast<float*>(a.y)[c] = gs;
             } else {
                 reinterpret_cast<uint16_t*>(a.y)[c] = float_to_bits<BF16>(gs);
             }
@@ -533,7 +542,8 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
                 float sum = 0.0f;
                 for (int sl = 0; sl < split; ++sl)
                     sum += __hip_atomic_load(&a.ws[c * (uint32_t)a.ws_stride + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                reinterpret_cast<uint16_t*>(a.y)[c] = (a.act0 && s == 0) ? silu_bits<BF16>(sum) : float_to_bits<BF16>(sum);
+                if (a.sum32) reinterpret_cast<float*>(a.y)[c] = sum;  // TEAL_OUT_SLAB_SUM: slice-order fp32 sum, rounded by the consumer
+                else reinterpret_cast<uint16_t*>(a.y)[c] = (a.act0 && s == 0) ? silu_bits<BF16>(sum) : float_to_bits<BF16>(sum);
                 if (tid == 0) __hip_atomic_store(&a.ticket[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -555,8 +565,9 @@ __global__ __launch_bounds__(1024) void gemv_fast_kernel(const void* in0, const 
 template <bool BF16, int MODE, bool PAIR, int LPR, int KR, bool EXACT, bool W8 = false>
 hipError_t launch_fast_e(const FastLaunch& f, hipStream_t st) {
     const dim3 grid(f.ntiles, f.split), block(1024);
+#ifdef TEAL_DIAGNOSTICS
     if constexpr (!W8) {
-        if (f.a.phase) {  // stamped instantiations (diagnostics: teal_set_phase_buffer), both activation dtypes
+        if (f.a.phase) {  // stamped instantiations (libteal_hip_diag.so: teal_set_phase_buffer), both activation dtypes
             if constexpr (MODE == 1 && !PAIR) {
                 if (f.a.rope) {  // the stamped form of the RoPE / KV-append epilogue: a rope request never runs unrotated
                     hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, true, 4, false, true>), grid, block, f.lds, st,
@@ -569,6 +580,7 @@ hipError_t launch_fast_e(const FastLaunch& f, hipStream_t st) {
             return hipGetLastError();
         }
     }
+#endif
     if constexpr (MODE == 1 && !PAIR && !W8) {
         if (f.a.rope) {  // fused wqkv projection, split == 1: RoPE + KV-cache append in the epilogue
             hipLaunchKernelGGL((gemv_fast_kernel<BF16, MODE, PAIR, LPR, KR, EXACT, false, 4, W8, true>), grid, block, f.lds, st, f.in0, f.in1,

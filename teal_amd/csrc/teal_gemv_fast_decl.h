@@ -33,6 +33,7 @@ struct FastArgs {
     int rope_hd, rope_dim, rope_kv, rope_max_seq;  // head_dim, n_head * head_dim, n_kv_head * head_dim, cache rows
     int act0;                       // rounded output of threshold segment 0 goes through silu (the gate of gate | up)
     int gate_act;                   // MODE 2: the gate half already holds round(silu(gate))
+    int sum32;                      // TEAL_OUT_SLAB_SUM: y is fp32 [ncols] and receives the unrounded sum over the row slices (slice order)
 };
 
 // Launch description filled by run_gemv when the shape qualifies (teal_kernels.hip: fast_eligible)

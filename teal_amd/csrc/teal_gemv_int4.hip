@@ -624,19 +624,25 @@ int fused_gemv_i4(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z, i
     hipError_t e;
 #define TEAL_I4_LAUNCH(BF, PH) \
     (kind == kI4Share ? launch_i4<BF, kI4Share, PH>(a, in->mode, grid, lds, st) : launch_i4<BF, kI4Group, PH>(a, in->mode, grid, lds, st))
-    if (g_phase && dtype == TEAL_F16) {  // measurement: the stamping instantiation (fp16 only)
-        a.phase = g_phase + (size_t)g_phase_seq * g_phase_stride;
-        if (g_phase_stride) ++g_phase_seq;
+#ifdef TEAL_DIAGNOSTICS
+    if (g_phase && dtype == TEAL_F16) {  // measurement: the stamping instantiation (fp16 only; libteal_hip_diag.so)
+        a.phase = phase_next_region();
         e = TEAL_I4_LAUNCH(false, true);
-    } else if (dtype == TEAL_BF16) {
+    } else
+#endif
+    if (dtype == TEAL_BF16) {
         e = TEAL_I4_LAUNCH(true, false);
     } else {
         e = TEAL_I4_LAUNCH(false, false);
     }
 #undef TEAL_I4_LAUNCH
     if (e != hipSuccess) return TEAL_ERR_LAUNCH;
-    snprintf(g_last_desc, sizeof(g_last_desc), "sparse_gemv_int4_kernel<%s,%d,%d,false> grid (%d,%d) x 1024", dtype == TEAL_BF16 ? "true" : "false",
-             in->mode, kind, ntiles, split);
+    if (out->desc || kDiagnostics) {
+        char d[160];
+        snprintf(d, sizeof d, "sparse_gemv_int4_kernel<%s,%d,%d,false> grid (%d,%d) x 1024", dtype == TEAL_BF16 ? "true" : "false",
+                 in->mode, kind, ntiles, split);
+        publish_desc(d, out->desc, out->desc_bytes);
+    }
     if (nslabs_out) *nslabs_out = split;
     return TEAL_OK;
 }

@@ -125,12 +125,15 @@ __global__ __launch_bounds__(1024) void compact_kernel(const uint16_t* __restric
 // ------------------------------------------------------------------------------------------------
 
 
+#ifdef TEAL_DIAGNOSTICS  // libteal_hip_diag.so only (teal_common.h): the product library has no mutable switches
 Config g_override = {0, 0, 0, 0};
 unsigned long long* g_phase = nullptr;
 size_t g_phase_stride = 0;  // > 0: consecutive GEMV launches stamp consecutive regions of this many uint64
 int g_phase_seq = 0;
 int g_wave_local = 1;
 int g_fast = 1;  // lean kernel (teal_gemv_fast.h) where the shape qualifies
+char g_last_desc[160] = "";  // template instantiation + grid of the most recent GEMV launch (teal_last_launch_desc)
+#endif
 
 // ---- per-device properties (immutable once cached) ---------------------------------------------------------------
 constexpr int kMaxDevices = 64;
@@ -167,8 +170,6 @@ bool ws_prepared(const void* ws, size_t ws_bytes) {
         if (e.ws == ws) return true;
     return false;
 }
-
-char g_last_desc[160] = "";  // template instantiation + grid of the most recent GEMV launch (teal_last_launch_desc)
 
 
 size_t lds_bytes(int Z, int cap, int waves, int lpr, bool pair = false) {
@@ -293,8 +294,10 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
     f.Z = p.Z; f.nslabs = p.in.nslabs; f.eps = p.in.eps;
     switch (mode) {
         case 1: f.in0 = p.in.resid_in; f.in1 = p.in.slabs; f.in2 = p.in.norm_w; f.row_index = p.in.row_index;
-                if (p.in.nslabs > 0 && !p.in.slabs_il) return false;
+                // interleaved slabs, or ONE planar fp32 vector (the hand-over of a TEAL_OUT_SLAB_SUM launch): bit 8 of the count
+                if (p.in.nslabs > 0 && !p.in.slabs_il && p.in.nslabs != 1) return false;
                 if (p.in.nslabs > 8) return false;
+                if (p.in.nslabs == 1 && !p.in.slabs_il) f.nslabs = 1 | 0x100;
                 break;
         case 2: f.in0 = p.x; break;  // gate | up contiguous [2Z]
         case 3: f.in0 = p.x; f.in1 = p.in.masks; break;
@@ -323,6 +326,8 @@ bool fast_eligible(const Params& p, const Config& c, bool to_ws, size_t ws_bytes
     f.a.seg_tile1 = (!p.pair && p.nseg > 1) ? p.seg[1].tile0 : INT_MAX;
     f.a.seg_tile2 = (!p.pair && p.nseg > 2) ? p.seg[2].tile0 : INT_MAX;
     f.a.act0 = p.act0;
+    f.a.sum32 = p.sum32;
+    if (p.sum32 && (to_ws || p.pair || p.nseg != 1 || p.act0 || p.rope)) return false;
     f.a.gate_act = p.in.gate_act;
     f.a.ws_stride = (to_ws || ticketed) ? ((c.split + 3) & ~3) : 0;
     f.a.ticket = ticketed ? p.tickets : nullptr;
@@ -345,7 +350,9 @@ inline hipError_t launch_gemv(const Params& p, int dtype, size_t lds, const Conf
 // Common driver: fills geometry fields of `p` (segments' w/y/tau/ld/col0/ncols are set by the
 // caller), launches the GEMV and, if needed, the ordered slab reduce.
 int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStream_t st,
-             Config* used, bool few_slabs = false, bool interleave = false, bool caller_ws = true, bool* rope_taken = nullptr) {
+             Config* used, bool few_slabs = false, bool interleave = false, bool caller_ws = true, bool* rope_taken = nullptr,
+             char* desc = nullptr, int desc_bytes = 0) {
+    // desc / desc_bytes: the caller's host buffer for the description of the launch this call makes (teal_gemv_out_t.desc)
     // *rope_taken: the launch ran a ROPE instantiation of the lean kernel (TEAL_OUT_QKV_ROPE bookkeeping; per call, no global)
     if (rope_taken) *rope_taken = false;
     // caller_ws: `ws` is the caller's workspace (as opposed to an explicit slab destination, TEAL_OUT_SLABS).  A workspace
@@ -360,7 +367,8 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
     for (int i = 0; i < p.nseg; ++i) total_cols += p.seg[i].ncols;
     Config c = pick_config(p.Z, total_cols, p.nseg);
     bool wide_sliced = false;
-    if (few_slabs && to_ws && (size_t)p.Z * total_cols >= (size_t)8192 * 8192 && !p.w8 && !p.pair && !g_override.split &&
+    // (a TEAL_OUT_SLAB_SUM launch — p.sum32 — is a slab launch whose last slice folds the slabs: same geometry)
+    if (few_slabs && (to_ws || p.sum32) && (size_t)p.Z * total_cols >= (size_t)8192 * 8192 && !p.w8 && !p.pair && !g_override.split &&
         !g_override.lpr) {
         // slab output of a 70B-class matrix (>= 8192 x 8192): 128-column tiles (256-byte row segments) with the kept
         // rows sliced so that tiles x slices ~ the CU count — fewer, longer row requests per CU.  Measured +2-8 % on
@@ -482,8 +490,7 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
     }
     p.to_ws = to_ws ? 1 : 0;
     p.ws = reinterpret_cast<float*>(ws);
-    p.phase = g_phase ? g_phase + (size_t)g_phase_seq * g_phase_stride : nullptr;
-    if (g_phase && g_phase_stride) ++g_phase_seq;
+    p.phase = phase_next_region();  // (nullptr in the product library)
     const size_t lds = lds_bytes(p.Z, p.wl ? p.cap * c.waves : p.cap, c.waves, c.lpr, p.pair != 0);
     if (lds > 64 * 1024) return TEAL_ERR_SHAPE;
     p.ws_il = (interleave && to_ws && c.split <= 8) ? 1 : 0;
@@ -497,24 +504,31 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
         FastLaunch f;
         const bool lean = fast_eligible(p, c, to_ws, ws_bytes, f);
         if (p.rope && !lean) return TEAL_ERR_CONFIG;  // the RoPE epilogue exists in the lean kernel only: never fall through unrotated
+        if (p.sum32 && !lean) return TEAL_ERR_CONFIG; // so does the fp32 slice-sum output (needs a prepared workspace when split-K is used)
         if (lean) {
             if (rope_taken) *rope_taken = f.a.rope != nullptr;
             // (the instantiation as rocprofv3 prints it: BF16, MODE, PAIR, LPR, KR, EXACT, PHASE, U, W8, ROPE)
-            snprintf(g_last_desc, sizeof g_last_desc, "gemv_fast_kernel<%s,%d,%s,%d,%d,%s,%s%s,%s> grid (%d,%d) x 1024",
-                     dtype == TEAL_BF16 ? "true" : "false", f.mode, f.pair ? "true" : "false", f.lpr, f.kr,
-                     (f.mode == 1 && f.Z == 1024 * f.kr) ? "true" : "false", (f.a.phase && !f.w8) ? "true" : "false",
-                     f.w8 ? ",4,true" : ",4,false", f.a.rope ? "true" : "false", f.ntiles, f.split);
+            if (desc || kDiagnostics) {
+                char d[160];
+                snprintf(d, sizeof d, "gemv_fast_kernel<%s,%d,%s,%d,%d,%s,%s%s,%s> grid (%d,%d) x 1024",
+                         dtype == TEAL_BF16 ? "true" : "false", f.mode, f.pair ? "true" : "false", f.lpr, f.kr,
+                         (f.mode == 1 && f.Z == 1024 * f.kr) ? "true" : "false", (f.a.phase && !f.w8) ? "true" : "false",
+                         f.w8 ? ",4,true" : ",4,false", f.a.rope ? "true" : "false", f.ntiles, f.split);
+                publish_desc(d, desc, desc_bytes);
+            }
             const hipError_t e = f.w8 ? (dtype == TEAL_BF16 ? launch_fast_w8_bf16(f, st) : launch_fast_w8_f16(f, st))
                                       : (dtype == TEAL_BF16 ? launch_fast_bf16(f, st) : launch_fast_f16(f, st));
             return e == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
         }
     }
-    {
+    if (desc || kDiagnostics) {
         const int owned = p.krt ? p.krt : (((p.Z + 63) >> 6) + c.waves - 1) / c.waves;
         const int krt = c.waves == 16 ? (owned <= 4 ? 4 : (owned <= 8 ? 8 : 16)) : 16;
-        snprintf(g_last_desc, sizeof g_last_desc, "sparse_gemv_kernel<%d,%d,%d,%s,%d,%d,%s,%s> grid %d x %d", c.lpr, c.waves, c.unroll,
+        char d[160];
+        snprintf(d, sizeof d, "sparse_gemv_kernel<%d,%d,%d,%s,%d,%d,%s,%s> grid %d x %d", c.lpr, c.waves, c.unroll,
                  dtype == TEAL_BF16 ? "true" : "false", p.in.mode, krt, p.pair ? "true" : "false", p.w8 ? "true" : "false",
                  p.ntiles * p.split, c.waves * 64);
+        publish_desc(d, desc, desc_bytes);
     }
     if (launch_gemv(p, dtype, lds, c, st) != hipSuccess) return TEAL_ERR_LAUNCH;
     if (c.split > 1 && !to_ws) {
@@ -605,6 +619,7 @@ int teal_workspace_release(void* ws) {
     return TEAL_ERR_ARG;
 }
 
+#ifdef TEAL_DIAGNOSTICS  // exported by libteal_hip_diag.so only
 int teal_set_tuning(int lanes_per_row, int waves, int split, int unroll) {
     auto in = [](int v, std::initializer_list<int> ok) {
         for (int o : ok) if (v == o) return true;
@@ -640,6 +655,7 @@ int teal_set_phase_stride(size_t u64_per_launch) {
     g_phase_seq = 0;
     return TEAL_OK;
 }
+#endif  // TEAL_DIAGNOSTICS
 
 int teal_get_config(int Z, int N, int nseg, int* out) {
     if (!out || Z <= 0 || N <= 0) return TEAL_ERR_ARG;
@@ -774,7 +790,7 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
     if (!device_ctx()) return TEAL_ERR_NO_DEVICE;
     if (out->act_seg0 && out->mode != TEAL_OUT_ROUNDED) return TEAL_ERR_ARG;
     if (out->weight_bits == 4) {
-        if (out->act_seg0 || in->gate_activated || out->mode == TEAL_OUT_QKV_ROPE) return TEAL_ERR_ARG;  // 16-bit / int8 launches only
+        if (out->act_seg0 || in->gate_activated || out->mode == TEAL_OUT_QKV_ROPE || out->mode == TEAL_OUT_SLAB_SUM) return TEAL_ERR_ARG;  // 16-bit / int8 launches only
         return fused_gemv_i4(in, out, Z, dtype, ws, ws_bytes, nslabs_out, reinterpret_cast<hipStream_t>(stream));
     }
     Params p = {};
@@ -842,15 +858,25 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
         p.pair = 1;
         p.mask_out = reinterpret_cast<unsigned long long*>(out->mask_out);
         p.mask_tau = out->mask_tau;
-        rc = run_gemv(p, dtype, ws, ws_bytes, false, st, &used, false);
+        rc = run_gemv(p, dtype, ws, ws_bytes, false, st, &used, false, false, true, nullptr, out->desc, out->desc_bytes);
     } else if (out->mode == TEAL_OUT_SLABS) {
         if (!out->slabs) return TEAL_ERR_ARG;
         if (ws_prepared(out->slabs, out->slabs_bytes)) return TEAL_ERR_ARG;  // a prepared workspace starts with the library's header
-        rc = run_gemv(p, dtype, out->slabs, out->slabs_bytes, true, st, &used, true, out->slabs_interleaved != 0, false);
+        rc = run_gemv(p, dtype, out->slabs, out->slabs_bytes, true, st, &used, true, out->slabs_interleaved != 0, false, nullptr, out->desc,
+                      out->desc_bytes);
         if (rc == TEAL_OK && out->slabs_interleaved && !p.ws_il) return TEAL_ERR_CONFIG;  // > 8 slices cannot interleave
+    } else if (out->mode == TEAL_OUT_SLAB_SUM) {
+        // one fp32 vector [ncols]: the row slices' partial sums folded in slice order by the last slice of each tile to arrive
+        // (arrival tickets in the caller's prepared workspace), NOT rounded — what tensor-parallel ranks all-reduce
+        if (out->nseg != 1 || !out->slabs || out->slabs_bytes < (size_t)out->ncols[0] * sizeof(float)) return TEAL_ERR_ARG;
+        if (ws_prepared(out->slabs, out->slabs_bytes)) return TEAL_ERR_ARG;
+        p.sum32 = 1;
+        p.seg[0].y = out->slabs;
+        rc = run_gemv(p, dtype, ws, ws_bytes, false, st, &used, true, false, true, nullptr, out->desc, out->desc_bytes);
+        if (rc == TEAL_OK && nslabs_out) { *nslabs_out = 1; return rc; }
     } else if (out->mode == TEAL_OUT_ROUNDED) {
         p.act0 = out->act_seg0 ? 1 : 0;
-        rc = run_gemv(p, dtype, ws, ws_bytes, false, st, &used, false);
+        rc = run_gemv(p, dtype, ws, ws_bytes, false, st, &used, false, false, true, nullptr, out->desc, out->desc_bytes);
     } else if (out->mode == TEAL_OUT_QKV_ROPE) {
         if (out->nseg != 3 || in->mode != TEAL_IN_RESID_NORM || !out->y[0] || !out->rope || !out->rope_pos || !out->k_cache ||
             !out->v_cache || out->rope_max_seq <= 0 || !nslabs_out)
@@ -874,7 +900,7 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
         const bool sliced = (size_t)Z * total_cols >= (size_t)8192 * 8192;
         if (c0.split == 1 && !sliced && g_fast && !g_override.split && !g_override.lpr) {
             bool taken = false;
-            rc = run_gemv(q, dtype, ws, ws_bytes, false, st, &used, false, false, true, &taken);
+            rc = run_gemv(q, dtype, ws, ws_bytes, false, st, &used, false, false, true, &taken, out->desc, out->desc_bytes);
             if (rc != TEAL_OK && rc != TEAL_ERR_CONFIG) return rc;  // TEAL_ERR_CONFIG: not a lean-kernel shape, nothing was launched
             fused = rc == TEAL_OK && taken;
             if (rc == TEAL_OK && !fused) return TEAL_ERR_LAUNCH;    // (unreachable: run_gemv refuses to launch a rope request unrotated)
@@ -882,7 +908,8 @@ int teal_fused_gemv(const teal_gemv_in_t* in, const teal_gemv_out_t* out, int Z,
         if (fused) { *nslabs_out = 0; return TEAL_OK; }
         if (!out->slabs) return TEAL_ERR_ARG;
         if (ws_prepared(out->slabs, out->slabs_bytes)) return TEAL_ERR_ARG;
-        rc = run_gemv(p, dtype, out->slabs, out->slabs_bytes, true, st, &used, true, out->slabs_interleaved != 0, false);
+        rc = run_gemv(p, dtype, out->slabs, out->slabs_bytes, true, st, &used, true, out->slabs_interleaved != 0, false, nullptr, out->desc,
+                      out->desc_bytes);
         if (rc == TEAL_OK && out->slabs_interleaved && !p.ws_il) return TEAL_ERR_CONFIG;
     } else {
         return TEAL_ERR_ARG;

@@ -21,6 +21,7 @@ with the unfused module path to fp16 rounding (tests/test_engine.py).
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -30,7 +31,7 @@ from ..monkeypatch import UP_SHIFT_BYTES, to_column_major
 from .model import Transformer
 
 TEAL_IN_PLAIN, TEAL_IN_RESID_NORM, TEAL_IN_SILU_MUL, TEAL_IN_MASKED, TEAL_IN_ATTN_MERGE = 0, 1, 2, 3, 4
-TEAL_OUT_ROUNDED, TEAL_OUT_SLABS, TEAL_OUT_PAIR_SILU, TEAL_OUT_QKV_ROPE = 0, 1, 2, 3
+TEAL_OUT_ROUNDED, TEAL_OUT_SLABS, TEAL_OUT_PAIR_SILU, TEAL_OUT_QKV_ROPE, TEAL_OUT_SLAB_SUM = 0, 1, 2, 3, 4
 MAX_SLABS = 32
 
 
@@ -50,7 +51,8 @@ class GemvOut(ctypes.Structure):  # teal_gemv_out_t
                 ("slabs_interleaved", ctypes.c_int), ("weight_bits", ctypes.c_int), ("scale", ctypes.c_void_p * 3),
                 ("scale_ld", ctypes.c_int * 3), ("groupsize", ctypes.c_int),
                 ("rope", ctypes.c_void_p), ("rope_pos", ctypes.c_void_p), ("k_cache", ctypes.c_void_p), ("v_cache", ctypes.c_void_p),
-                ("rope_head_dim", ctypes.c_int), ("rope_max_seq", ctypes.c_int), ("act_seg0", ctypes.c_int)]
+                ("rope_head_dim", ctypes.c_int), ("rope_max_seq", ctypes.c_int), ("act_seg0", ctypes.c_int),
+                ("desc", ctypes.c_char_p), ("desc_bytes", ctypes.c_int)]
 
 
 def _out(segs, mode, slabs: Optional[torch.Tensor] = None) -> GemvOut:
@@ -139,7 +141,7 @@ class DecodeEngine:
         return None
 
     def __init__(self, model: Transformer, thresholds: List[Dict[str, float]], pair: Optional[bool] = None,
-                 att_split: int = 0):
+                 att_split: int = 0, reduce_presummed: Optional[bool] = None):
         why = DecodeEngine.supports(model)
         if why is not None:
             raise ValueError(f"DecodeEngine cannot run this model: {why}")
@@ -171,6 +173,16 @@ class DecodeEngine:
         # the block's two partial outputs (wo, down) summed over the ranks: reduce(fp32 slab buffer) in place, None = one rank
         self.reduce = getattr(model, "tp_reduce", None)
         self.tp_world = int(getattr(model, "tp_world", 1))
+        self.gather = getattr(model, "tp_gather", None)  # all-gather of a 1-D fp32 tensor over the ranks (synthetic calibration)
+        # reduce_presummed (TEAL_TP_PRESUM=1): wo / down fold their row slices themselves (TEAL_OUT_SLAB_SUM: arrival tickets, the
+        # last slice of a tile adds the partials in slice order) and hand over ONE fp32 [dim] vector, so the ranks all-reduce
+        # 16-32 KB — the reference's element count (gpt-fast/tp.py:120-121) in fp32 — instead of the [dim][4..8] slab buffer
+        # (64-256 KB); costs the launch its ticket round (+1.2 us measured, profiles/r06_tp_rank_local_launches.txt).  Same
+        # arithmetic on one rank (bit-identical: tests/test_rccl_one_rank.py); across ranks the sum associates (slices, then
+        # ranks) instead of (ranks, then slices).  Off by default: the slab hand-over is the faster launch.
+        if reduce_presummed is None:
+            reduce_presummed = os.environ.get("TEAL_TP_PRESUM", "0") == "1"
+        self.presum = bool(reduce_presummed)
         for layer in model.layers:
             for lin in (layer.attention.wqkv, layer.attention.wo, layer.feed_forward.w1, layer.feed_forward.w3,
                         layer.feed_forward.w2):
@@ -201,6 +213,10 @@ class DecodeEngine:
         self.gate_act = False  # (set by _build: unpaired 16-bit / int8 gate | up stores silu(gate) | up)
         self.s_wo, self.s_down = e(MAX_SLABS, dim, dtype=torch.float32), e(MAX_SLABS, dim, dtype=torch.float32)
         self.s_qkv = e(8, self.nqkv, dtype=torch.float32)  # wqkv split-K slabs, summed by the attention launch
+        if self.presum:
+            if self.int4:
+                raise ValueError("reduce_presummed: the int4 kernel has no TEAL_OUT_SLAB_SUM output")
+            self.sum_wo, self.sum_down = e(dim, dtype=torch.float32), e(dim, dtype=torch.float32)
         self.logits = e(1, 1, cfg.vocab_size)
         self.ws = runtime.new_workspace(max(dim, inter), max(self.nqkv, inter, cfg.vocab_size))  # own header: own tickets
         self.rope = model.freqs_cis.contiguous()
@@ -256,8 +272,19 @@ class DecodeEngine:
         self.stages = []
         for i, layer in enumerate(m.layers):
             at, ff, th = layer.attention, layer.feed_forward, ths[i]
+            # the row-wise projections' hand-over: interleaved fp32 slabs [dim][4 or 8], or (reduce_presummed) ONE fp32 [dim] vector
+            il = 0 if self.presum else 1
+            h_wo, h_down = (self.sum_wo, self.sum_down) if self.presum else (self.s_wo, self.s_down)
+
+            def rowwise_out(lin, tau, dst):
+                if not self.presum:
+                    return _out([seg(lin, 0, dim, tau, None)], TEAL_OUT_SLABS, dst)
+                o = _out([seg(lin, 0, dim, tau, None)], TEAL_OUT_SLAB_SUM)
+                o.slabs, o.slabs_bytes = dst.data_ptr(), dst.numel() * 4
+                return o
+
             k1_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=(m.tok_embeddings.weight.data_ptr() if i == 0 else A.data_ptr()),
-                           slabs=(None if i == 0 else self.s_down.data_ptr()), nslabs=0, slabs_interleaved=1,
+                           slabs=(None if i == 0 else h_down.data_ptr()), nslabs=0, slabs_interleaved=il,
                            norm_weight=layer.attention_norm.weight.data_ptr(), eps=self.eps, resid_out=B.data_ptr())
             es = 2  # bytes per activation / scale element
 
@@ -290,8 +317,8 @@ class DecodeEngine:
                 k3_in = GemvIn(mode=TEAL_IN_MASKED, x=self.y_attn.data_ptr(), masks=self.y_mask.data_ptr())
             else:
                 k3_in = GemvIn(mode=TEAL_IN_PLAIN, x=self.y_attn.data_ptr())
-            k3_out = _out([seg(at.wo, 0, dim, th["o"], None)], TEAL_OUT_SLABS, self.s_wo)
-            k4_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=B.data_ptr(), slabs=self.s_wo.data_ptr(), nslabs=0, slabs_interleaved=1,
+            k3_out = rowwise_out(at.wo, th["o"], h_wo)
+            k4_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=B.data_ptr(), slabs=h_wo.data_ptr(), nslabs=0, slabs_interleaved=il,
                            norm_weight=layer.ffn_norm.weight.data_ptr(), eps=self.eps, resid_out=A.data_ptr())
             k4_out = _out([seg(ff.w1, 0, inter, th["gate"], self.gu.data_ptr()),
                            seg(ff.w3, 0, inter, th["up"], self.gu.data_ptr() + 2 * inter)], TEAL_OUT_ROUNDED)
@@ -308,14 +335,28 @@ class DecodeEngine:
                 self.gate_act = not self.int4 and getattr(self, "use_gate_act", True)  # (use_gate_act = False: tests / A/B)
                 k4_out.act_seg0 = 1 if self.gate_act else 0
                 k5_in = GemvIn(mode=TEAL_IN_SILU_MUL, x=self.gu.data_ptr(), gate_activated=1 if self.gate_act else 0)
-            k5_out = _out([seg(ff.w2, 0, dim, th["down"], None)], TEAL_OUT_SLABS, self.s_down)
+            k5_out = rowwise_out(ff.w2, th["down"], h_down)
             kc, vc = at.kv_cache.k_cache, at.kv_cache.v_cache
             assert kc.is_contiguous() and kc.shape[0] == 1 and kc.shape[2] == self.max_seq
             self.stages.append((k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out, th["o"]))
-        self.head_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=A.data_ptr(), slabs=self.s_down.data_ptr(), nslabs=0, slabs_interleaved=1,
+        self.head_in = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=A.data_ptr(), slabs=(self.sum_down if self.presum else self.s_down).data_ptr(),
+                              nslabs=0, slabs_interleaved=0 if self.presum else 1,
                               norm_weight=m.norm.weight.data_ptr(), eps=self.eps, resid_out=None)
         self.head_out = _out([(m.output.weight.data_ptr(), m.output.weight.stride(1), 0, self.cfg.vocab_size, float("-inf"),
                                self.logits.data_ptr(), m.output.scales.data_ptr() if self.int8 else None)], TEAL_OUT_ROUNDED)
+
+    def describe_launch(self, gin: GemvIn, gout: GemvOut, Z: int) -> str:
+        """Kernel template instantiation and grid of the launch (gin, gout) makes — reported by the call itself through
+        teal_gemv_out_t.desc (per call; the library keeps no "last launch" state).  Launches once, on the current stream."""
+        buf = ctypes.create_string_buffer(160)
+        keep = (gout.desc, gout.desc_bytes)
+        gout.desc, gout.desc_bytes = ctypes.cast(buf, ctypes.c_char_p), 160
+        try:
+            self._stream = runtime.stream_ptr()
+            self._gemv(gin, gout, Z, ctypes.c_int(0))
+        finally:
+            gout.desc, gout.desc_bytes = keep
+        return buf.value.decode()
 
     def _gemv(self, gin: GemvIn, gout: GemvOut, Z: int, nslabs_out=None):
         rc = self.L.teal_fused_gemv(ctypes.byref(gin), ctypes.byref(gout), Z, self.code, self.ws.data_ptr(),
@@ -394,7 +435,7 @@ class DecodeEngine:
         cb("before", "wo", i)
         self._gemv(k3_in, k3_out, self.qdim, self.n_wo)
         if self.reduce is not None:
-            self._reduce_slabs(self.s_wo, self.n_wo.value)
+            self._reduce_slabs("wo")
         cb("after", "wo", i)
         k4_in.nslabs = self.n_wo.value
         cb("before", "gate_up", i)
@@ -403,7 +444,7 @@ class DecodeEngine:
         cb("before", "down", i)
         self._gemv(k5_in, k5_out, self.inter, self.n_down)
         if self.reduce is not None:
-            self._reduce_slabs(self.s_down, self.n_down.value)
+            self._reduce_slabs("down")
         cb("after", "down", i)
 
     def _layer_only(self, i: int, tok_ptr: int, pos_ptr: int, only):
@@ -512,13 +553,38 @@ class DecodeEngine:
         self.pos_buf.copy_(pos0)
         return out
 
-    def _reduce_slabs(self, slabs: torch.Tensor, n: int):
-        """Tensor parallelism: the ONE sum over the ranks per attention and per MLP (gpt-fast/tp.py:120-121, 139-140), taken on
-        the fp32 split-K slabs of the row-wise projection [dim][(n + 3) & ~3] before anything is rounded: the consumer's
-        RESID_NORM producer then computes h = resid + round(sum over slices AND ranks) with ONE rounding, exactly the
-        unsharded step's expression (the reference all-reduces each rank's fp16-rounded output).  Every rank launches the
-        same geometry (a pure function of the local shape), so the buffers line up slab for slab."""
+    def _reduce_slabs(self, which: str):
+        """Tensor parallelism: the ONE sum over the ranks per attention ("wo") and per MLP ("down") (gpt-fast/tp.py:120-121,
+        139-140), taken on the fp32 hand-over of the row-wise projection before anything is rounded: the consumer's RESID_NORM
+        producer then computes h = resid + round(sum over slices AND ranks) with ONE rounding, exactly the unsharded step's
+        expression (the reference all-reduces each rank's fp16-rounded output).  The hand-over is the interleaved slab buffer
+        [dim][(n + 3) & ~3] — every rank launches the same geometry (a pure function of the local shape), so the buffers line up
+        slab for slab — or, with reduce_presummed, the launch's own slice-order sum: one fp32 [dim]."""
+        if self.presum:
+            self.reduce(self.sum_wo if which == "wo" else self.sum_down)
+            return
+        slabs, n = (self.s_wo, self.n_wo.value) if which == "wo" else (self.s_down, self.n_down.value)
         self.reduce(slabs.view(-1)[: self.dim * ((n + 3) & ~3)])
+
+    def reduce_bytes(self) -> Dict[str, int]:
+        """payload of one all-reduce, by projection (after at least one step: the slab counts are the launches' own)"""
+        if self.presum:
+            return {"wo": self.dim * 4, "down": self.dim * 4}
+        return {"wo": self.dim * ((self.n_wo.value + 3) & ~3) * 4, "down": self.dim * ((self.n_down.value + 3) & ~3) * 4}
+
+    @torch.no_grad()
+    def handover_sum(self, which: str) -> torch.Tensor:
+        """fp32 [dim]: what the consumer's RESID_NORM producer adds up from the hand-over of `wo` / `down` as it stands — the
+        slabs in slice order, or the presummed vector (measurements / restatements only)"""
+        if self.presum:
+            return (self.sum_wo if which == "wo" else self.sum_down).clone()
+        slabs, n = (self.s_wo, self.n_wo.value) if which == "wo" else (self.s_down, self.n_down.value)
+        st = (n + 3) & ~3
+        v = slabs.view(-1)[: self.dim * st].view(self.dim, st)
+        t = torch.zeros(self.dim, device=v.device, dtype=torch.float32)
+        for j in range(n):
+            t = t + v[:, j]
+        return t
 
     @torch.no_grad()
     def site_activations(self, idx: torch.Tensor, input_pos: torch.Tensor) -> List[Dict[str, torch.Tensor]]:
@@ -545,14 +611,6 @@ class DecodeEngine:
         A, B = self.resid
         layer = self.model.layers[i]
 
-        def slab_sum(slabs, n, ncols):
-            st = (n + 3) & ~3
-            v = slabs.view(-1)[: ncols * st].view(ncols, st)
-            t = torch.zeros(ncols, device=v.device, dtype=torch.float32)
-            for j in range(n):
-                t = t + v[:, j]
-            return t.to(dt)
-
         def normed(resid, y, w):
             h = (resid + y).to(dt) if y is not None else resid
             hf = h.float()
@@ -562,7 +620,7 @@ class DecodeEngine:
             if i == 0:
                 resid, y = self.model.tok_embeddings.weight[token], None
             else:
-                resid, y = A, slab_sum(self.s_down, self.n_down.value, dim)
+                resid, y = A, self.handover_sum("down").to(dt)
             return normed(resid, y, layer.attention_norm.weight)
         if stage == "wo":
             if self.att_fused_merge:
@@ -573,7 +631,7 @@ class DecodeEngine:
                 return ((o * f[:, :, None]).sum(1) / (l * f).sum(1, keepdim=True)).reshape(-1).to(dt).float().abs()
             return self.y_attn.float().abs().clone()
         if stage == "gate_up":
-            return normed(B, slab_sum(self.s_wo, self.n_wo.value, dim), layer.ffn_norm.weight)
+            return normed(B, self.handover_sum("wo").to(dt), layer.ffn_norm.weight)
         assert stage == "down"
         if self.pair:
             return self.h_mlp.float().abs().clone()
@@ -632,9 +690,17 @@ class DecodeEngine:
 
             self._walk(first_token, pos0, n_steps, n_samples, visit)
             for i in range(len(self.stages)):
+                cat = {site: torch.cat(v) for site, v in pool[i].items()}
+                if self.gather is not None:
+                    # tensor parallelism: the row-wise projections' sites (attention output, silu(gate) * up) are SLICED over the
+                    # ranks; the threshold is a property of the whole site, so every rank takes the quantile of the all-gathered
+                    # samples — the unsharded model's own quantile — and every round already runs with it (the replicated
+                    # sites hold the same samples on every rank: same reduce result, same bits)
+                    for site in ("attn_out", "mlp_mid"):
+                        cat[site] = self.gather(cat[site])
                 for p, site in self.SITE.items():
                     s = float(sparsities[p][i])
-                    ths[i][p] = -1.0 if s <= 0 else float(torch.quantile(torch.cat(pool[i][site]), s))
+                    ths[i][p] = -1.0 if s <= 0 else float(torch.quantile(cat[site], s))
             self._build(ths)
             self._graph = None
         return ths
@@ -698,10 +764,12 @@ class DecodeEngine:
         torch.cuda.current_stream().wait_stream(s)
         self.tok_buf.copy_(state[0]); self.pos_buf.copy_(state[1]); self.rng_state.copy_(state[2])
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for _ in range(int(tokens)):
-                self._self_step(temperature, top_k)
-        self.tok_buf.copy_(state[0]); self.pos_buf.copy_(state[1]); self.rng_state.copy_(state[2])
+        try:
+            with torch.cuda.graph(g):
+                for _ in range(int(tokens)):
+                    self._self_step(temperature, top_k)
+        finally:  # (also when the capture fails — decode_n then decodes a sharded model eagerly from the same state)
+            self.tok_buf.copy_(state[0]); self.pos_buf.copy_(state[1]); self.rng_state.copy_(state[2])
         self._graphs[key] = g
         self._graph, self._graph_key = g, key
         return g
@@ -730,8 +798,22 @@ class DecodeEngine:
             self.begin_sequence()
         if use_graph and self.reduce is not None and not getattr(self.reduce, "capturable", False):
             use_graph = False  # host-staged all-reduce (gloo): the step cannot live in a hipGraph
+        if use_graph and getattr(self, "tp_capture_error", None):
+            use_graph = False  # an earlier capture of this sharded step failed: stay eager
+        g = None
         if use_graph:
-            g = self.capture_loop(temperature, top_k)
+            try:
+                g = self.capture_loop(temperature, top_k)
+            except Exception as e:  # noqa: BLE001
+                # Under tensor parallelism the step holds two all-reduces per layer (RCCL, captured as graph nodes).  If this stack
+                # cannot capture them, degrade to eager decode and say why instead of aborting the run; an unsharded step holds
+                # only this library's launches — a capture failure there is a bug and propagates.
+                if self.reduce is None:
+                    raise
+                self.tp_capture_error = f"{type(e).__name__}: {e}"
+                print(f"teal_amd: hipGraph capture of the tensor-parallel decode step failed ({self.tp_capture_error}); decoding eagerly")
+                torch.cuda.synchronize()
+        if g is not None:
             for _ in range(n):
                 g.replay()
         else:

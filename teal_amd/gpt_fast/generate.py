@@ -22,6 +22,7 @@ Same flags (`--hist_path`, `--sparsity`, `--checkpoint_path`, `--compile`, `--nu
 from __future__ import annotations
 
 import argparse
+import collections
 import contextlib
 import itertools
 import json
@@ -338,12 +339,18 @@ class GraphedPrefill:
     graph; the model's KV caches must not be re-allocated between capture and replay (setup_caches keeps them
     when the sizes are unchanged; a new cache object gets a new graph)."""
 
+    MAX_GRAPHS = 4  # distinct (prompt length, buffers) keys kept; each graph owns a private memory pool (--interactive with
+                    # varying prompt lengths would otherwise grow one per new length forever): least recently used goes first
+
     def __init__(self, model: Transformer):
         self.model = model
-        self.graphs = {}
+        self.graphs = collections.OrderedDict()
+        self.eager_reason = None  # set when a capture failed under tensor parallelism: the pass then runs op by op
 
     def __call__(self, prompt: torch.Tensor) -> torch.Tensor:
         T = prompt.numel()
+        if self.eager_reason is not None:
+            return self.model(prompt.view(1, -1), torch.arange(0, T, device=prompt.device))
         # everything the captured launches hold raw pointers to: a re-laid-out weight (DecodeEngine / monkeypatch
         # to_column_major replace the storage) or a re-allocated KV cache forces a new capture
         key = (T, self.model.max_seq_length, self.model.output.weight.data_ptr(), self.model.tok_embeddings.weight.data_ptr()) + tuple(
@@ -362,9 +369,24 @@ class GraphedPrefill:
                 self.model(toks, pos)  # warm-up outside capture (allocator pools, GEMM heuristics)
             torch.cuda.current_stream().wait_stream(s)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                logits = self.model(toks, pos)
+            try:
+                with torch.cuda.graph(g):
+                    logits = self.model(toks, pos)
+            except Exception as e:  # noqa: BLE001
+                # a sharded model's pass holds one all-reduce per attention and per MLP (tp._reduce_hook): if the collective
+                # cannot be captured on this stack, run the pass op by op instead of aborting the run (no silent change for an
+                # unsharded model: there a capture failure is a bug and propagates)
+                if int(getattr(self.model, "tp_world", 1)) < 2:
+                    raise
+                self.eager_reason = f"{type(e).__name__}: {e}"
+                print(f"teal_amd: hipGraph capture of the tensor-parallel prompt pass failed ({self.eager_reason}); running it eagerly")
+                torch.cuda.synchronize()
+                return self.model(prompt.view(1, -1), torch.arange(0, T, device=dev))
             self.graphs[key] = (g, toks, pos, logits)  # every tensor the graph reads or writes stays alive
+            while len(self.graphs) > self.MAX_GRAPHS:
+                torch.cuda.synchronize()  # the evicted graph's pool goes back to the allocator: nothing of it may be in flight
+                self.graphs.popitem(last=False)
+        self.graphs.move_to_end(key)
         g, toks, _pos, logits = self.graphs[key]
         toks.copy_(prompt.view(1, -1))
         g.replay()
@@ -497,7 +519,9 @@ def main(args) -> Dict:
     torch.manual_seed(1234)
     model_size = _get_model_size(model)
     # a hipGraph holds the step only if the ranks' all-reduce can be captured (RCCL); a host-staged gloo reduce decodes eagerly
-    use_graph = args.compile and (tp_rank is None or bool(getattr(getattr(model, "tp_reduce", None), "capturable", False)))
+    # (TEAL_TP_GRAPH=0 keeps a sharded model's decode eager even over RCCL; a capture that fails falls back by itself)
+    use_graph = args.compile and (tp_rank is None or (bool(getattr(getattr(model, "tp_reduce", None), "capturable", False))
+                                                      and os.environ.get("TEAL_TP_GRAPH", "1") != "0"))
     decoder = GraphedDecoder(model, use_graph, args.temperature, args.top_k)
     use_engine = args.engine or (args.compile and thresholds is not None and not getattr(args, "no_engine", False))
     if use_engine and not args.engine:

@@ -20,9 +20,12 @@ and calls `model.tp_reduce` on the fp32 split-K slabs of `wo` and `down` (the ro
 consumer's RESID_NORM producer rounds the sum over slices AND ranks once — the unsharded step's own expression.  The reference
 all-reduces each rank's fp16-rounded output (`funcol.all_reduce(output, "sum")`); the module path here (prefill) does the same.
 
-Exercised on CPU with gloo at world_size 2 (tests/test_tp.py: partition math, module path) and on ONE GPU shared by two
+Exercised on CPU with gloo at world_size 2 (tests/test_tp.py: partition math, module path), on ONE GPU shared by two
 processes (tests/test_tp_gpu.py: the fused engine with a host-staged gloo all-reduce against the unsharded engine, and every
-rank's launches at 7B / 8B / 70B rank-local widths against the oracle).  NOT timed on a multi-GPU node (the lease is one GPU).
+rank's launches at 7B / 8B / 70B rank-local widths against the oracle), and — the RCCL calls themselves — with a ONE-rank
+"nccl" group on the leased GPU (tests/test_rccl_one_rank.py: the all-reduce captured as a node of the engine's hipGraph,
+bit-identical to the engine without a reduce; the presummed fp32 [dim] hand-over; the device branches of sync_thresholds and
+make_gather).  NOT timed on a multi-GPU node (the lease is one GPU).
 
 Entry points mirror the reference's: `maybe_init_dist()`, `apply_tp(model)`.
 """
@@ -96,12 +99,32 @@ def make_reduce(group=None):
     return reduce
 
 
-def sync_thresholds(ths, model, group=None):
-    """Synthetic calibration under TP: thresholds are properties of the activation SITES, not of a rank — the row-wise
-    projections' sites (attention output, silu(gate) * up) are sliced over the ranks, so a quantile taken on a rank's slice
-    is averaged over the ranks; every rank then masks with the same tau (the rank-local slice of ONE global mask).
-    Only for a model `apply_tp` sharded: independent replicas under one process group (bench.py --gpus N) keep their own."""
-    if int(getattr(model, "tp_world", 1)) < 2 or not dist.is_initialized() or dist.get_world_size(group) < 2:
+def make_gather(group=None):
+    """all-gather of a 1-D tensor over the ranks, concatenated in rank order (equal lengths on every rank).  The synthetic
+    calibration pools |activation| samples of the SLICED sites with it, so that every rank takes the quantile of the whole
+    site (engine.calibrate_on_decode).  RCCL gathers device tensors; gloo is staged through the host."""
+    nccl = dist.get_backend(group) == "nccl"
+
+    def gather(t: torch.Tensor) -> torch.Tensor:
+        world = dist.get_world_size(group)
+        src = t.contiguous() if (nccl or not t.is_cuda) else t.detach().cpu().contiguous()
+        parts = [torch.empty_like(src) for _ in range(world)]
+        dist.all_gather(parts, src, group=group)
+        return torch.cat(parts).to(t.device)
+    return gather
+
+
+def sync_thresholds(ths, model, group=None, force: bool = False):
+    """Synthetic calibration under TP: thresholds are properties of the activation SITES, not of a rank.  The decode-path
+    calibration already takes every sliced site's quantile on the all-gathered samples (engine.calibrate_on_decode through
+    model.tp_gather), so the ranks agree before they get here; the prefill-based first guess (generate.calibrate_thresholds)
+    sees a rank's slice of the row-wise projections' sites, and this mean over the ranks makes every rank start from the same
+    tau (the rank-local slice of ONE global mask).  Equal inputs come back unchanged (the mean of equal doubles is exact).
+    Only for a model `apply_tp` sharded: independent replicas under one process group (bench.py --gpus N) keep their own;
+    `force` runs the collective whatever the world size (the one-rank RCCL test of the device branch)."""
+    if not dist.is_initialized():
+        return ths
+    if not force and (int(getattr(model, "tp_world", 1)) < 2 or dist.get_world_size(group) < 2):
         return ths
     keys = sorted(ths[0].keys())
     t = torch.tensor([[float(th[k]) for k in keys] for th in ths], dtype=torch.float64)
@@ -222,6 +245,7 @@ def apply_tp(model: Transformer, rank: Optional[int] = None, world: Optional[int
     model.tp_world, model.tp_rank = world, rank
     # (no process group, e.g. a single process checking a rank's shard: the sum over the ranks is the caller's business)
     model.tp_reduce = make_reduce(group) if dist.is_initialized() else None
+    model.tp_gather = make_gather(group) if dist.is_initialized() else None
 
 
 def collectives_per_token(model: Transformer, bytes_per_elem: int = 2) -> dict:

@@ -98,6 +98,14 @@ def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     return ws
 
 
+def drop_workspaces() -> None:
+    """Forget the cached per-stream workspaces (their finalizers release the registrations once the device has drained):
+    _lib.diagnostics() switches the library every later launch goes through, and a workspace is prepared per library."""
+    if _workspaces or _retired:
+        torch.cuda.synchronize()
+    _workspaces.clear()
+
+
 def reserve_workspace(Z: int, N: int, device=None) -> torch.Tensor:
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     return workspace(device, int(_lib.load().teal_workspace_bytes(int(Z), int(N))))

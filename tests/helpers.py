@@ -42,3 +42,39 @@ def bits_from_torch(t):
 def colmajor_weight(wT_bits, Z, N, dtype, device):
     """torch weight of shape [N, Z] with strides (1, N) whose memory image is wT [Z][N]."""
     return torch_from_bits(wT_bits, dtype, device).view(Z, N).T
+
+
+# ---- which build of the library a GPU test launches through ---------------------------------------------------------------
+# libteal_hip.so (the product) has no switches; forcing the general kernel, a launch geometry or the workgroup-wide list, and
+# reading teal_last_launch_desc, are features of libteal_hip_diag.so (same sources, -DTEAL_DIAGNOSTICS).  Tests run the
+# production configuration through the PRODUCT build and everything else through the diagnostics build.
+import contextlib  # noqa: E402
+import functools  # noqa: E402
+
+
+@contextlib.contextmanager
+def lib_for(fast=1, wave_local=1, tuning=None, desc=False):
+    """`with lib_for(fast) as L:` — the product library for the production configuration (lean kernel where the shape
+    qualifies, automatic geometry, wave-local compaction, no launch description asked for); otherwise the diagnostics build
+    with the switches set.  Everything CONSTRUCTED inside the block (engines, workspaces, op calls) launches through L."""
+    from teal_amd import _lib
+    if fast == 1 and wave_local == 1 and tuning is None and not desc:
+        yield _lib.load()
+        return
+    with _lib.diagnostics() as D:
+        D.teal_set_fast(int(fast))
+        D.teal_set_wave_local(int(wave_local))
+        if tuning is not None:
+            assert D.teal_set_tuning(*tuning) == 0
+        yield D
+
+
+def with_diagnostics(fn):
+    """decorator: the whole test runs through libteal_hip_diag.so (`_lib.load()` returns it inside); the switches are reset and
+    the product library is back afterwards"""
+    @functools.wraps(fn)
+    def wrapper(*a, **k):
+        from teal_amd import _lib
+        with _lib.diagnostics():
+            return fn(*a, **k)
+    return wrapper

@@ -62,3 +62,39 @@ def test_floor_model_recovers_fixed_cost_and_stream_rate():
     assert abs(m["layer_ratio"]["measured"] - d["layer"] / s["layer"]) < 1e-3
     assert abs(m["layer_ratio"]["model (fixed + attention + streaming)"] - m["layer_ratio"]["measured"]) < 2e-3
     assert abs(m["layer_ratio"]["if the fixed per-launch cost and the attention launch were free"] - 2.0) < 1e-2
+
+
+def test_forced_one_rank_group_takes_the_distributed_branch():
+    """TEAL_BENCH_FORCE_DIST makes a single process take bench.py's N > 1 branch (process group, barrier, max over ranks of the
+    timing): here with gloo on CPU; tests/test_rccl_one_rank.py does the same with RCCL on the GPU."""
+    code = ("import os, sys, time, json; sys.path.insert(0, %r); import bench\n"
+            "rank, world, _ = bench.dist_setup(1)\n"
+            "import torch.distributed as dist\n"
+            "assert dist.is_initialized() and dist.get_world_size() == 1 and bench._dist_on()\n"
+            "t = bench.timed_decode(lambda: time.sleep(0.002), steps=10, warmup=1, world=world)\n"
+            "print(json.dumps({'t': t, 'value': bench.aggregate_tokens_per_sec(world, 10, t)}))\n"
+            "dist.destroy_process_group()\n" % ROOT)
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", TEAL_BENCH_FORCE_DIST="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert 0.019 < r["t"] < 0.2 and abs(r["value"] - 10 / r["t"]) < 1e-6
+
+
+def test_roofline_object_follows_survey_8d_to_the_letter():
+    """bench.gateup_launch_bytes / roofline_fields: algorithmic bytes of the dominant launch = kept rows of both matrices + Z*2 +
+    N_out*2 — nothing of what the fused producer reads — and frac = algorithmic / us / 8e6, on a made-up launch."""
+    import bench
+    Z, N = 4096, 11008
+    b = bench.gateup_launch_bytes(2036, 2040, Z, N, nslabs=4)
+    assert b["algorithmic"] == (2036 + 2040) * N * 2 + Z * 2 + 2 * N * 2
+    assert b["producer"] == Z * 2 + 4 * Z * 4 + Z * 2
+    assert abs(b["kept_fraction"] - (2036 + 2040) / (2 * Z)) < 1e-12
+    p = bench.gateup_launch_bytes(2036, 2040, Z, N, nslabs=4, pair=True)
+    assert p["algorithmic"] == (2036 + 2040) * N * 2 + Z * 2 + N * 2 and p["producer"] == b["producer"] + N // 8
+    r = bench.roofline_fields(b["algorithmic"], 18.29)
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert abs(r["frac"] - b["algorithmic"] / 18.29 / 8e6) < 1e-9 and abs(r["achieved"] - r["frac"] * 8000.0) < 1e-6
+    assert abs(r["frac"] - 0.6135) < 2e-3  # the round-5 launch: 89.8 MB in 18.29 us

@@ -14,13 +14,14 @@ fraction that no activation sits next to, and checks what the launch produced:
 Reference semantics: kernels/sparse_gemv.py:75-83,167-181 (keep rule, masked GEMV), gpt-fast/model.py:158-161,258-259,
 289-291 (residual adds, silu * up, RMSNorm).  Covers the lean kernel (teal_gemv_fast.h) and, with it switched off, the
 general kernel — including the 128-column sliced geometry 70B-class slab launches use."""
+import contextlib
 import ctypes
 
 import numpy as np
 import pytest
 import torch
 
-from helpers import bits_from_torch, tolerance
+from helpers import bits_from_torch, lib_for, tolerance
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -120,12 +121,10 @@ def _silu_mul_variants(O, gu_bits, inter, dtype):
 @pytest.mark.parametrize("fast", [1, 0])
 @pytest.mark.parametrize("name,tdt,sparsity,n_layer,target,pair", CASES)
 def test_engine_launches_vs_oracle_under_sparsity(oracle, name, tdt, sparsity, n_layer, target, pair, fast):
-    from teal_amd import _lib
     from teal_amd.gpt_fast import generate as G
     from teal_amd.gpt_fast.engine import DecodeEngine
     O = oracle
     dtype = 0 if tdt == torch.float16 else 1
-    L = _lib.load()
     if n_layer > 2 and fast == 0:
         pytest.skip("full depth runs with the production (lean) kernel; the general kernel is covered at 2 layers")
     model = G.build_synthetic_model(name, DEV, tdt, seed=11, n_layer=n_layer)
@@ -144,8 +143,9 @@ def test_engine_launches_vs_oracle_under_sparsity(oracle, name, tdt, sparsity, n
     ths = G.apply_sparsity(model, sparsity=sparsity, hist_path=None, greedy_lookup=None, synthetic=True)
     V = cfg.vocab_size
     prompt = torch.randint(0, V, (6,), device=DEV, dtype=torch.int, generator=torch.Generator(device=DEV).manual_seed(2))
+    stack = contextlib.ExitStack()
+    stack.enter_context(lib_for(fast))  # fast = 1: the PRODUCT library; fast = 0: the general kernel, forced in the diagnostics build
     try:
-        L.teal_set_fast(fast)
         with torch.no_grad():
             model.max_seq_length = -1
             model.setup_caches(1, 32)
@@ -310,7 +310,7 @@ def test_engine_launches_vs_oracle_under_sparsity(oracle, name, tdt, sparsity, n
         assert W_head is None or seen.get("head"), "the lm_head launch was not checked"
         assert abs(seen["qkv_kept"] - (1 - sparsity)) < 0.03 and 0.2 < seen["down_kept"] < 0.8
     finally:
-        L.teal_set_fast(1)
+        stack.close()
         del model
         torch.cuda.empty_cache()
 
@@ -319,15 +319,14 @@ def test_engine_launches_vs_oracle_under_sparsity(oracle, name, tdt, sparsity, n
 def test_engine_step_bit_reproducible_at_real_width(fast):
     """the same decode step, replayed 60 times from the same state at Llama-2-7B widths under 50 % sparsity, writes the
     same bits into every hand-over buffer and the logits (no atomics on data; the split-K tickets only decide WHO sums)."""
-    from teal_amd import _lib
     from teal_amd.gpt_fast import generate as G
     from teal_amd.gpt_fast.engine import DecodeEngine
-    L = _lib.load()
     model = G.build_synthetic_model("7B", DEV, torch.float16, seed=13, n_layer=2)
     ths = G.apply_sparsity(model, sparsity=0.5, hist_path=None, greedy_lookup=None, synthetic=True, decode_calibration=False)
     prompt = torch.randint(0, model.config.vocab_size, (6,), device=DEV, dtype=torch.int, generator=torch.Generator(device=DEV).manual_seed(4))
+    stack = contextlib.ExitStack()
+    stack.enter_context(lib_for(fast))
     try:
-        L.teal_set_fast(fast)
         with torch.no_grad():
             model.max_seq_length = -1
             model.setup_caches(1, 32)
@@ -344,6 +343,6 @@ def test_engine_step_bit_reproducible_at_real_width(fast):
                 for name, a, b in zip(("s_qkv", "q (rotated)", "att_ws", "s_wo", "h_mlp", "h_mask", "s_down", "resid A", "resid B", "logits"), ref, cur):
                     assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), (it, name)
     finally:
-        L.teal_set_fast(1)
+        stack.close()
         del model
         torch.cuda.empty_cache()

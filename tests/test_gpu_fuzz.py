@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import bits_from_torch, colmajor_weight, tolerance, torch_from_bits
+from helpers import bits_from_torch, colmajor_weight, lib_for, tolerance, torch_from_bits
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -34,15 +34,15 @@ def _cases(n, seed):
 
 @pytest.mark.parametrize("case", _cases(48, 20260927), ids=lambda c: f"{c[0]}-Z{c[1]}-N{c[2]}-d{c[3]}-kv{c[5]}-wl{c[6]}-{'i8' if c[7] else 'w16'}")
 def test_random_gemv_cases_vs_truth(oracle, case):
-    from teal_amd import _lib
+    import contextlib
     i, Z, N, dtype, taus, kv, wl, int8, padded = case
-    L = _lib.load()
     xb = oracle.hash_uniform(Z, 1000 + i, 4.0, dtype)          # U(-2, 2)
     x = torch_from_bits(xb, dtype, DEV).view(1, 1, Z)
     tq, tk, tv = taus if kv else (taus[0],) * 3
     N_q = N - 2 * kv
     to_tau = lambda t: t if t >= 0 else float("-inf")          # noqa: E731
-    L.teal_set_wave_local(wl if wl < 2 else 1)
+    stack = contextlib.ExitStack()
+    stack.enter_context(lib_for(wave_local=(wl if wl < 2 else 1)))  # workgroup-wide list: a switch of the diagnostics build
     try:
         if int8:
             u = oracle.from_bits(oracle.hash_uniform_c(N * Z, 2000 + i, 2.0, 0), 0).reshape(N, Z)
@@ -71,4 +71,4 @@ def test_random_gemv_cases_vs_truth(oracle, case):
             want = oracle.compact(xb, tq, dtype)
             assert n == len(want) and np.array_equal(idx.cpu().numpy(), want)
     finally:
-        L.teal_set_wave_local(1)
+        stack.close()

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLDEN, bits_from_torch, tolerance, torch_from_bits
+from helpers import GOLDEN, bits_from_torch, tolerance, torch_from_bits, with_diagnostics
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -56,6 +56,7 @@ def test_fixture_reference_module_outputs(oracle, tag, dtype):
                                            (4096, 14336, 1, 0.4), (8192, 1024, 0, 0.9), (1000, 1000, 0, 0.5),
                                            (4096, 32000, 0, -1.0)])
 @pytest.mark.parametrize("fast", [1, 0])
+@with_diagnostics  # (forces the general kernel and reads the launch description: diagnostics build)
 def test_int8_gemv_vs_truth(oracle, Z, N, dtype, tau, fast):
     """fast = 1: the lean kernel's int8 instantiations where the shape qualifies (whole 128-column tiles, whole chunks);
     fast = 0: the general kernel everywhere.  Same lane <-> row mapping and arithmetic order: identical bits."""
@@ -99,6 +100,7 @@ def _int8_gemv_vs_truth(oracle, Z, N, dtype, tau, L, fast):
         _INT8_SEEN[key] = y.view(torch.int16).cpu()
 
 
+@with_diagnostics
 def test_int8_qkv_three_thresholds_and_geometries(oracle):
     from teal_amd import _lib
     L = _lib.load()
@@ -187,6 +189,7 @@ def test_int8_engine_matches_int8_module_path(dtype, sparsity):
 
 
 @pytest.mark.parametrize("name,tdt,sparsity", [("7B", torch.float16, 0.5), ("llama-3-8b", torch.bfloat16, 0.4)])
+@with_diagnostics
 def test_int8_engine_runs_lean_kernel_and_equals_general_at_real_width(name, tdt, sparsity):
     """The fused int8 engine at real widths under sparsity: every GEMV launch of a decode step is a lean-kernel int8
     instantiation (RMSNorm / attention-merge / silu*up producers, 128-column tiles; qkv and down row-sliced into slabs), and

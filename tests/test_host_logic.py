@@ -212,24 +212,41 @@ def test_monkeypatch_layer_installs_reference_attribute_bundle():
 
 
 def test_c_abi_library_exports_every_declared_symbol():
+    """include/teal_hip.h declares the product ABI and, under #ifdef TEAL_DIAGNOSTICS, the process-global tuning / phase-stamp
+    switches.  libteal_hip.so (what the product path loads) exports every product symbol and NONE of the switches — no entry point
+    changes how a later call behaves (SURVEY 8(b) "Ownership") — and libteal_hip_diag.so, the same sources with
+    -DTEAL_DIAGNOSTICS, exports both sets."""
+    import subprocess
     from teal_amd import _lib
     _lib.build()
     header = open(os.path.join(ROOT, "include", "teal_hip.h")).read()
-    declared = set(re.findall(r"\b(teal_[a-z_0-9]+)\s*\(", header))
+    a, b = header.index("#ifdef TEAL_DIAGNOSTICS"), header.index("#endif /* TEAL_DIAGNOSTICS */")
+    declared_diag = set(re.findall(r"\b(teal_[a-z_0-9]+)\s*\(", header[a:b]))
+    declared = set(re.findall(r"\b(teal_[a-z_0-9]+)\s*\(", header[:a] + header[b:]))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert declared_diag == set(_lib.DIAG_EXPORTS), declared_diag ^ set(_lib.DIAG_EXPORTS)
+
+    def dynamic_symbols(path):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+        return {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("teal_")}
+
+    assert dynamic_symbols(_lib.LIB_PATH) == declared                       # nothing undeclared, no switch, no "last launch" global
+    assert dynamic_symbols(_lib.DIAG_LIB_PATH) == declared | declared_diag
     L = ctypes.CDLL(_lib.LIB_PATH)
-    for name in declared:
-        assert hasattr(L, name), f"{name} declared in teal_hip.h but not exported"
     L.teal_strerror.restype = ctypes.c_char_p
     L.teal_strerror.argtypes = [ctypes.c_int]
     assert L.teal_version() >= 100
     assert L.teal_strerror(0) == b"ok" and b"workspace" in L.teal_strerror(-5)
     L.teal_workspace_bytes.restype = ctypes.c_size_t
     assert L.teal_workspace_bytes(4096, 4096) >= 4096 * 4
-    assert L.teal_set_tuning(7, 0, 0, 0) == -8 and L.teal_set_tuning(0, 0, 0, 0) == 0
-    # the loader declares signatures for all of them
+    D = ctypes.CDLL(_lib.DIAG_LIB_PATH)
+    assert D.teal_set_tuning(7, 0, 0, 0) == -8 and D.teal_set_tuning(0, 0, 0, 0) == 0
+    # the loader declares signatures for all of them; load() is the product library unless the session asked for the other one
     lib = _lib.load()
     assert all(hasattr(lib, n) for n in _lib.EXPORTS)
+    if os.environ.get("TEAL_LIB_FLAVOR", "") != "diag":
+        assert not lib.teal_is_diagnostics_build and not any(hasattr(lib, n) for n in _lib.DIAG_EXPORTS)
+    assert all(hasattr(_lib.load_diag(), n) for n in _lib.EXPORTS + _lib.DIAG_EXPORTS)
 
 
 def test_oracle_is_not_reachable_from_the_product_package():

@@ -23,7 +23,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import bits_from_torch, tolerance, torch_from_bits
+from helpers import bits_from_torch, lib_for, tolerance, torch_from_bits
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -61,6 +61,8 @@ def _slabs_launch(L, x, W, tau, code, ws):
     slabs = torch.zeros(8, N, dtype=torch.float32, device=DEV)
     gin = GemvIn(mode=TEAL_IN_PLAIN, x=x.data_ptr())
     gout = _out([(W.data_ptr(), W.stride(1), 0, N, float(tau), None)], TEAL_OUT_SLABS, slabs)
+    dbuf = ctypes.create_string_buffer(160)  # the launch describes itself (teal_gemv_out_t.desc: per call, no library state)
+    gout.desc, gout.desc_bytes = ctypes.cast(dbuf, ctypes.c_char_p), 160
     n = ctypes.c_int(0)
     _lib.check(L.teal_fused_gemv(ctypes.byref(gin), ctypes.byref(gout), Z, code, ws.data_ptr(), ws.numel() * 4, ctypes.byref(n),
                                  runtime.stream_ptr()), "teal_fused_gemv")
@@ -69,7 +71,7 @@ def _slabs_launch(L, x, W, tau, code, ws):
     acc = torch.zeros(N, dtype=torch.float32, device=DEV)
     for j in range(n.value):
         acc = acc + v[:, j]
-    return acc, n.value, L.teal_last_launch_desc().decode()
+    return acc, n.value, dbuf.value.decode()
 
 
 # (name, dtype code, world, dim, n_head, n_kv_head, head_dim, intermediate)
@@ -117,32 +119,28 @@ def test_rank_local_launches_vs_oracle(oracle, name, dtype, world, dim, n_head, 
     for r in range(world):
         cols = np.concatenate([np.arange(lo, hi) for lo, hi in tp.shard_features(nqkv, r, world, [q, kv, kv])])
         y_loc = K.qkv_gemv(x, _image(wq, dim, nqkv, dtype, cols=cols), t3[0], t3[1], t3[2], 0, kv // world).view(-1)
-        geom.setdefault("qkv", L.teal_last_launch_desc().decode())
+        geom.setdefault("qkv", "%d lanes per row segment x %d row slice(s)" % local_geometry(len(cols), 3))
         ci = torch.from_numpy(cols).to(DEV)
         same_columns(y_loc, y_full[ci], ("qkv", r))
         # the unsharded launch run with the rank-local launch's row slicing: a column's sum does not depend on which other
         # columns the image holds -> BIT-identical
+        # (the rank-local launches run through the PRODUCT library; forcing its geometry onto the unsharded launch is a switch of
+        #  the diagnostics build — same kernels, same bits)
         lpr, split = local_geometry(len(cols), 3)
-        try:
-            assert L.teal_set_tuning(lpr, 0, split, 0) == 0
+        with lib_for(tuning=(lpr, 0, split, 0)):
             y_same = K.qkv_gemv(x, _image(wq, dim, nqkv, dtype), t3[0], t3[1], t3[2], 0, kv).view(-1)
-        finally:
-            L.teal_set_tuning(0, 0, 0, 0)
         assert torch.equal(y_loc.view(torch.int16), y_same[ci].view(torch.int16)), (name, "qkv", r, lpr, split)
     del wq
     for nm, seed, tau in (("gate", 103, t3[0]), ("up", 104, t3[1])):
         wb = O.hash_uniform_c(dim * inter, seed, 0.05, dtype)
         y_full = K.splitk_sparse_gemv(x, _image(wb, dim, inter, dtype), tau, 0).view(-1)
         lpr, split = local_geometry(inter // world, 1)
-        try:
-            assert L.teal_set_tuning(lpr, 0, split, 0) == 0
+        with lib_for(tuning=(lpr, 0, split, 0)):
             y_same = K.splitk_sparse_gemv(x, _image(wb, dim, inter, dtype), tau, 0).view(-1)
-        finally:
-            L.teal_set_tuning(0, 0, 0, 0)
         for r in (range(world) if world <= 2 else (0, world // 2, world - 1)):
             lo, hi = tp.shard_range(inter, r, world)
             y_loc = K.splitk_sparse_gemv(x, _image(wb, dim, inter, dtype, cols=np.arange(lo, hi)), tau, 0).view(-1)
-            geom.setdefault(nm, L.teal_last_launch_desc().decode())
+            geom.setdefault(nm, "%d lanes per row segment x %d row slice(s)" % (lpr, split))
             same_columns(y_loc, y_full[lo:hi], (nm, r))
             assert torch.equal(y_loc.view(torch.int16), y_same[lo:hi].view(torch.int16)), (name, nm, r, lpr, split)
         del wb
@@ -208,3 +206,94 @@ def test_generate_main_under_tp():
                       "--num_samples", "2", "--max_new_tokens", "24"])
     assert "Average tokens/sec" in out and out.count("Average tokens/sec") == 1, out[-1500:]
     assert "fused engine not used" not in out
+
+
+# (what, dtype code, Z = the row-wise projection's input rows on this rank, N = dim)
+SUM_SHAPES = [("7B wo", 0, 4096, 4096), ("7B down", 0, 11008, 4096), ("7B / 2 wo", 0, 2048, 4096), ("8B down bf16", 1, 14336, 4096),
+              ("70B wo", 0, 8192, 8192), ("70B down", 0, 28672, 8192), ("70B / 8 down", 0, 3584, 8192)]
+
+
+@pytest.mark.parametrize("what,dtype,Z,N", SUM_SHAPES)
+def test_presummed_handover_equals_the_slabs_in_slice_order(oracle, what, dtype, Z, N):
+    """TEAL_OUT_SLAB_SUM (reduce_presummed: what tensor-parallel ranks all-reduce instead of the slab buffer, gpt-fast/tp.py:
+    120-121,139-140): the launch's own fp32 sum over its row slices is BIT-IDENTICAL to adding the TEAL_OUT_SLABS slabs in slice
+    order, its rounding meets the oracle (SURVEY 8(c) tolerance), and the consumer's RESID_NORM producer computes the same bits
+    from the one planar vector as from the interleaved slabs.  Product library, the launch describes itself."""
+    import ctypes
+
+    from teal_amd import _lib, runtime
+    from teal_amd.gpt_fast.engine import (TEAL_IN_PLAIN, TEAL_IN_RESID_NORM, TEAL_OUT_ROUNDED, TEAL_OUT_SLAB_SUM, TEAL_OUT_SLABS, GemvIn,
+                                          _out)
+    O = oracle
+    L = _lib.load()
+    runtime.init()
+    assert not L.teal_is_diagnostics_build or os.environ.get("TEAL_LIB_FLAVOR") == "diag"
+    hb = O.hash_uniform(Z, 301, 2.0, dtype)
+    tau = float(np.median(np.abs(O.from_bits(hb, dtype).astype(np.float32))))
+    wb = O.hash_uniform_c(Z * N, 302, 0.05, dtype)
+    x = torch_from_bits(hb, dtype, DEV)
+    W = _image(wb, Z, N, dtype)
+    ws = runtime.new_workspace(max(Z, N), N)
+    gin = GemvIn(mode=TEAL_IN_PLAIN, x=x.data_ptr())
+
+    def launch(mode, dst):
+        gout = _out([(W.data_ptr(), W.stride(1), 0, N, tau, None)], mode)
+        gout.slabs, gout.slabs_bytes, gout.slabs_interleaved = dst.data_ptr(), dst.numel() * 4, (1 if mode == TEAL_OUT_SLABS else 0)
+        dbuf = ctypes.create_string_buffer(160)
+        gout.desc, gout.desc_bytes = ctypes.cast(dbuf, ctypes.c_char_p), 160
+        n = ctypes.c_int(-1)
+        _lib.check(L.teal_fused_gemv(ctypes.byref(gin), ctypes.byref(gout), Z, dtype, ws.data_ptr(), ws.numel() * 4, ctypes.byref(n),
+                                     runtime.stream_ptr()), "teal_fused_gemv")
+        return n.value, dbuf.value.decode()
+
+    slabs = torch.zeros(8, N, dtype=torch.float32, device=DEV)
+    ns, d_slabs = launch(TEAL_OUT_SLABS, slabs)
+    st = (ns + 3) & ~3
+    v = slabs.view(-1)[: N * st].view(N, st)
+    acc = torch.zeros(N, dtype=torch.float32, device=DEV)
+    for j in range(ns):
+        acc = acc + v[:, j]
+    total = torch.full((N,), float("nan"), dtype=torch.float32, device=DEV)
+    n1, d_sum = launch(TEAL_OUT_SLAB_SUM, total)
+    assert n1 == 1 and d_sum == d_slabs and "gemv_fast_kernel" in d_sum, (d_slabs, d_sum)  # the same instantiation and grid
+    assert torch.equal(total.view(torch.int32), acc.view(torch.int32)), (what, ns, float((total - acc).abs().max()))
+    # replays: the last slice of a tile to arrive changes, the sum does not (slice order, no atomics on data)
+    for _ in range(20):
+        again = torch.zeros(N, dtype=torch.float32, device=DEV)
+        launch(TEAL_OUT_SLAB_SUM, again)
+        assert torch.equal(again.view(torch.int32), total.view(torch.int32))
+    got = O.from_bits(O.to_bits(total.cpu().numpy(), dtype), dtype)
+    truth = O.truth64(hb, wb, Z, N, tau, dtype=dtype)
+    err = np.abs(got - truth)
+    assert (err <= tolerance(O, truth, dtype)).all(), (what, float(err.max()))
+    # a prepared workspace is required when the launch slices the rows; plain memory is refused without launching
+    if ns > 1:
+        plain = torch.zeros(ws.numel(), dtype=torch.float32, device=DEV)
+        gout = _out([(W.data_ptr(), W.stride(1), 0, N, tau, None)], TEAL_OUT_SLAB_SUM)
+        gout.slabs, gout.slabs_bytes = total.data_ptr(), total.numel() * 4
+        assert L.teal_fused_gemv(ctypes.byref(gin), ctypes.byref(gout), Z, dtype, plain.data_ptr(), plain.numel() * 4, None,
+                                 runtime.stream_ptr()) == -8
+    # ---- the consumer: h = resid + round(sum), x = RMSNorm(h) * w, a sparse projection of it --------------------------------
+    N2 = 4096
+    tdt = torch.float16 if dtype == 0 else torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(9)
+    resid = torch.randn(N, device=DEV, generator=g).to(tdt)
+    normw = (1.0 + 0.1 * torch.randn(N, device=DEV, generator=g)).to(tdt)
+    w2 = ((torch.rand(N, N2 + 64, device=DEV, generator=g) - 0.5) * 0.05).to(tdt)
+    outs = []
+    for slabs_ptr, nsl, il in ((slabs.data_ptr(), ns, 1), (total.data_ptr(), 1, 0)):
+        hout = torch.zeros(N, device=DEV, dtype=tdt)
+        y = torch.zeros(N2, device=DEV, dtype=tdt)
+        cin = GemvIn(mode=TEAL_IN_RESID_NORM, resid_in=resid.data_ptr(), slabs=slabs_ptr, nslabs=nsl, slabs_interleaved=il,
+                     norm_weight=normw.data_ptr(), eps=1e-5, resid_out=hout.data_ptr())
+        cout = _out([(w2.data_ptr(), N2 + 64, 0, N2, 0.4, y.data_ptr())], TEAL_OUT_ROUNDED)
+        dbuf = ctypes.create_string_buffer(160)
+        cout.desc, cout.desc_bytes = ctypes.cast(dbuf, ctypes.c_char_p), 160
+        _lib.check(L.teal_fused_gemv(ctypes.byref(cin), ctypes.byref(cout), N, dtype, ws.data_ptr(), ws.numel() * 4, None,
+                                     runtime.stream_ptr()), "consumer")
+        assert "gemv_fast_kernel" in dbuf.value.decode(), dbuf.value  # the planar single vector stays on the lean kernel
+        outs.append((hout.clone(), y.clone()))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16)), "residual stream"
+    assert torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16)), "projection of the normalised activation"
+    assert L.teal_workspace_release(ws.data_ptr()) == 0
