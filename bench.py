@@ -249,7 +249,7 @@ def roofline_dominant_kernel(model, a):
         launch(0)
     torch.cuda.current_stream().wait_stream(s)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with runtime.graph_capture(graph):
         for i in range(len(weights)):
             launch(i)
     for _ in range(3):
@@ -334,7 +334,7 @@ def roofline_engine_gateup(eng, a):
         run_all()
     torch.cuda.current_stream().wait_stream(s)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with runtime.graph_capture(graph):
         run_all()
     for _ in range(3):
         graph.replay()
@@ -379,6 +379,17 @@ def roofline_engine_gateup(eng, a):
     return out
 
 
+def _finite(o):
+    """non-finite floats -> None, recursively (json.dumps(..., allow_nan=False) then never raises on a measurement artefact)"""
+    if isinstance(o, float):
+        return o if o == o and o not in (float("inf"), float("-inf")) else None
+    if isinstance(o, dict):
+        return {k: _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    return o
+
+
 def floor_model(st_sparse, st_dense, n_layer):
     """Why the ratio is what it is, from numbers measured in this run (DecodeEngine.stage_times on the sparse and on the dense
     engine): each GEMV launch type fitted as t = fixed + bytes / stream_rate through its two measured points (kept rows at the
@@ -391,11 +402,16 @@ def floor_model(st_sparse, st_dense, n_layer):
     F = 0.0
     for k in gemv:
         ts, td, bs, bd = st_sparse[k], st_dense[k], st_sparse["bytes"][k], st_dense["bytes"][k]
-        rate = (bd - bs) / (td - ts) if td > ts else float("nan")   # bytes per us = MB/s
-        fixed = ts - bs / rate
+        if not (td > ts and bd > bs):
+            # no slope through these two points (--sparsity 0, or timing noise on a narrow launch): no fit for this launch type —
+            # its whole time counts as fixed, and the line stays valid JSON (no NaN tokens)
+            rate, fixed = None, ts
+        else:
+            rate = (bd - bs) / (td - ts)   # bytes per us = MB/s
+            fixed = ts - bs / rate
         F += fixed
         out["launch"][k] = {"us_sparse": round(ts, 2), "us_dense": round(td, 2), "MB_sparse": round(bs / 1e6, 2), "MB_dense": round(bd / 1e6, 2),
-                            "stream_TBps": round(rate / 1e6, 2), "fixed_us": round(fixed, 2),
+                            "stream_TBps": None if rate is None else round(rate / 1e6, 2), "fixed_us": round(fixed, 2),
                             "of_8TBps_sparse": round(bs / ts / 8e6, 3), "of_8TBps_dense": round(bd / td / 8e6, 3)}
     att_s, att_d = st_sparse["attn"], st_dense["attn"]
     Ds = sum(st_sparse[k] - out["launch"][k]["fixed_us"] for k in gemv)
@@ -408,7 +424,7 @@ def floor_model(st_sparse, st_dense, n_layer):
     out["streaming_us_per_layer"] = {"sparse": round(Ds, 2), "dense": round(Dd, 2)}
     out["layer_ratio"] = {"measured": round(st_dense["layer"] / st_sparse["layer"], 3),
                           "model (fixed + attention + streaming)": round((F + att_d + Dd) / (F + att_s + Ds), 3),
-                          "if the fixed per-launch cost and the attention launch were free": round(Dd / Ds, 3)}
+                          "if the fixed per-launch cost and the attention launch were free": round(Dd / Ds, 3) if Ds > 0 else None}
     out["note"] = ("fixed_us = launch boundary + entry + producer + list + memory-pipeline fill/drain + tail, paid per launch by sparse and "
                    "dense alike; stream_TBps = the slope between the two measured points of a launch type")
     return out
@@ -726,7 +742,7 @@ def main():
         out["roofline"] = None
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(_finite(out), allow_nan=False))  # strict JSON: a non-finite number would print as a bare NaN token
     if _dist_on():
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -534,7 +534,7 @@ class DecodeEngine:
             if key != "layer":
                 out["bytes"][key] = stage_bytes(key)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with runtime.graph_capture(g):
                 run()
             for _ in range(3):
                 g.replay()
@@ -765,7 +765,7 @@ class DecodeEngine:
         self.tok_buf.copy_(state[0]); self.pos_buf.copy_(state[1]); self.rng_state.copy_(state[2])
         g = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(g):
+            with runtime.graph_capture(g):
                 for _ in range(int(tokens)):
                     self._self_step(temperature, top_k)
         finally:  # (also when the capture fails — decode_n then decodes a sharded model eagerly from the same state)

@@ -38,6 +38,7 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 
+from teal_amd import runtime  # noqa: E402
 from teal_amd.gpt_fast.model import ModelArgs, Transformer  # noqa: E402
 from teal_amd.monkeypatch import monkeypatch_layer  # noqa: E402
 from teal_amd.utils import PROJS, get_layer_greedy_sparsities  # noqa: E402
@@ -321,7 +322,7 @@ class GraphedDecoder:
                 self._step()
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with runtime.graph_capture(self.graph):
             self.out_tok = self._step()
 
     def __call__(self, cur_token: torch.Tensor, input_pos: torch.Tensor) -> torch.Tensor:
@@ -370,7 +371,7 @@ class GraphedPrefill:
             torch.cuda.current_stream().wait_stream(s)
             g = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(g):
+                with runtime.graph_capture(g):
                     logits = self.model(toks, pos)
             except Exception as e:  # noqa: BLE001
                 # a sharded model's pass holds one all-reduce per attention and per MLP (tp._reduce_hook): if the collective

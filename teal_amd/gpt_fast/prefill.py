@@ -206,7 +206,7 @@ class FusedPrefill:
                 eng(static)  # warm-up outside capture
             torch.cuda.current_stream().wait_stream(s)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with runtime.graph_capture(g):
                 logits = eng(static)
             self._graphs[T] = (g, static, logits)
         g, static, logits = self._graphs[T]

@@ -41,6 +41,21 @@ def init() -> int:
     return cu
 
 
+def graph_capture(g: "torch.cuda.CUDAGraph", **kw):
+    """`with graph_capture(g):` = torch.cuda.graph(g) with the stream-capture error mode a process with an RCCL process group
+    needs.  torch captures in hipStreamCaptureModeGlobal by default: while ANY stream of the process is capturing, a
+    capture-unsafe call from ANY thread fails.  ProcessGroupNCCL's watchdog thread polls the completion events of earlier
+    collectives (hipEventQuery) every 100 ms; on this ROCm stack that query is refused under a global-mode capture
+    ("operation not permitted when stream is capturing") and the watchdog aborts the whole process — measured with a one-rank
+    group on the leased GPU (profiles/r06_nccl_one_rank_probe.txt: the default mode dies, thread-local mode captures and
+    replays the all-reduce).  With a process group alive the capture therefore runs in thread-local mode: only the capturing
+    thread's own calls are checked, which is all this package's captures rely on."""
+    import torch.distributed as dist
+    if "capture_error_mode" not in kw and dist.is_available() and dist.is_initialized():
+        kw["capture_error_mode"] = "thread_local"
+    return torch.cuda.graph(g, **kw)
+
+
 def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 

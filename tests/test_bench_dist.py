@@ -98,3 +98,22 @@ def test_roofline_object_follows_survey_8d_to_the_letter():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert abs(r["frac"] - b["algorithmic"] / 18.29 / 8e6) < 1e-9 and abs(r["achieved"] - r["frac"] * 8000.0) < 1e-6
     assert abs(r["frac"] - 0.6135) < 2e-3  # the round-5 launch: 89.8 MB in 18.29 us
+
+
+def test_floor_model_without_a_slope_stays_valid_json():
+    """a dense stage that is not slower than the sparse one (--sparsity 0, or noise on the narrow wo launch) has no fit: the launch
+    reports stream_TBps null and the line is still strict JSON"""
+    import bench
+    mk = lambda f: dict({k: 5.0 + f * v for k, v in (("qkv", 10.0), ("wo", 3.0), ("gate_up", 20.0), ("down", 9.0))}, attn=4.0,  # noqa: E731
+                        bytes={k: f * v * 1e6 for k, v in (("qkv", 100.0), ("wo", 33.0), ("gate_up", 180.0), ("down", 90.0))})
+    s, d = mk(0.5), mk(1.0)
+    d["wo"] = s["wo"] - 0.01  # noise: "dense" faster than sparse
+    s["layer"], d["layer"] = 50.0, 77.0
+    m = bench.floor_model(s, d, 32)
+    assert m["launch"]["wo"]["stream_TBps"] is None and m["launch"]["wo"]["fixed_us"] == round(s["wo"], 2)
+    assert m["launch"]["qkv"]["stream_TBps"] is not None
+    line = json.dumps(bench._finite({"floor_model": m, "x": float("nan"), "y": [1.0, float("inf")]}), allow_nan=False)
+    back = json.loads(line)
+    assert back["x"] is None and back["y"] == [1.0, None]
+    same = bench.floor_model(s, dict(s, layer=50.0), 32)  # --sparsity 0: both engines keep every row
+    json.dumps(bench._finite(same), allow_nan=False)

@@ -255,15 +255,31 @@ def test_generate_main_synthetic_cli(extra):
 
 @pytest.mark.gpu
 def test_compile_prefill_generates_the_same_tokens():
-    """--compile --compile_prefill on the default (engine) path: the prefill graph is captured before the engine exists;
-    the engine then re-lays the weights out (freeing the storage a stale graph would still point at).  Every timed sample
-    must produce the tokens of the run without a prefill graph, across several samples (allocator reuse in between)."""
+    """--compile captures the prompt pass too (the hand-fused HIP pass for <= 8 tokens, the patched modules under a hipGraph
+    otherwise): the prefill graph is captured before the engine exists; the engine then re-lays the weights out (freeing the
+    storage a stale graph would still point at).  Every timed sample must produce the tokens of the run WITHOUT a prefill graph
+    (--eager_prefill: the op-by-op pass), across several samples (allocator reuse in between) — for the default pass and for
+    the graphed module pass (--module_prefill), each against the eager baseline."""
     base = ["--synthetic", "tiny-test", "--sparsity", "0.5", "--compile", "--num_samples", "3", "--max_new_tokens", "24", "--top_k", "1"]
-    a = G.main(G.build_parser().parse_args(base))
-    junk = [torch.randn(1 << 16, device="cuda") for _ in range(16)]  # churn the caching allocator between the two runs
-    b = G.main(G.build_parser().parse_args(base + ["--compile_prefill"]))
-    del junk
-    assert len(a["sequences"]) == 3 and a["sequences"] == b["sequences"]
+    eager = G.main(G.build_parser().parse_args(base + ["--eager_prefill"]))
+    assert eager["prefill"] is None and len(eager["sequences"]) == 3
+    junk = [torch.randn(1 << 16, device="cuda") for _ in range(16)]  # churn the caching allocator between the runs
+    module = G.main(G.build_parser().parse_args(base + ["--module_prefill"]))
+    assert module["prefill"] == "GraphedPrefill", module["prefill"]
+    assert module["sequences"] == eager["sequences"]  # the same torch ops, replayed from a graph: the same tokens
+    junk2 = [torch.randn(1 << 15, device="cuda") for _ in range(16)]
+    default = G.main(G.build_parser().parse_args(base))
+    assert str(default["prefill"]).startswith("FusedPrefill"), default["prefill"]
+    del junk, junk2
+    if default["prefill"].endswith(":hip"):
+        # the HIP pass accumulates in another order than torch's matmuls: its last-position logits agree to a few output ulps
+        # (tests/test_prefill.py), so under top_k = 1 the FIRST token may differ only on a near-tie; every sample of the run must
+        # at least agree with the run's own first sample (same prompt, same graphs, allocator reuse in between)
+        assert all(sq == default["sequences"][0] for sq in default["sequences"])
+        agree = sum(a == b for a, b in zip(default["sequences"][0], eager["sequences"][0]))
+        assert agree >= 7, (agree, default["sequences"][0], eager["sequences"][0])  # the 6 prompt tokens + at least the first new one
+    else:
+        assert default["sequences"] == eager["sequences"]
 
 
 @pytest.mark.gpu
