@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Is the fused decode step bit-reproducible while ANOTHER PROCESS keeps the same GPU busy?  (tests/test_soak.py shows 5 800
+bit-identical hipGraph replays in one process; tests/test_tp_gpu.py's two-ranks-on-one-GPU test showed the UNSHARDED engine's
+logits differing in ~1 of 7 runs, round 6.)  One decode step of a 2-layer Llama-2-7B-width model at 50 %, repeated from the same
+state; after EVERY launch the buffer that launch completes is compared on the device with the first run's.  Reports the first
+differing (repeat, layer, stage, buffer) with the differing elements.
+
+    python scripts/micro/concurrency_determinism_probe.py [--repeats 2000] [--noise matmul|copy|engine|none] [--graph 0|1]
+"""
+import argparse
+import os
+import subprocess
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def noise(kind):
+    torch.cuda.set_device(0)
+    if kind == "matmul":
+        a = torch.randn(4096, 4096, device="cuda", dtype=torch.float16)
+        while True:
+            for _ in range(50):
+                a @ a
+            torch.cuda.synchronize()
+    if kind == "copy":
+        a = torch.empty(256 << 20, device="cuda", dtype=torch.uint8)
+        b = torch.empty_like(a)
+        while True:
+            for _ in range(20):
+                b.copy_(a)
+            torch.cuda.synchronize()
+    if kind == "engine":  # a second decode engine of the same kind: what the two-rank test runs next to each rank
+        from teal_amd.gpt_fast import generate as G
+        from teal_amd.gpt_fast.engine import DecodeEngine
+        m = G.build_synthetic_model("7B", "cuda", torch.float16, seed=5, n_layer=4)
+        ths = G.apply_sparsity(m, sparsity=0.5, hist_path=None, greedy_lookup=None, synthetic=True, decode_calibration=False)
+        m.max_seq_length = -1
+        m.setup_caches(1, 64)
+        with torch.no_grad():
+            m(torch.randint(0, 32000, (1, 6), device="cuda", dtype=torch.int), torch.arange(6, device="cuda"))
+            eng = DecodeEngine(m, ths)
+            tok = torch.tensor([[3]], device="cuda", dtype=torch.int)
+            pos = torch.tensor([6], device="cuda", dtype=torch.int)
+            while True:
+                for _ in range(20):
+                    eng(tok, pos)
+                torch.cuda.synchronize()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--repeats", type=int, default=2000)
+    ap.add_argument("--noise", default="engine")
+    ap.add_argument("--noise-child", default=None)
+    ap.add_argument("--n_layer", type=int, default=2)
+    ap.add_argument("--sparsity", type=float, default=0.5)
+    ap.add_argument("--churn", type=int, default=0, help="1: hipMalloc / fill / hipFree of a few large blocks before every step")
+    ap.add_argument("--rebuild", type=int, default=0, help="N > 0: build a fresh DecodeEngine every N steps (same model)")
+    ap.add_argument("--tag", default="p0")
+    a = ap.parse_args()
+    if a.noise_child:
+        return noise(a.noise_child)
+    from teal_amd.gpt_fast import generate as G
+    from teal_amd.gpt_fast.engine import DecodeEngine
+    child = None
+    if a.noise != "none":
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--noise-child", a.noise], stdout=subprocess.DEVNULL,
+                                 stderr=subprocess.DEVNULL)
+        time.sleep(25 if a.noise == "engine" else 8)  # let it get going
+    try:
+        dev = "cuda"
+        model = G.build_synthetic_model("7B", dev, torch.float16, seed=11, n_layer=a.n_layer)
+        ths = G.apply_sparsity(model, sparsity=a.sparsity, hist_path=None, greedy_lookup=None, synthetic=True, decode_calibration=False)
+        P = 6
+        prompt = torch.randint(0, 32000, (P,), device=dev, dtype=torch.int, generator=torch.Generator(device=dev).manual_seed(2))
+        model.max_seq_length = -1
+        model.setup_caches(1, 32)
+        with torch.no_grad():
+            model(prompt.view(1, -1), torch.arange(P, device=dev))
+            eng = DecodeEngine(model, ths)
+            tok = torch.tensor([[17]], device=dev, dtype=torch.int)
+            pos = torch.tensor([P], device=dev, dtype=torch.int)
+
+            def bufs(stage, i):
+                L = model.layers[i] if i >= 0 else None
+                if stage == "qkv":
+                    return {"q": eng.qkv[: eng.qdim], "k_row": L.attention.kv_cache.k_cache[0, :, P], "v_row": L.attention.kv_cache.v_cache[0, :, P],
+                            "resid_B": eng.resid[1]}
+                if stage == "attn":
+                    return {"att_ws": eng.att_ws}
+                if stage == "wo":
+                    return {"s_wo": eng.s_wo.view(-1)[: eng.dim * 4]}
+                if stage == "gate_up":
+                    return {"gu": eng.gu, "resid_A": eng.resid[0]}
+                if stage == "down":
+                    return {"s_down": eng.s_down.view(-1)[: eng.dim * 4]}
+                return {"logits": eng.logits}
+
+            ref, found = {}, []
+
+            def hook(when, stage, i):
+                if when != "after":
+                    return
+                for name, t in bufs(stage, i).items():
+                    key = (i, stage, name)
+                    if key not in ref:
+                        ref[key] = t.clone()
+                    elif not found and not torch.equal(ref[key].view(torch.uint8), t.view(torch.uint8)):
+                        d = (ref[key] != t) if ref[key].dtype != torch.float32 else (ref[key].view(torch.int32) != t.view(torch.int32))
+                        idx = torch.nonzero(d.view(-1)).view(-1)
+                        found.append((key, int(idx.numel()), idx[:12].tolist(), ref[key].view(-1)[idx[:6]].tolist(), t.view(-1)[idx[:6]].tolist()))
+
+            eng(tok, pos, hook=hook)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for r in range(a.repeats):
+                if a.churn:
+                    junk = [torch.full(((64 + 32 * k) << 18,), float(k), device=dev) for k in range(3)]  # 64 / 96 / 128 MB
+                    del junk
+                    torch.cuda.empty_cache()
+                if a.rebuild and r % a.rebuild == a.rebuild - 1:
+                    del eng
+                    torch.cuda.empty_cache()
+                    eng = DecodeEngine(model, ths)
+                eng(tok, pos, hook=hook)
+                if found:
+                    torch.cuda.synchronize()
+                    key, n, idx, was, now = found[0]
+                    print(f"[{a.tag}] repeat {r}: layer {key[0]} stage {key[1]} buffer {key[2]}: {n} elements differ; first indices {idx}; was {was}; now {now}")
+                    found.clear()
+                    # which later buffers differ in this same step is a consequence; restart the comparison from a fresh step
+            torch.cuda.synchronize()
+            print(f"[{a.tag}] {a.repeats} repeats with noise={a.noise} churn={a.churn} rebuild={a.rebuild}: done in {time.time() - t0:.1f} s")
+    finally:
+        if child is not None:
+            child.kill()
+
+
+if __name__ == "__main__":
+    main()

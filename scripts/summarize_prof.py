@@ -78,7 +78,9 @@ def launch_table(line, model):
         ("wo", lambda k, w: mode_of(k) in ("4", "0"), g("o") * dim * dim * 2 + dim * 2 + dim * 2),
         ("attention", lambda k, w: k.startswith("decode_attention_split_kernel") or k.startswith("decode_attention_gqa_kernel"),
          2.0 * nkv * (pos + 1) * hd * 2 + dim * 2 * 2),
-        ("lm_head", lambda k, w: mode_of(k) == "1" and w in (vocab // 128, vocab // 64, vocab // 256), dim * vocab * 2 + dim * 2 + vocab * 2),
+        # (a 128 k-entry vocabulary takes 512-column tiles: the general kernel, sparse_gemv_kernel<64,...>, ceil(vocab / 512) workgroups)
+        ("lm_head", lambda k, w: (mode_of(k) == "1" and w in (vocab // 128, vocab // 64, vocab // 256)) or
+         (k.startswith("sparse_gemv_kernel<64,") and w == -(-vocab // 512)), dim * vocab * 2 + dim * 2 + vocab * 2),
         ("sampler", lambda k, w: k.startswith("sample_topk"), vocab * 2),
     ]
 

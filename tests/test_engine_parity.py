@@ -103,7 +103,10 @@ def _mask_words(O, bits, tau, dtype):
 CASES = [("7B", torch.float16, 0.5, 2, 1, True), ("7B", torch.float16, 0.5, 2, 1, False), ("7B", torch.float16, 0.5, 2, 0, None),
          ("llama-3-8b", torch.bfloat16, 0.4, 2, 1, True), ("llama-3-8b", torch.bfloat16, 0.4, 2, 1, False),
          ("llama-3-8b", torch.bfloat16, 0.4, 2, 0, None), ("70B", torch.float16, 0.5, 2, 1, True), ("70B", torch.float16, 0.5, 2, 1, False),
-         ("7B", torch.float16, 0.5, 32, 31, None)]
+         ("7B", torch.float16, 0.5, 32, 31, None),
+         # the widths between 7B and 70B that profiles/r06_ratio_vs_width.txt quotes (Llama-2-13B: 5120 = five rounds of 16 chunks,
+         # the non-EXACT instantiations; CodeLlama-34B: 8192-wide, grouped-query, intermediate 22016 = 344 tiles of 128 columns)
+         ("13B", torch.float16, 0.5, 2, 1, None), ("34B", torch.float16, 0.5, 2, 1, None)]
 
 
 def _silu_mul_variants(O, gu_bits, inter, dtype):
@@ -153,7 +156,7 @@ def test_engine_launches_vs_oracle_under_sparsity(oracle, name, tdt, sparsity, n
             eng = DecodeEngine(model, ths, pair=pair)
         assert eng.att_fused_merge and (pair is None or eng.pair == pair)
         if pair is None:
-            assert eng.pair == (name == "70B")
+            assert eng.pair == (name in ("70B", "34B")), (name, eng.pair)  # paired where 128-column paired tiles cover 2/3 of the CUs
         k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out, _ = eng.stages[target]
         A, B = eng.resid
         seen = {}

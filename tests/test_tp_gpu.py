@@ -192,7 +192,7 @@ def test_tp_engine_two_ranks_share_one_gpu(arch, precision):
     # 50 %: near-threshold activations may flip between the two summation orders (as between engine and module path)
     # (bf16 carries 8 significant bits: one last-place difference of the residual stream moves a normalised activation by 0.4-0.8 %,
     #  so several per cent of the rows near a threshold can flip — observed 0.975-0.998 over boxes; fp16: > 0.995 as elsewhere)
-    assert r["sparse_cosine"] > (0.995 if precision == "fp16" else 0.95) and 0.4 < r["kept_o"] < 0.6 and 0.4 < r["kept_down"] < 0.6, r
+    assert r["sparse_cosine"] > (0.995 if precision == "fp16" else 0.95) and 0.4 < r["kept_o"] < 0.6 and 0.4 < r["kept_down"] < 0.6, json.dumps(r)
     assert r["kv_rows_equal"], "the rank's KV heads hold the same rows as the unsharded cache's"
     # eager decode steps with the fused sampler: the ranks and the unsharded engine draw the same first token (later ones may
     # part ways once a last-place difference of a logit decides an exponential race; reported, not asserted)

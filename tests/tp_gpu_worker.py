@@ -57,6 +57,10 @@ def main():
         pre_f, log_f, eng_f, toks_f = run(full, ths)
         assert eng_f.reduce is None
         kc_f = full.layers[1].attention.kv_cache.k_cache[0, :, :P + 1].clone()
+        import zlib
+        torch.cuda.synchronize()
+        early = {"decode_full": zlib.crc32(log_f.cpu().numpy().tobytes()), "kc_full": zlib.crc32(kc_f.cpu().numpy().tobytes()),
+                 "ptr_log_f": log_f.data_ptr(), "ptr_kc_f": kc_f.data_ptr()}
         del eng_f, full
         torch.cuda.empty_cache()
         part = G.build_synthetic_model(arch, dev, dt, seed=11, n_layer=n_layer, shard=tp.apply_tp)
@@ -72,6 +76,16 @@ def main():
         pre_p, log_p, eng_p, toks_p = run(part, ths)
         assert eng_p.reduce is counted and eng_p.qdim * world == eng_p.dim
         out[label] = (pre_f, log_f, pre_p, log_p, toks_f, toks_p)
+        # digests of what each side produced (run-to-run reproducibility of the two-process test is checked on these)
+        import zlib
+        crc = lambda t: zlib.crc32(t.detach().contiguous().cpu().numpy().tobytes())  # noqa: E731
+        res.setdefault("digest", {})[label] = {"prefill_full": crc(pre_f), "decode_full": crc(log_f), "prefill_rank": crc(pre_p),
+                                               "decode_rank": crc(log_p), "kc_full": crc(kc_f),
+                                               "early": early,
+                                               "ths": zlib.crc32(json.dumps(ths, sort_keys=True).encode()),
+                                               "resid_rank": crc(eng_p.resid[0]) ^ crc(eng_p.resid[1]), "gu_rank": crc(eng_p.gu),
+                                               "s_wo_rank": crc(eng_p.handover_sum("wo")), "s_down_rank": crc(eng_p.handover_sum("down")),
+                                               "qkv_rank": crc(eng_p.qkv), "att_rank": crc(eng_p.att_ws)}
         if label == "dense":
             res["engine_fused"] = True
             res["reduces_per_step"] = calls["n"] // (1 + 4)  # one forward call + four decode_n steps
@@ -102,6 +116,8 @@ def main():
     dist.all_gather(gathered, flags)
     res["dense_max_err"] = float(max(g[0] for g in gathered))
     res["sparse_cosine"] = float(min(g[1] for g in gathered))
+    if os.environ.get("TEAL_TP_WORKER_DIGESTS"):  # every rank's digests (run-to-run reproducibility probes)
+        print("RANKDIGEST " + json.dumps({"rank": rank, "digest": res.get("digest")}), flush=True)
     if rank == 0:
         print(json.dumps(res))
     dist.destroy_process_group()
