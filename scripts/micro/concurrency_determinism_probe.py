@@ -34,6 +34,101 @@ def noise(kind):
             for _ in range(20):
                 b.copy_(a)
             torch.cuda.synchronize()
+    if kind == "malloc":  # hipMalloc / fill / hipFree of large blocks (what torch.cuda.empty_cache() + a rebuild does)
+        while True:
+            junk = [torch.full(((64 + 32 * k) << 18,), float(k), device="cuda") for k in range(3)]
+            torch.cuda.synchronize()
+            del junk
+            torch.cuda.empty_cache()
+    if kind == "h2d":  # pageable host memory copied to the device (staging / pinning inside the runtime)
+        while True:
+            h = torch.randn(8 << 20)
+            d = h.to("cuda")
+            torch.cuda.synchronize()
+            del h, d
+    if kind == "pinned":  # pinned host allocations coming and going
+        while True:
+            h = torch.empty(16 << 20, pin_memory=True)
+            d = h.to("cuda", non_blocking=True)
+            torch.cuda.synchronize()
+            del h, d
+            torch._C._host_emptyCache() if hasattr(torch._C, "_host_emptyCache") else None
+    if kind == "build":  # the model build of the probes: random init on the device, thresholds, caches; freed again
+        from teal_amd.gpt_fast import generate as G
+        while True:
+            m = G.build_synthetic_model("7B", "cuda", torch.float16, seed=5, n_layer=2)
+            G.apply_sparsity(m, sparsity=0.5, hist_path=None, greedy_lookup=None, synthetic=True, decode_calibration=False)
+            torch.cuda.synchronize()
+            del m
+            torch.cuda.empty_cache()
+    if kind in ("randn", "prefill", "quantile", "sdpa", "cat"):  # the pieces of "build", one at a time
+        from teal_amd.gpt_fast import generate as G
+        m = G.build_synthetic_model("7B", "cuda", torch.float16, seed=5, n_layer=2)
+        m.setup_caches(1, 32)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        toks = torch.randint(0, 32000, (1, 24), device="cuda", dtype=torch.int)
+        big = torch.randn(1 << 20, device="cuda")
+        q = torch.randn(1, 32, 24, 128, device="cuda", dtype=torch.float16)
+        with torch.no_grad():
+            while True:
+                for _ in range(10):
+                    if kind == "randn":
+                        w = torch.randn((11008, 4096), device="cuda", dtype=torch.float32, generator=g) * 0.02
+                        m.layers[0].feed_forward.w1.weight.data.copy_(w)
+                        del w
+                    elif kind == "prefill":
+                        m(toks, torch.arange(24, device="cuda"))
+                    elif kind == "quantile":
+                        torch.quantile(big[::5].abs(), 0.5)
+                    elif kind == "sdpa":
+                        torch.nn.functional.scaled_dot_product_attention(q, q, q, is_causal=True)
+                    else:
+                        torch.cat([big, big]).abs().float().flatten()
+                torch.cuda.synchronize()
+                if os.environ.get("NOISE_READY_FILE"):
+                    open(os.environ["NOISE_READY_FILE"], "w").write("ready")
+    if kind.startswith("op_"):  # single operations of the dense prompt pass (24 tokens, Llama-2-7B widths)
+        import torch.nn.functional as F
+        T = int(os.environ.get("NOISE_TOKENS", "24"))
+        x = torch.randn(1, T, 4096, device="cuda", dtype=torch.float16)
+        h = torch.randn(1, T, 11008, device="cuda", dtype=torch.float16)
+        w_qkv = torch.randn(12288, 4096, device="cuda", dtype=torch.float16) * 0.02
+        w_o = torch.randn(4096, 4096, device="cuda", dtype=torch.float16) * 0.02
+        w_gu = torch.randn(11008, 4096, device="cuda", dtype=torch.float16) * 0.02
+        w_d = torch.randn(4096, 11008, device="cuda", dtype=torch.float16) * 0.02
+        w_head = torch.randn(32000, 4096, device="cuda", dtype=torch.float16) * 0.02
+        emb = torch.nn.Embedding(32000, 4096, device="cuda", dtype=torch.float16)
+        toks = torch.randint(0, 32000, (1, T), device="cuda")
+        nw = torch.ones(4096, device="cuda", dtype=torch.float16)
+        with torch.no_grad():
+            while True:
+                for _ in range(20):
+                    if kind == "op_linear_qkv":
+                        F.linear(x, w_qkv)
+                    elif kind == "op_linear_o":
+                        F.linear(x, w_o)
+                    elif kind == "op_linear_gu":
+                        F.linear(x, w_gu)
+                    elif kind == "op_linear_d":
+                        F.linear(h, w_d)
+                    elif kind == "op_linear_head":
+                        F.linear(x, w_head)
+                    elif kind == "op_norm":
+                        xf = x.float()
+                        (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)).type_as(x) * nw
+                    elif kind == "op_silu":
+                        F.silu(h) * h
+                    elif kind == "op_emb":
+                        emb(toks)
+                    elif kind == "op_add":
+                        x + x
+                torch.cuda.synchronize()
+                if os.environ.get("NOISE_READY_FILE"):
+                    open(os.environ["NOISE_READY_FILE"], "w").write("ready")
+    if kind == "spawn":  # processes that open the device (queues created and destroyed: the scheduler's run list changes)
+        while True:
+            subprocess.run([sys.executable, "-c", "import torch; torch.zeros(1, device='cuda'); torch.cuda.synchronize()"],
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     if kind == "engine":  # a second decode engine of the same kind: what the two-rank test runs next to each rank
         from teal_amd.gpt_fast import generate as G
         from teal_amd.gpt_fast.engine import DecodeEngine
@@ -69,9 +164,16 @@ def main():
     from teal_amd.gpt_fast.engine import DecodeEngine
     child = None
     if a.noise != "none":
+        ready = f"/tmp/noise_ready_{os.getpid()}"
         child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--noise-child", a.noise], stdout=subprocess.DEVNULL,
-                                 stderr=subprocess.DEVNULL)
-        time.sleep(25 if a.noise == "engine" else 8)  # let it get going
+                                 stderr=subprocess.DEVNULL, env={**os.environ, "NOISE_READY_FILE": ready})
+        if a.noise.startswith("op_") or a.noise in ("randn", "prefill", "quantile", "sdpa", "cat"):
+            for _ in range(300):
+                if os.path.exists(ready):
+                    break
+                time.sleep(0.5)
+        else:
+            time.sleep(25 if a.noise == "engine" else 8)  # let it get going
     try:
         dev = "cuda"
         model = G.build_synthetic_model("7B", dev, torch.float16, seed=11, n_layer=a.n_layer)
@@ -102,6 +204,9 @@ def main():
                 return {"logits": eng.logits}
 
             ref, found = {}, []
+            nbad = 0
+            from collections import Counter
+            first_stage, jhist = Counter(), Counter()
 
             def hook(when, stage, i):
                 if when != "after":
@@ -113,7 +218,12 @@ def main():
                     elif not found and not torch.equal(ref[key].view(torch.uint8), t.view(torch.uint8)):
                         d = (ref[key] != t) if ref[key].dtype != torch.float32 else (ref[key].view(torch.int32) != t.view(torch.int32))
                         idx = torch.nonzero(d.view(-1)).view(-1)
-                        found.append((key, int(idx.numel()), idx[:12].tolist(), ref[key].view(-1)[idx[:6]].tolist(), t.view(-1)[idx[:6]].tolist()))
+                        found.append((key, int(idx.numel()), idx[:12].tolist(), ref[key].reshape(-1)[idx[:6]].tolist(), t.reshape(-1)[idx[:6]].tolist()))
+                        first_stage[stage] += 1
+                        if name in ("gu", "s_wo", "s_down"):  # which of a lane's eight columns (no rotation mixes neighbours here)
+                            col = idx // 4 if name != "gu" else idx
+                            for j, c in zip(*[v.tolist() for v in torch.unique(col % 8, return_counts=True)]):
+                                jhist[j] += c
 
             eng(tok, pos, hook=hook)
             torch.cuda.synchronize()
@@ -131,11 +241,13 @@ def main():
                 if found:
                     torch.cuda.synchronize()
                     key, n, idx, was, now = found[0]
-                    print(f"[{a.tag}] repeat {r}: layer {key[0]} stage {key[1]} buffer {key[2]}: {n} elements differ; first indices {idx}; was {was}; now {now}")
+                    if nbad < 5:
+                        print(f"[{a.tag}] repeat {r}: layer {key[0]} stage {key[1]} buffer {key[2]}: {n} elements differ; first indices {idx}; was {was}; now {now}")
                     found.clear()
+                    nbad += 1
                     # which later buffers differ in this same step is a consequence; restart the comparison from a fresh step
             torch.cuda.synchronize()
-            print(f"[{a.tag}] {a.repeats} repeats with noise={a.noise} churn={a.churn} rebuild={a.rebuild}: done in {time.time() - t0:.1f} s")
+            print(f"[{a.tag}] {a.repeats} repeats with noise={a.noise} churn={a.churn} rebuild={a.rebuild}: {nbad} repeats differed; done in {time.time() - t0:.1f} s; first differing stage {dict(first_stage)}; column mod 8 of the differing elements {dict(sorted(jhist.items()))}")
     finally:
         if child is not None:
             child.kill()

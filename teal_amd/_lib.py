@@ -12,6 +12,7 @@ import glob
 import os
 import shutil
 import subprocess
+import sys
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
@@ -25,6 +26,20 @@ SOURCES = ("teal_kernels.hip", "teal_attention.hip", "teal_gemv_w16_f16.hip", "t
 # first 11 dwords into SGPRs at wave launch (no scalar-cache miss before the first activation load)
 PRELOAD = {"teal_gemv_fast_f16.hip": 12, "teal_gemv_fast_bf16.hip": 12, "teal_gemv_fast_w8_f16.hip": 12,
            "teal_gemv_fast_w8_bf16.hip": 12, "teal_attention.hip": 12}
+# No packed-fp32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) in any kernel of the library (round 6).  Measured on
+# MI355X: while ANOTHER process's skinny rocBLAS / hipBLASLt GEMM (Tensile MT64x32x256 / MT32x16x256, a 24-token F.linear) shares
+# the GPU, the LOW half of v_pk_fma_f32 results is dropped now and then for a whole row group — every decode step next to such a
+# process differed (whole accumulators, even columns only, delta = -x_r * W[r, cols]); the same kernels with v_fma_mix_f32 /
+# v_fmac_f32 in its place are bit-reproducible under the same load, and alone on the GPU both forms give the same bits
+# (profiles/r06_concurrent_packed_fp32.txt).  With the feature off the compiler folds the fp16 -> fp32 conversion into
+# v_fma_mix_f32 (8 instructions per 16 bytes of weights instead of 8 conversions + 4 packed FMAs).
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+# Floating-point contraction follows the SOURCE, not the optimiser: `a += x * y` inside one expression is one fma in every
+# instantiation (hipcc's default, -ffp-contract=fast, fuses wherever the DAG combiner sees fit — it saw fit differently in the
+# ROPED and the slab-reading instantiation of decode_attention_split_kernel once the packed forms were gone, and the lean and the
+# general decode step, specified to be bit-identical, were not: tests/test_soak.py).  The GEMV units go further and switch
+# contraction off (explicit fmaf only: the note at the top of teal_gemv_kernel.h).
+FP_CONTRACT = "-ffp-contract=on"
 INCLUDE = os.path.join(_ROOT, "include")
 OBJ_DIR = os.path.join(CSRC, "_obj")
 LIB_PATH = os.path.join(_PKG, "libteal_hip.so")  # the in-tree PRODUCT library: what build() writes and what load() opens
@@ -89,7 +104,7 @@ def build(force: bool = False, verbose: bool = False, out: str | None = None, ex
     its objects live in their own directory and it is always rebuilt."""
     headers = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(INCLUDE, "teal_hip.h")]
     srcs = [os.path.join(CSRC, f) for f in SOURCES]
-    base = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", f"-I{INCLUDE}", f"-I{CSRC}"]
+    base = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", f"-I{INCLUDE}", f"-I{CSRC}", *NO_PACKED_FP32, FP_CONTRACT]
     if out is not None:
         targets = [(out, os.path.join(OBJ_DIR, os.path.basename(out).replace(".", "_")), [*base, *extra_flags], True)]
     else:
@@ -108,7 +123,13 @@ def build(force: bool = False, verbose: bool = False, out: str | None = None, ex
     def compile_one(job):
         if verbose:
             print(" ".join(job[0]))
-        subprocess.check_call(job[0])
+        r = subprocess.run(job[0], stderr=subprocess.PIPE, text=True)
+        # (the host pass of the same command line does not know the AMDGPU feature and says so once per function: not news)
+        err = "\n".join(ln for ln in r.stderr.splitlines() if "'-packed-fp32-ops' is not a recognized feature" not in ln)
+        if err.strip():
+            print(err, file=sys.stderr)
+        if r.returncode != 0:
+            raise subprocess.CalledProcessError(r.returncode, job[0])
 
     if all_jobs:
         with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(all_jobs), os.cpu_count() or 1)) as ex:

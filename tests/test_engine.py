@@ -245,23 +245,33 @@ def test_generate_with_engine_decoder():
 
 def test_pair_and_masked_stages_equal_unfused_stages():
     """PAIR (gate|up in one workgroup + silu*mul epilogue + masks) and MASKED consumers reproduce the
-    SILU_MUL / PLAIN path bit for bit at 50 % with two different gate/up thresholds."""
+    SILU_MUL / PLAIN path: bit for bit with one threshold for gate and up (the same kept-row list, hence the same fp32
+    summation order), and to the last place of h with two different thresholds — the paired workgroup streams the UNION of
+    the two keep sets (teal_gemv_fast.h: tau = min(tau_gate, tau_up), rows outside a set multiply zero weights), so a gate row
+    sits at another list position than in the unpaired gate-only list and its fp32 partial sums associate differently: a
+    rounding of h may flip in the last place now and then (round 6: seen once the fp16 roundings stopped being folded into
+    v_fma_mixlo_f16; with the folded build the seeded inputs below happened not to hit one)."""
     from teal_amd.gpt_fast.engine import DecodeEngine
-    _, m1, ths = _models(torch.float16, 0.5)
-    _, m2, _ = _models(torch.float16, 0.5)
-    for t in ths:  # block-wise-greedy style: gate and up thresholds differ
-        t["up"] = t["gate"] * 0.8
     prompt = torch.tensor([3, 141, 59, 26, 500, 358], device=DEV, dtype=torch.int)
-    with torch.no_grad():
-        for m in (m1, m2):
-            m(prompt.view(1, -1), torch.arange(6, device=DEV))
-        e1, e2 = DecodeEngine(m1, ths, pair=True), DecodeEngine(m2, ths, pair=False)
-        tok = torch.tensor([[5]], device=DEV, dtype=torch.int)
-        for step in range(4):
-            pos = torch.tensor([6 + step], device=DEV, dtype=torch.int)
-            a, b = e1(tok, pos), e2(tok, pos)
-            assert torch.equal(a.view(torch.int16), b.view(torch.int16)), step
-            tok = a.float().argmax().view(1, 1).to(torch.int)
+    for up_scale in (1.0, 0.8):
+        _, m1, ths = _models(torch.float16, 0.5)
+        _, m2, _ = _models(torch.float16, 0.5)
+        for t in ths:  # (0.8: block-wise-greedy style, gate and up thresholds differ)
+            t["up"] = t["gate"] * up_scale
+        with torch.no_grad():
+            for m in (m1, m2):
+                m(prompt.view(1, -1), torch.arange(6, device=DEV))
+            e1, e2 = DecodeEngine(m1, ths, pair=True), DecodeEngine(m2, ths, pair=False)
+            tok = torch.tensor([[5]], device=DEV, dtype=torch.int)
+            for step in range(4):
+                pos = torch.tensor([6 + step], device=DEV, dtype=torch.int)
+                a, b = e1(tok, pos), e2(tok, pos)
+                if up_scale == 1.0:
+                    assert torch.equal(a.view(torch.int16), b.view(torch.int16)), step
+                else:
+                    ulp = float(b.float().abs().max()) * 2.0 ** -10
+                    assert float((a.float() - b.float()).abs().max()) <= 16 * ulp, (step, float((a.float() - b.float()).abs().max()), ulp)
+                tok = b.float().argmax().view(1, 1).to(torch.int)
 
 
 def test_interleaved_slabs_equal_planar():

@@ -249,6 +249,36 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert all(hasattr(_lib.load_diag(), n) for n in _lib.EXPORTS + _lib.DIAG_EXPORTS)
 
 
+def test_no_packed_fp32_instruction_in_the_libraries(tmp_path):
+    """Round 6: next to another process's skinny GEMM the low half of v_pk_fma_f32 results gets dropped on MI355X
+    (profiles/r06_concurrent_packed_fp32.txt); the libraries are built without the packed-fp32 feature (teal_amd/_lib.py:
+    NO_PACKED_FP32), and no kernel of either build may contain v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32.
+    Nor v_fma_mixlo_f16 / v_fma_mixhi_f16: they round the exact a * b + c ONCE to fp16 where the oracle (and fp32 arithmetic
+    followed by .to(fp16)) rounds twice (profiles/r06_fma_mixlo_rounding.txt); teal_common.h: float_to_bits keeps the
+    conversion a separate v_cvt_f16_f32."""
+    import shutil
+    import subprocess
+    from teal_amd import _lib
+    _lib.build()
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump in this image")
+    for lib in (_lib.LIB_PATH, _lib.DIAG_LIB_PATH):
+        d = tmp_path / os.path.basename(lib)
+        d.mkdir()
+        shutil.copy(lib, d / "lib.so")
+        subprocess.run([objdump, "--offloading", "lib.so"], cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        objs = sorted(f for f in os.listdir(d) if f.endswith("gfx950"))
+        assert len(objs) == len(_lib.SOURCES), objs   # one code object per translation unit
+        n_inst = 0
+        for f in objs:
+            asm = subprocess.check_output([objdump, "-d", f], cwd=d, text=True)
+            n_inst += asm.count("v_fma") + asm.count("v_fmac")
+            hits = re.findall(r"v_pk_(?:fma|mul|add)_f32|v_pk_mov_b32|v_fma_mix(?:lo|hi)_f16", asm)
+            assert not hits, (lib, f, hits[:3])
+        assert n_inst > 1000   # (the disassembly was not empty)
+
+
 def test_oracle_is_not_reachable_from_the_product_package():
     """teal_amd/ must never import, link or shell out to oracle/ (parity would be void)."""
     pkg = os.path.join(ROOT, "teal_amd")

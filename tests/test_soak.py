@@ -277,3 +277,21 @@ def test_int4_graph_replay_soak(dtype):
     finally:
         del model
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("noise", ["op_linear_qkv", "op_linear_d"])
+def test_step_is_reproducible_next_to_another_process(noise):
+    """The decode step gives the same bits while ANOTHER PROCESS keeps the GPU busy with a skinny rocBLAS / hipBLASLt GEMM (a
+    24-token F.linear at Llama-2-7B widths: Tensile MT64x32x256 / MT32x16x256 stream-K kernels).  Round 6: with v_pk_fma_f32 in
+    the GEMV inner loops every step next to such a process differed (the low half of packed results dropped for whole row
+    groups; two TP ranks sharing the GPU through tests/tp_gpu_worker.py disagreed in ~1 of 7 runs); the libraries are built
+    without packed fp32 since (teal_amd/_lib.py: NO_PACKED_FP32, profiles/r06_concurrent_packed_fp32.txt).  After every launch
+    of a 2-layer Llama-2-7B-width step at 50 % the buffer it completes is compared, on the device, with the first run's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "micro", "concurrency_determinism_probe.py"), "--noise", noise,
+                          "--repeats", "1500"], capture_output=True, text=True, timeout=600, cwd=root)
+    line = [ln for ln in out.stdout.splitlines() if "repeats with noise=" in ln]
+    assert out.returncode == 0 and line, (out.stdout[-1500:], out.stderr[-1500:])
+    assert " 0 repeats differed" in line[-1], line[-1][:600]

@@ -58,9 +58,9 @@ def main():
         assert eng_f.reduce is None
         kc_f = full.layers[1].attention.kv_cache.k_cache[0, :, :P + 1].clone()
         import zlib
+        crc = lambda t: zlib.crc32(t.detach().contiguous().view(torch.uint8).cpu().numpy().tobytes())  # noqa: E731 (bytes: bf16 too)
         torch.cuda.synchronize()
-        early = {"decode_full": zlib.crc32(log_f.cpu().numpy().tobytes()), "kc_full": zlib.crc32(kc_f.cpu().numpy().tobytes()),
-                 "ptr_log_f": log_f.data_ptr(), "ptr_kc_f": kc_f.data_ptr()}
+        early = {"decode_full": crc(log_f), "kc_full": crc(kc_f)}
         del eng_f, full
         torch.cuda.empty_cache()
         part = G.build_synthetic_model(arch, dev, dt, seed=11, n_layer=n_layer, shard=tp.apply_tp)
@@ -77,8 +77,6 @@ def main():
         assert eng_p.reduce is counted and eng_p.qdim * world == eng_p.dim
         out[label] = (pre_f, log_f, pre_p, log_p, toks_f, toks_p)
         # digests of what each side produced (run-to-run reproducibility of the two-process test is checked on these)
-        import zlib
-        crc = lambda t: zlib.crc32(t.detach().contiguous().cpu().numpy().tobytes())  # noqa: E731
         res.setdefault("digest", {})[label] = {"prefill_full": crc(pre_f), "decode_full": crc(log_f), "prefill_rank": crc(pre_p),
                                                "decode_rank": crc(log_p), "kc_full": crc(kc_f),
                                                "early": early,
