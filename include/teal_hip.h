@@ -330,15 +330,16 @@ int teal_sample_topk_ws(const void* logits, int vocab, int dtype, int top_k, flo
                         size_t ws_bytes, void* stream);
 
 
-/* ---- dense prompt pass for short prompts (T <= 8 tokens), teal_amd/csrc/teal_prefill.hip ------ */
+/* ---- dense prompt pass for short prompts (T <= 16 tokens), teal_amd/csrc/teal_prefill.hip ----- */
 
 /* The reference's prefill is dense (its ops run torch.matmul when the sequence is longer than one token,
  * kernels/sparse_gemv.py:271,298; the rest is the stock model, gpt-fast/model.py:107-121,158-186,258-259,289-291) and its
  * tokens/sec counts it (gpt-fast/generate.py:458,487-496).  These entry points make one layer of that pass seven launches over
- * the decode step's own weight images.  Every hand-over is TRANSPOSED, [feature][8]: the up to eight tokens of a feature in one
- * 16-byte word (16-bit activations: xt, ht, yt) or one 32-byte pair (fp32 slabs [slice][feature][8]); token slots >= T of the
- * 16-bit vectors are written as zero, of the slabs left untouched (consumers ignore them).  1 <= T <= 8.  Floating-point
- * results: fp32 sums, the rounding points of the module path's 16-bit tensors. */
+ * the decode step's own weight images.  Every hand-over is TRANSPOSED, [feature][R] with R = 8 for T <= 8 and R = 16 for
+ * 9 <= T <= 16 (every call of one pass takes the same T, hence the same R; "[..][8]" below reads "[..][R]"): the tokens of a
+ * feature in one or two 16-byte words (16-bit activations: xt, ht, yt) or R / 4 of them (fp32 slabs [slice][feature][R]); token
+ * slots >= T of the 16-bit vectors are written as zero, of the slabs left untouched (consumers ignore them).  1 <= T <= 16.
+ * Floating-point results: fp32 sums, the rounding points of the module path's 16-bit tensors. */
 
 /* What a GEMM launch builds its activations from (every workgroup builds the rows of its own slice, once, while staging them) */
 #define TEAL_PREFILL_IN_XT 0        /* xt [Z][8] as given */
@@ -358,7 +359,7 @@ typedef struct teal_prefill_in {
 
 /* slabs[slice][n][s] = sum over the slice's rows m of W^T[m][n] * x[m][s]: w0T [Z][ld0] (n0 columns) and, optionally, w1T [Z][ld1]
  * (n1 columns, output columns n0 ..: gate | up in one launch).  Z, n0, n1 multiples of 256.  *split_out = slices written (<= 16;
- * the consumer sums them in slice order and rounds once); slabs must hold 16 * (n0 + n1) * 8 floats and must not be the buffer a
+ * the consumer sums them in slice order and rounds once); slabs must hold 16 * (n0 + n1) * R floats and must not be the buffer a
  * TEAL_PREFILL_IN_SILU_MUL launch reads. */
 int teal_prefill_gemm(const teal_prefill_in_t* in, const void* w0T, int ld0, int n0, const void* w1T, int ld1, int n1, float* slabs,
                       size_t slabs_bytes, int Z, int T, int dtype, int* split_out, void* stream);
@@ -366,7 +367,7 @@ int teal_prefill_gemm(const teal_prefill_in_t* in, const void* w0T, int ld0, int
  * Exactly one of tokens (+ emb [vocab][dim]) / ht_in is given; with neither xt_out nor x_last only the first of the two launches runs
  * (h and the sums of squares: a TEAL_PREFILL_IN_NORM GEMM normalises while it stages).  Outputs: ht_out [dim][8] (required; must not alias ht_in's
  * words of other columns — the same buffer is fine), xt_out [dim][8] and x_last [dim] (optional) = the normalised vector of
- * token T - 1 as a plain vector (input of the lm_head GEMV).  sumsq_scratch: (dim / 256 rounded up) * 8 floats of caller memory
+ * token T - 1 as a plain vector (input of the lm_head GEMV).  sumsq_scratch: (dim / 256 rounded up) * R floats of caller memory
  * (the per-workgroup sums of squares between the two launches this call makes).  dim <= 16384. */
 int teal_prefill_resid_norm(const void* emb, const int32_t* tokens, int T, const void* ht_in, const float* slabs, int split,
                             const void* norm_w, float eps, int dim, void* ht_out, void* xt_out, void* x_last, float* sumsq_scratch,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The prompt pass's validity range (round-5 verdict, item 5): generate() by the reference's definition — new tokens / wall time
 INCLUDING the prompt pass (gpt-fast/generate.py:458,487-496) — at prompt lengths 6, 8, 9, 16, 64, 256, 1024 on Llama-2-7B @ 50 %
-under --compile: which pass ran (the hand-fused HIP pass serves 2..8 tokens, teal_amd/gpt_fast/prefill.py; longer prompts take the
+under --compile: which pass ran (the hand-fused HIP pass serves 2..16 tokens, teal_amd/gpt_fast/prefill.py; longer prompts take the
 patched modules under a per-length hipGraph; --eager is the op-by-op pass), its milliseconds, and the tokens/s of the whole call.
 The prefill stays DENSE in all of them (kernels/sparse_gemv.py:271,298).  GPU box, through gpurun:
 
@@ -66,7 +66,7 @@ def main():
             base = t_pre
         note = "" if base is None or T <= 8 else f"   ({t_pre / base:.1f}x the 8-token pass)"
         print("%8d | %-42s %10.2f | %12.2f %10.1f | %14.2f%s" % (T, path, t_pre, w, a.max_new_tokens / w * 1e3, min(te), note))
-    print(f"# graphs held: {len(graphed.graphs)} module-path lengths (LRU, at most {graphed.MAX_GRAPHS}), {len(pre._graphs)} HIP-pass lengths (2..8 only)")
+    print(f"# graphs held: {len(graphed.graphs)} module-path lengths (LRU, at most {graphed.MAX_GRAPHS}), {len(pre._graphs)} HIP-pass lengths (2..16 only)")
 
 
 if __name__ == "__main__":

@@ -1,4 +1,4 @@
-// teal_prefill.hip — the DENSE prompt pass for short prompts (T <= 8 tokens), hand-fused for gfx950 / CDNA4, wave64.
+// teal_prefill.hip — the DENSE prompt pass for short prompts (T <= 16 tokens), hand-fused for gfx950 / CDNA4, wave64.
 //
 // The reference's prefill is dense by construction: its ops fall back to torch.matmul when the sequence is longer than one
 // token (kernels/sparse_gemv.py:271,298), and the rest of the prompt pass is the stock gpt-fast model (gpt-fast/model.py:
@@ -10,8 +10,10 @@
 //   gemm(wqkv) [RMSNorm while staging] -> attention (RoPE, cache rows 0..T-1, causal softmax) -> gemm(wo) -> resid ->
 //   gemm(w1 | w3) [RMSNorm while staging] -> gemm(w2) [silu * up while staging] -> resid
 //
-// Every hand-over between launches is TRANSPOSED: [feature][8] — the up to eight tokens of a feature are one 16-byte word
-// (16-bit activations) or one 32-byte pair (fp32 split-K slabs) — so that "row m of every token" is one word: a GEMM workgroup
+// Every hand-over between launches is TRANSPOSED: [feature][KR], KR = 8 for T <= 8 and 16 for 9 <= T <= 16 (round 6: prompts of
+// 9-16 tokens cost 2.1-2.2x the 8-token pass through the module path, profiles/r06_prefill_vs_prompt_length.txt) — the tokens of a
+// feature are one or two 16-byte words (16-bit activations) or KR / 4 of them (fp32 split-K slabs) — so that "row m of every
+// token" is contiguous: a GEMM workgroup
 // stages its slice's rows in LDS once, and a wave then fetches a row with one broadcast read.  The GEMM is bound by HBM like the GEMV (every weight
 // byte is read once for all tokens: 2 * T flops per byte, far from MFMA territory at T <= 8, and the reduction dimension is
 // the strided one in the W^T image, which rules the matrix cores' operand layout out without a second copy of the weights).
@@ -25,40 +27,73 @@ namespace teal {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kRows = 8;  // tokens per transposed word
+constexpr int kRowsMax = 16;  // most tokens a pass takes; a feature's row holds rows_for(T) of them
 constexpr int kPrefillMaxSplit = 16;
+constexpr int rows_for(const int T) { return T <= 8 ? 8 : 16; }
 
 // sum of `split` slabs in slice order, rounded once to the activation dtype: what a projection's 16-bit output tensor holds
-template <bool BF16>
+template <bool BF16, int KR>
 __device__ __forceinline__ void rounded_row(const float* __restrict__ slabs, const int split, const size_t n_total, const size_t col,
-                                            float (&out)[kRows]) {
-    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < split; k0 += 4) {  // four slices' loads in flight (clamped: a repeated slice is not added); slice order kept
-        f32x4 va[4], vb[4];
+                                            float (&out)[KR]) {
+    constexpr int NW = KR / 4, UU = KR == 8 ? 4 : 2;  // 16-byte words per row; slices whose loads are in flight together
+    f32x4 acc[NW];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float* p = slabs + ((size_t)min(k0 + u, split - 1) * n_total + col) * kRows;
-            va[u] = *reinterpret_cast<const f32x4*>(p);
-            vb[u] = *reinterpret_cast<const f32x4*>(p + 4);
+    for (int w = 0; w < NW; ++w) acc[w] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < split; k0 += UU) {  // (clamped: a repeated slice is not added); slice order kept
+        f32x4 v[UU][NW];
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            const float* p = slabs + ((size_t)min(k0 + u, split - 1) * n_total + col) * KR;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v[u][w] = *reinterpret_cast<const f32x4*>(p + 4 * w);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (k0 + u < split) { a += va[u]; b += vb[u]; }
+        for (int u = 0; u < UU; ++u) {
+            if (k0 + u < split) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) acc[w] += v[u][w];
+            }
         }
     }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        out[s] = bits_to_float(float_to_bits<BF16>(a[s]), BF16);
-        out[4 + s] = bits_to_float(float_to_bits<BF16>(b[s]), BF16);
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) out[4 * w + s] = bits_to_float(float_to_bits<BF16>(acc[w][s]), BF16);
+}
+
+// a feature's KR tokens as KR / 8 16-byte words of 16-bit values
+template <bool BF16, int KR>
+__device__ __forceinline__ void store_row(uint16_t* __restrict__ p, const float (&v)[KR]) {
+#pragma unroll
+    for (int w = 0; w < KR / 8; ++w) {
+        u32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            r[j] = (uint32_t)float_to_bits<BF16>(v[8 * w + 2 * j]) | ((uint32_t)float_to_bits<BF16>(v[8 * w + 2 * j + 1]) << 16);
+        *reinterpret_cast<u32x4*>(p + 8 * w) = r;
     }
 }
 
-template <bool BF16>
-__device__ __forceinline__ u32x4 pack_row(const float (&v)[kRows]) {
-    u32x4 r;
+template <bool BF16, int KR>
+__device__ __forceinline__ void load_row(const uint16_t* __restrict__ p, float (&x)[KR]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = (uint32_t)float_to_bits<BF16>(v[2 * j]) | ((uint32_t)float_to_bits<BF16>(v[2 * j + 1]) << 16);
-    return r;
+    for (int w = 0; w < KR / 8; ++w) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(p + 8 * w);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x[8 * w + 2 * j] = bits_to_float(v[j] & 0xFFFFu, BF16); x[8 * w + 2 * j + 1] = bits_to_float(v[j] >> 16, BF16); }
+    }
+}
+
+// 1 / rms per token from the per-workgroup sums of squares sumsq [nwg][KR] (lane = producing workgroup, nwg <= 64; the total in
+// workgroup order)
+template <int KR>
+__device__ __forceinline__ void rstd_rows(const float* __restrict__ sumsq, const int nwg, const int lane, const int Z, const float eps,
+                                          float (&rstd)[KR]) {
+    f32x4 pw[KR / 4];
+#pragma unroll
+    for (int w = 0; w < KR / 4; ++w) pw[w] = lane < nwg ? *reinterpret_cast<const f32x4*>(sumsq + (size_t)lane * KR + 4 * w) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KR; ++s) rstd[s] = rsqrtf(wave_sum_f(pw[s >> 2][s & 3]) / (float)Z + eps);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -88,14 +123,17 @@ struct PrefillProd {
     int nwg, gu_split, T;
 };
 
-template <bool BF16, int NP, int PROD>
+template <bool BF16, int NP, int PROD, int KR>
 __global__ __launch_bounds__(1024) void prefill_gemm_kernel(const PrefillProd pr, const uint16_t* __restrict__ w0, const int ld0,
                                                             const uint16_t* __restrict__ w1, const int ld1, const int tiles0,
                                                             float* __restrict__ slabs, const int Z, const int n_total) {
     const uint16_t* __restrict__ xt = pr.xt;
-    constexpr int WAVES = 16, CPL = 4, BN = 256, U = 8, PHASE_GROUPS = 128;  // 128 groups x 16 rows x 16 bytes = 32 KB of activations
+    // KR = 16 (9-16 tokens): twice the accumulators per lane, so half the weight rows in flight per batch (the loop is bound by
+    // its multiply-adds there, not by the loads) and half the row groups per staging phase (the same 32 KB of activations)
+    constexpr int WAVES = 16, CPL = 4, BN = 256, U = KR == 8 ? 8 : 4, KW = KR / 8, PHASE_GROUPS = 1024 / KR;
+    static_assert(NP <= KR / 2 && NP > (KR == 8 ? 0 : 4), "token pairs of this row width");
     extern __shared__ __align__(16) unsigned char smem[];
-    u32x4* xs = reinterpret_cast<u32x4*>(smem);   // the slice's activation rows of the current phase: xs[j * 16 + wave]
+    u32x4* xs = reinterpret_cast<u32x4*>(smem);   // the slice's activation rows of the current phase: xs[(j * 16 + wave) * KW + word]
     float* red = reinterpret_cast<float*>(smem);  // epilogue (after a barrier): [WAVES][BN][2], one token pair per round
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x, slice = blockIdx.y, split = gridDim.y;
@@ -112,10 +150,10 @@ __global__ __launch_bounds__(1024) void prefill_gemm_kernel(const PrefillProd pr
     for (int c = 0; c < CPL; ++c)
 #pragma unroll
         for (int p = 0; p < NP; ++p) acc[c][p] = (f32x2){0.0f, 0.0f};
-    auto consume = [&](const u32x2 w, const u32x4 xv) {
+    auto consume = [&](const u32x2 w, const u32x4 (&xv)[KW]) {
         f32x2 xp[NP];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) xp[p] = (f32x2){bits_to_float(xv[p] & 0xFFFFu, BF16), bits_to_float(xv[p] >> 16, BF16)};
+        for (int p = 0; p < NP; ++p) xp[p] = (f32x2){bits_to_float(xv[p >> 2][p & 3] & 0xFFFFu, BF16), bits_to_float(xv[p >> 2][p & 3] >> 16, BF16)};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float wl = bits_to_float(w[j] & 0xFFFFu, BF16), wh = bits_to_float(w[j] >> 16, BF16);
@@ -136,42 +174,34 @@ __global__ __launch_bounds__(1024) void prefill_gemm_kernel(const PrefillProd pr
         //  measured: the 16 registers it keeps live through the producers push the kernel to 126-128 registers with spills, and
         //  the gate | up launch went 41 -> 48 us; profiles/r05_prefill_kernel_stats.txt)
         if (jb) __syncthreads();
-        [[maybe_unused]] float rstd[kRows];
-        if constexpr (PROD == 1) {  // lane = producing workgroup of the resid launch (nwg <= 64); the total in workgroup order
-            f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
-            if (lane < pr.nwg) {
-                pa = *reinterpret_cast<const f32x4*>(pr.sumsq + (size_t)lane * kRows);
-                pb = *reinterpret_cast<const f32x4*>(pr.sumsq + (size_t)lane * kRows + 4);
-            }
-#pragma unroll
-            for (int s_ = 0; s_ < kRows; ++s_) rstd[s_] = rsqrtf(wave_sum_f(s_ < 4 ? pa[s_ & 3] : pb[s_ & 3]) / (float)Z + pr.eps);
-        }
+        [[maybe_unused]] float rstd[KR];
+        if constexpr (PROD == 1) rstd_rows<KR>(pr.sumsq, pr.nwg, lane, Z, pr.eps, rstd);
         for (int r = tid; r < njp * 16; r += 1024) {
             const uint32_t m = (uint32_t)(slice + split * (jb + (r >> 4))) * 16u + (uint32_t)(r & 15);
+            [[maybe_unused]] uint16_t* dst = reinterpret_cast<uint16_t*>(xs + (size_t)r * KW);
             if constexpr (PROD == 0) {
-                xs[r] = *reinterpret_cast<const u32x4*>(xt + (size_t)m * kRows);
+#pragma unroll
+                for (int w = 0; w < KW; ++w) xs[(size_t)r * KW + w] = *reinterpret_cast<const u32x4*>(xt + (size_t)m * KR + 8 * w);
             } else if constexpr (PROD == 1) {  // x = round(round(h * rstd) * w)  (gpt-fast/model.py:289-291)
-                const u32x4 v = *reinterpret_cast<const u32x4*>(xt + (size_t)m * kRows);
                 const float nw = bits_to_float(pr.norm_w[m], BF16);
-                float x[kRows];
+                float x[KR];
+                load_row<BF16, KR>(xt + (size_t)m * KR, x);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { x[2 * j] = bits_to_float(v[j] & 0xFFFFu, BF16); x[2 * j + 1] = bits_to_float(v[j] >> 16, BF16); }
-#pragma unroll
-                for (int s_ = 0; s_ < kRows; ++s_) {
+                for (int s_ = 0; s_ < KR; ++s_) {
                     const float xn = bits_to_float(float_to_bits<BF16>(x[s_] * rstd[s_]), BF16);
                     x[s_] = s_ < pr.T ? bits_to_float(float_to_bits<BF16>(xn * nw), BF16) : 0.0f;
                 }
-                xs[r] = pack_row<BF16>(x);
+                store_row<BF16, KR>(dst, x);
             } else {  // x = round(round(silu(round(gate))) * round(up))  (gpt-fast/model.py:258-259)
-                float gv[kRows], uv[kRows], x[kRows];
-                rounded_row<BF16>(pr.gu, pr.gu_split, (size_t)2 * Z, (size_t)m, gv);
-                rounded_row<BF16>(pr.gu, pr.gu_split, (size_t)2 * Z, (size_t)Z + m, uv);
+                float gv[KR], uv[KR], x[KR];
+                rounded_row<BF16, KR>(pr.gu, pr.gu_split, (size_t)2 * Z, (size_t)m, gv);
+                rounded_row<BF16, KR>(pr.gu, pr.gu_split, (size_t)2 * Z, (size_t)Z + m, uv);
 #pragma unroll
-                for (int s_ = 0; s_ < kRows; ++s_) {
+                for (int s_ = 0; s_ < KR; ++s_) {
                     const float sl = bits_to_float(float_to_bits<BF16>(gv[s_] / (1.0f + expf(-gv[s_]))), BF16);
                     x[s_] = s_ < pr.T ? bits_to_float(float_to_bits<BF16>(sl * uv[s_]), BF16) : 0.0f;
                 }
-                xs[r] = pack_row<BF16>(x);
+                store_row<BF16, KR>(dst, x);
             }
         }
         __syncthreads();
@@ -187,8 +217,12 @@ __global__ __launch_bounds__(1024) void prefill_gemm_kernel(const PrefillProd pr
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int j = decltype(guard)::value ? min(j0 + u, njp - 1) : j0 + u;
-                u32x4 xv = xs[j * 16 + wave];  // wave-uniform address: one LDS broadcast read
-                if (decltype(guard)::value && j0 + u >= njp) xv = (u32x4){0u, 0u, 0u, 0u};
+                u32x4 xv[KW];
+#pragma unroll
+                for (int q = 0; q < KW; ++q) {
+                    xv[q] = xs[(j * 16 + wave) * KW + q];  // wave-uniform address: one LDS broadcast read per word
+                    if (decltype(guard)::value && j0 + u >= njp) xv[q] = (u32x4){0u, 0u, 0u, 0u};
+                }
                 consume(w[u], xv);
             }
         };
@@ -212,7 +246,7 @@ __global__ __launch_bounds__(1024) void prefill_gemm_kernel(const PrefillProd pr
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (j0 < njp) {  // the partial pair: one guarded batch if eight rows or fewer remain, else two
+        if (j0 < njp) {  // the partial pair: one guarded batch if U rows or fewer remain, else two
             issue(wa, j0, guarded);
             const bool two = j0 + U < njp;
             if (two) issue(wb, j0 + U, guarded);
@@ -234,7 +268,7 @@ __global__ __launch_bounds__(1024) void prefill_gemm_kernel(const PrefillProd pr
             float sum = 0.0f;
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) sum += red[((size_t)w * BN + col) * 2 + e];
-            slabs[((size_t)slice * n_total + col_base + col) * kRows + 2 * p + e] = sum;
+            slabs[((size_t)slice * n_total + col_base + col) * KR + 2 * p + e] = sum;
         }
     }
 }
@@ -247,131 +281,127 @@ __global__ __launch_bounds__(1024) void prefill_gemm_kernel(const PrefillProd pr
 //   prefill_norm_kernel   every wave adds the workgroups' sums itself (lane = workgroup), x -> xt_out [dim][8] and, optionally,
 //                         the normalised vector of token `last` as a plain [dim] vector (the lm_head of the prompt's last token)
 // ------------------------------------------------------------------------------------------------
-template <bool BF16>
+template <bool BF16, int KR>
 __global__ __launch_bounds__(256) void prefill_resid_kernel(const uint16_t* __restrict__ emb, const int32_t* __restrict__ tokens, const int T,
                                                             const uint16_t* __restrict__ ht_in, const float* __restrict__ slabs,
                                                             const int split, const int dim, uint16_t* __restrict__ ht_out,
                                                             float* __restrict__ sumsq) {
-    __shared__ float part[4][kRows];
+    __shared__ float part[4][KR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = blockIdx.x * 256 + tid;
-    float h[kRows];
+    float h[KR];
 #pragma unroll
-    for (int s = 0; s < kRows; ++s) h[s] = 0.0f;
+    for (int s = 0; s < KR; ++s) h[s] = 0.0f;
     if (col < dim) {
         if (tokens) {
 #pragma unroll
-            for (int s = 0; s < kRows; ++s) h[s] = bits_to_float(emb[(size_t)tokens[min(s, T - 1)] * dim + col], BF16);
+            for (int s = 0; s < KR; ++s) h[s] = bits_to_float(emb[(size_t)tokens[min(s, T - 1)] * dim + col], BF16);
         } else {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(ht_in + (size_t)col * kRows);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { h[2 * j] = bits_to_float(v[j] & 0xFFFFu, BF16); h[2 * j + 1] = bits_to_float(v[j] >> 16, BF16); }
+            load_row<BF16, KR>(ht_in + (size_t)col * KR, h);
         }
         if (split > 0) {
-            float y[kRows];
-            rounded_row<BF16>(slabs, split, (size_t)dim, (size_t)col, y);
+            float y[KR];
+            rounded_row<BF16, KR>(slabs, split, (size_t)dim, (size_t)col, y);
 #pragma unroll
-            for (int s = 0; s < kRows; ++s) h[s] = bits_to_float(float_to_bits<BF16>(h[s] + y[s]), BF16);
+            for (int s = 0; s < KR; ++s) h[s] = bits_to_float(float_to_bits<BF16>(h[s] + y[s]), BF16);
         }
 #pragma unroll
-        for (int s = 0; s < kRows; ++s) h[s] = s < T ? h[s] : 0.0f;
-        *reinterpret_cast<u32x4*>(ht_out + (size_t)col * kRows) = pack_row<BF16>(h);
+        for (int s = 0; s < KR; ++s) h[s] = s < T ? h[s] : 0.0f;
+        store_row<BF16, KR>(ht_out + (size_t)col * KR, h);
     }
 #pragma unroll
-    for (int s = 0; s < kRows; ++s) {
+    for (int s = 0; s < KR; ++s) {
         const float w = wave_sum_f(h[s] * h[s]);
         if (lane == 0) part[wave][s] = w;
     }
     __syncthreads();
-    if (tid < kRows) sumsq[(size_t)blockIdx.x * kRows + tid] = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+    if (tid < KR) sumsq[(size_t)blockIdx.x * KR + tid] = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
 }
 
-template <bool BF16>
+template <bool BF16, int KR>
 __global__ __launch_bounds__(256) void prefill_norm_kernel(const uint16_t* __restrict__ ht, const float* __restrict__ sumsq, const int nwg,
                                                            const uint16_t* __restrict__ norm_w, const float eps, const int dim, const int T,
                                                            uint16_t* __restrict__ xt_out, uint16_t* __restrict__ x_last, const int last) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int col = blockIdx.x * 256 + tid;
-    // lane = producing workgroup (nwg = dim / 256 <= 64): its eight sums are two 16-byte loads; the total in workgroup order
-    f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
-    if (lane < nwg) {
-        pa = *reinterpret_cast<const f32x4*>(sumsq + (size_t)lane * kRows);
-        pb = *reinterpret_cast<const f32x4*>(sumsq + (size_t)lane * kRows + 4);
-    }
-    float rstd[kRows];
-#pragma unroll
-    for (int s = 0; s < kRows; ++s) rstd[s] = rsqrtf(wave_sum_f(s < 4 ? pa[s & 3] : pb[s & 3]) / (float)dim + eps);
+    float rstd[KR];
+    rstd_rows<KR>(sumsq, nwg, lane, dim, eps, rstd);
     if (col >= dim) return;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(ht + (size_t)col * kRows);
     const float nw = bits_to_float(norm_w[col], BF16);
-    float x[kRows];
+    float x[KR];
+    load_row<BF16, KR>(ht + (size_t)col * KR, x);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { x[2 * j] = bits_to_float(v[j] & 0xFFFFu, BF16); x[2 * j + 1] = bits_to_float(v[j] >> 16, BF16); }
-#pragma unroll
-    for (int s = 0; s < kRows; ++s) {
+    for (int s = 0; s < KR; ++s) {
         const float xn = bits_to_float(float_to_bits<BF16>(x[s] * rstd[s]), BF16);
         x[s] = s < T ? bits_to_float(float_to_bits<BF16>(xn * nw), BF16) : 0.0f;
     }
-    if (xt_out) *reinterpret_cast<u32x4*>(xt_out + (size_t)col * kRows) = pack_row<BF16>(x);
+    if (xt_out) store_row<BF16, KR>(xt_out + (size_t)col * KR, x);
     if (x_last) {
         float xl = 0.0f;
 #pragma unroll
-        for (int s = 0; s < kRows; ++s) xl = s == last ? x[s] : xl;
+        for (int s = 0; s < KR; ++s) xl = s == last ? x[s] : xl;
         x_last[col] = float_to_bits<BF16>(xl);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Attention of the prompt's T <= 8 tokens at positions 0 .. T-1 (gpt-fast/model.py:170-186): q | k | v from the slabs of the wqkv
+// Attention of the prompt's T <= KR tokens at positions 0 .. T-1 (gpt-fast/model.py:170-186): q | k | v from the slabs of the wqkv
 // launch, RoPE(q, k), cache rows 0 .. T-1, causal softmax(q K^T / sqrt(d)) V.  One workgroup per query head, thread d = column d
-// of the head (all T tokens in registers); the first query head of a KV group writes the cache rows.  yt[n_head * hd][8].
+// of the head (all T tokens in registers); the first query head of a KV group writes the cache rows.  yt[n_head * hd][KR].
 // ------------------------------------------------------------------------------------------------
-template <bool BF16, int HD>
+template <bool BF16, int HD, int KR>
 __global__ __launch_bounds__(HD) void prefill_attention_kernel(const float* __restrict__ slabs, const int split, const int n_head,
                                                                const int n_kv, const int T, const uint16_t* __restrict__ rope,
                                                                uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache,
                                                                const int max_seq, const float scale, uint16_t* __restrict__ yt) {
-    __shared__ float qs[kRows][HD + 1], ks[kRows][HD + 1], sc[kRows][kRows], ls[kRows];
+    __shared__ float qs[KR][HD + 1], ks[KR][HD + 1], sc[KR][KR], ls[KR];
     const int h = blockIdx.x, d = threadIdx.x, rep = n_head / n_kv, kvh = h / rep;
     const size_t nq = (size_t)n_head * HD, nkv = (size_t)n_kv * HD, ntot = nq + 2 * nkv;
-    float q[kRows], k[kRows], v[kRows];
-    {   // the three columns' slabs together: four slices x three columns of loads in flight per round, slice order kept
+    float q[KR], k[KR], v[KR];
+    {   // the three columns' slabs together: UU slices x three columns of loads in flight per round, slice order kept
+        constexpr int NW = KR / 4, UU = KR == 8 ? 4 : 2;
         const size_t cols[3] = {(size_t)h * HD + d, nq + (size_t)kvh * HD + d, nq + nkv + (size_t)kvh * HD + d};
-        f32x4 sa[3], sb[3];
+        f32x4 sa[3][NW];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { sa[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; sb[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        for (int k0 = 0; k0 < split; k0 += 4) {
-            f32x4 va[4][3], vb[4][3];
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int w = 0; w < NW; ++w) sa[c][w] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < split; k0 += UU) {
+            f32x4 va[UU][3][NW];
+#pragma unroll
+            for (int u = 0; u < UU; ++u)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float* p = slabs + ((size_t)min(k0 + u, split - 1) * ntot + cols[c]) * kRows;
-                    va[u][c] = *reinterpret_cast<const f32x4*>(p);
-                    vb[u][c] = *reinterpret_cast<const f32x4*>(p + 4);
+                    const float* p = slabs + ((size_t)min(k0 + u, split - 1) * ntot + cols[c]) * KR;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) va[u][c][w] = *reinterpret_cast<const f32x4*>(p + 4 * w);
                 }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < UU; ++u)
                 if (k0 + u < split) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) { sa[c] += va[u][c]; sb[c] += vb[u][c]; }
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) sa[c][w] += va[u][c][w];
                 }
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            q[s] = bits_to_float(float_to_bits<BF16>(sa[0][s]), BF16); q[4 + s] = bits_to_float(float_to_bits<BF16>(sb[0][s]), BF16);
-            k[s] = bits_to_float(float_to_bits<BF16>(sa[1][s]), BF16); k[4 + s] = bits_to_float(float_to_bits<BF16>(sb[1][s]), BF16);
-            v[s] = bits_to_float(float_to_bits<BF16>(sa[2][s]), BF16); v[4 + s] = bits_to_float(float_to_bits<BF16>(sb[2][s]), BF16);
-        }
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                q[4 * w + s] = bits_to_float(float_to_bits<BF16>(sa[0][w][s]), BF16);
+                k[4 * w + s] = bits_to_float(float_to_bits<BF16>(sa[1][w][s]), BF16);
+                v[4 * w + s] = bits_to_float(float_to_bits<BF16>(sa[2][w][s]), BF16);
+            }
     }
 #pragma unroll
-    for (int s = 0; s < kRows; ++s) {  // (token slots past T hold whatever the slabs held: keep them out of every sum)
+    for (int s = 0; s < KR; ++s) {  // (token slots past T hold whatever the slabs held: keep them out of every sum)
         q[s] = s < T ? q[s] : 0.0f;
         k[s] = s < T ? k[s] : 0.0f;
         v[s] = s < T ? v[s] : 0.0f;
     }
 #pragma unroll
-    for (int s = 0; s < kRows; ++s) {
+    for (int s = 0; s < KR; ++s) {
         const uint32_t cs = *reinterpret_cast<const uint32_t*>(rope + ((size_t)min(s, max_seq - 1) * (HD / 2) + (d >> 1)) * 2);
         const float c = bits_to_float(cs & 0xFFFFu, BF16), sn = bits_to_float(cs >> 16, BF16);
         const float qp = __shfl_xor(q[s], 1), kp = __shfl_xor(k[s], 1);
@@ -385,8 +415,8 @@ __global__ __launch_bounds__(HD) void prefill_attention_kernel(const float* __re
         }
     }
     __syncthreads();
-    if (d < kRows * kRows) {  // one (query, key) pair per thread: the causal half only
-        const int s = d / kRows, t = d % kRows;
+    for (int pq = d; pq < KR * KR; pq += HD) {  // one (query, key) pair per thread and round: the causal half only
+        const int s = pq / KR, t = pq % KR;
         float a = 0.0f;
         if (t <= s && s < T) {
             for (int j = 0; j < HD; ++j) a = fmaf(qs[s][j], ks[t][j], a);
@@ -395,11 +425,11 @@ __global__ __launch_bounds__(HD) void prefill_attention_kernel(const float* __re
         sc[s][t] = a;
     }
     __syncthreads();
-    if (d < kRows) {
+    if (d < KR) {
         const int s = d;
         float mx = -INFINITY, l = 0.0f;
         for (int t = 0; t <= s; ++t) mx = fmaxf(mx, sc[s][t]);
-        for (int t = 0; t < kRows; ++t) {
+        for (int t = 0; t < KR; ++t) {
             const float e = t <= s ? expf(sc[s][t] - mx) : 0.0f;
             sc[s][t] = e;
             l += e;
@@ -407,15 +437,15 @@ __global__ __launch_bounds__(HD) void prefill_attention_kernel(const float* __re
         ls[s] = l;
     }
     __syncthreads();
-    float o[kRows];
+    float o[KR];
 #pragma unroll
-    for (int s = 0; s < kRows; ++s) {
+    for (int s = 0; s < KR; ++s) {
         float a = 0.0f;
 #pragma unroll
-        for (int t = 0; t < kRows; ++t) a = fmaf(sc[s][t], v[t], a);
+        for (int t = 0; t < KR; ++t) a = fmaf(sc[s][t], v[t], a);
         o[s] = s < T ? bits_to_float(float_to_bits<BF16>(a / ls[s]), BF16) : 0.0f;
     }
-    *reinterpret_cast<u32x4*>(yt + ((size_t)h * HD + d) * kRows) = pack_row<BF16>(o);
+    store_row<BF16, KR>(yt + ((size_t)h * HD + d) * KR, o);
 }
 
 }  // namespace teal
@@ -428,7 +458,8 @@ int teal_prefill_gemm(const teal_prefill_in_t* in, const void* w0T, int ld0, int
                       size_t slabs_bytes, int Z, int T, int dtype, int* split_out, void* stream) {
     if (!in || !w0T || !slabs || !split_out || Z <= 0 || n0 <= 0 || n1 < 0 || (n1 > 0 && !w1T)) return TEAL_ERR_ARG;
     if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
-    if (T < 1 || T > kRows || (Z & 255) || Z > 65536 || (ld0 & 7) || (ld1 & 7) || ld0 < n0 || (n1 > 0 && ld1 < n1)) return TEAL_ERR_SHAPE;
+    if (T < 1 || T > kRowsMax || (Z & 255) || Z > 65536 || (ld0 & 7) || (ld1 & 7) || ld0 < n0 || (n1 > 0 && ld1 < n1)) return TEAL_ERR_SHAPE;
+    const int kr = rows_for(T);
     PrefillProd pr = {};
     pr.T = T;
     switch (in->mode) {
@@ -467,16 +498,18 @@ int teal_prefill_gemm(const teal_prefill_in_t* in, const void* w0T, int ld0, int
         const int batches = ((ngroups + c - 1) / c + 7) / 8;
         if (batches < best) { best = batches; split = c; }
     }
-    if (slabs_bytes < (size_t)split * ntot * kRows * sizeof(float)) return TEAL_ERR_WORKSPACE;
+    if (slabs_bytes < (size_t)split * ntot * kr * sizeof(float)) return TEAL_ERR_WORKSPACE;
     const dim3 grid(tiles, split), block(1024);
     const size_t lds = (size_t)16 * bn * 2 * sizeof(float);  // 32 KB: the activation rows of a phase, then the reduction tile
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int np = (T + 1) / 2, tiles0 = n0 / bn;
     auto* a = reinterpret_cast<const uint16_t*>(w0T);
     auto* b = reinterpret_cast<const uint16_t*>(w1T);
-#define TEAL_PG(BF, NPV, PR) hipLaunchKernelGGL((prefill_gemm_kernel<BF, NPV, PR>), grid, block, lds, st, pr, a, ld0, b, ld1, tiles0, slabs, Z, ntot)
-#define TEAL_PG_PR(BF, NPV) do { if (in->mode == TEAL_PREFILL_IN_NORM) TEAL_PG(BF, NPV, 1); else if (in->mode == TEAL_PREFILL_IN_SILU_MUL) TEAL_PG(BF, NPV, 2); else TEAL_PG(BF, NPV, 0); } while (0)
-#define TEAL_PG_NP(BF) do { switch (np) { case 1: TEAL_PG_PR(BF, 1); break; case 2: TEAL_PG_PR(BF, 2); break; case 3: TEAL_PG_PR(BF, 3); break; default: TEAL_PG_PR(BF, 4); } } while (0)
+#define TEAL_PG(BF, NPV, PR, KRV) hipLaunchKernelGGL((prefill_gemm_kernel<BF, NPV, PR, KRV>), grid, block, lds, st, pr, a, ld0, b, ld1, tiles0, slabs, Z, ntot)
+#define TEAL_PG_PR(BF, NPV, KRV) do { if (in->mode == TEAL_PREFILL_IN_NORM) TEAL_PG(BF, NPV, 1, KRV); else if (in->mode == TEAL_PREFILL_IN_SILU_MUL) TEAL_PG(BF, NPV, 2, KRV); else TEAL_PG(BF, NPV, 0, KRV); } while (0)
+#define TEAL_PG_NP(BF) do { switch (np) { case 1: TEAL_PG_PR(BF, 1, 8); break; case 2: TEAL_PG_PR(BF, 2, 8); break; case 3: TEAL_PG_PR(BF, 3, 8); break; \
+    case 4: TEAL_PG_PR(BF, 4, 8); break; case 5: TEAL_PG_PR(BF, 5, 16); break; case 6: TEAL_PG_PR(BF, 6, 16); break; case 7: TEAL_PG_PR(BF, 7, 16); break; \
+    default: TEAL_PG_PR(BF, 8, 16); } } while (0)
     if (dtype == TEAL_BF16) TEAL_PG_NP(true); else TEAL_PG_NP(false);
 #undef TEAL_PG_NP
 #undef TEAL_PG_PR
@@ -491,7 +524,7 @@ int teal_prefill_resid_norm(const void* emb, const int32_t* tokens, int T, const
     if ((!tokens) == (!ht_in) || (tokens && !emb) || ((xt_out || x_last) && !norm_w) || !ht_out || !sumsq_scratch || dim <= 0 || split < 0 || (split > 0 && !slabs))
         return TEAL_ERR_ARG;
     if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
-    if (T < 1 || T > kRows || dim > 16384) return TEAL_ERR_SHAPE;
+    if (T < 1 || T > kRowsMax || dim > 16384) return TEAL_ERR_SHAPE;
     if (!device_ctx()) return TEAL_ERR_NO_DEVICE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nwg = (dim + 255) / 256;  // <= 64
@@ -501,13 +534,12 @@ int teal_prefill_resid_norm(const void* emb, const int32_t* tokens, int T, const
     auto* nw = reinterpret_cast<const uint16_t*>(norm_w);
     auto* xo = reinterpret_cast<uint16_t*>(xt_out);
     auto* xl = reinterpret_cast<uint16_t*>(x_last);
-    if (dtype == TEAL_BF16) {
-        hipLaunchKernelGGL((prefill_resid_kernel<true>), dim3(nwg), dim3(256), 0, st, e, tokens, T, hi, slabs, split, dim, ho, sumsq_scratch);
-        if (xo || xl) hipLaunchKernelGGL((prefill_norm_kernel<true>), dim3(nwg), dim3(256), 0, st, ho, sumsq_scratch, nwg, nw, eps, dim, T, xo, xl, T - 1);
-    } else {
-        hipLaunchKernelGGL((prefill_resid_kernel<false>), dim3(nwg), dim3(256), 0, st, e, tokens, T, hi, slabs, split, dim, ho, sumsq_scratch);
-        if (xo || xl) hipLaunchKernelGGL((prefill_norm_kernel<false>), dim3(nwg), dim3(256), 0, st, ho, sumsq_scratch, nwg, nw, eps, dim, T, xo, xl, T - 1);
-    }
+#define TEAL_PR(BF, KRV) do { \
+        hipLaunchKernelGGL((prefill_resid_kernel<BF, KRV>), dim3(nwg), dim3(256), 0, st, e, tokens, T, hi, slabs, split, dim, ho, sumsq_scratch); \
+        if (xo || xl) hipLaunchKernelGGL((prefill_norm_kernel<BF, KRV>), dim3(nwg), dim3(256), 0, st, ho, sumsq_scratch, nwg, nw, eps, dim, T, xo, xl, T - 1); } while (0)
+    if (dtype == TEAL_BF16) { if (rows_for(T) == 8) TEAL_PR(true, 8); else TEAL_PR(true, 16); }
+    else { if (rows_for(T) == 8) TEAL_PR(false, 8); else TEAL_PR(false, 16); }
+#undef TEAL_PR
     return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
 }
 
@@ -515,14 +547,16 @@ int teal_prefill_attention(const float* qkv_slabs, int split, const void* rope, 
                            int n_kv_head, int head_dim, int max_seq, int dtype, void* stream) {
     if (!qkv_slabs || !rope || !k_cache || !v_cache || !yt || split < 1) return TEAL_ERR_ARG;
     if (dtype != TEAL_F16 && dtype != TEAL_BF16) return TEAL_ERR_DTYPE;
-    if ((head_dim != 64 && head_dim != 128) || n_head <= 0 || n_kv_head <= 0 || n_head % n_kv_head || T < 1 || T > kRows || max_seq < T)
+    if ((head_dim != 64 && head_dim != 128) || n_head <= 0 || n_kv_head <= 0 || n_head % n_kv_head || T < 1 || T > kRowsMax || max_seq < T)
         return TEAL_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const float scale = 1.0f / sqrtf((float)head_dim);
-#define TEAL_PA(BF, HDV) hipLaunchKernelGGL((prefill_attention_kernel<BF, HDV>), dim3(n_head), dim3(HDV), 0, st, qkv_slabs, split, n_head, n_kv_head, T, \
+#define TEAL_PA(BF, HDV, KRV) hipLaunchKernelGGL((prefill_attention_kernel<BF, HDV, KRV>), dim3(n_head), dim3(HDV), 0, st, qkv_slabs, split, n_head, n_kv_head, T, \
     reinterpret_cast<const uint16_t*>(rope), reinterpret_cast<uint16_t*>(k_cache), reinterpret_cast<uint16_t*>(v_cache), max_seq, scale, reinterpret_cast<uint16_t*>(yt))
-    if (dtype == TEAL_BF16) { if (head_dim == 128) TEAL_PA(true, 128); else TEAL_PA(true, 64); }
-    else { if (head_dim == 128) TEAL_PA(false, 128); else TEAL_PA(false, 64); }
+#define TEAL_PA_KR(BF, HDV) do { if (rows_for(T) == 8) TEAL_PA(BF, HDV, 8); else TEAL_PA(BF, HDV, 16); } while (0)
+    if (dtype == TEAL_BF16) { if (head_dim == 128) TEAL_PA_KR(true, 128); else TEAL_PA_KR(true, 64); }
+    else { if (head_dim == 128) TEAL_PA_KR(false, 128); else TEAL_PA_KR(false, 64); }
+#undef TEAL_PA_KR
 #undef TEAL_PA
     return hipGetLastError() == hipSuccess ? TEAL_OK : TEAL_ERR_LAUNCH;
 }

@@ -1,4 +1,4 @@
-"""The prompt pass of a SHORT prompt (T <= 8 tokens) as hand-fused HIP launches — dense, like the reference's.
+"""The prompt pass of a SHORT prompt (T <= 16 tokens) as hand-fused HIP launches — dense, like the reference's.
 
 The reference's prefill is dense by construction: `SparseGEMV.forward` / `SparseQKVGEMV.forward` run `torch.matmul(x, W.T)`
 when the sequence is longer than one token (kernels/sparse_gemv.py:271,298) inside the stock gpt-fast forward
@@ -13,7 +13,9 @@ decode step's own weight images (teal_amd/csrc/teal_prefill.hip):
 
 and returns logits [1, 1, vocab] of the last prompt token (all `generate()` samples from).  Nothing is sparsified: thresholds
 play no role in the prompt pass.  `FusedPrefill` is what generate() calls: the HIP pass (replayed from a hipGraph per prompt
-length) where it applies — 16-bit weights, one GPU, 2 <= T <= 8, positions 0..T-1 — and the module path otherwise.
+length) where it applies — 16-bit weights, one GPU, 2 <= T <= 16, positions 0..T-1 — and the module path otherwise.
+Round 6: 9-16 tokens (two 16-byte words per feature in the hand-over layout) — they cost 2.1-2.2x the 8-token pass through the
+module path (profiles/r06_prefill_vs_prompt_length.txt).
 """
 from __future__ import annotations
 
@@ -26,7 +28,7 @@ from .. import _lib, runtime
 from ..monkeypatch import UP_SHIFT_BYTES, to_column_major
 from .model import Transformer
 
-MAX_T = 8  # tokens per transposed word of the hand-over layout ([feature][8])
+MAX_T = 16  # most tokens of a pass; the hand-over layout is [feature][8] for T <= 8 and [feature][16] for 9 <= T <= 16 (buffers sized for 16)
 IN_XT, IN_NORM, IN_SILU_MUL = 0, 1, 2
 
 
@@ -86,7 +88,7 @@ class PrefillEngine:
         z = lambda *shape, dtype=dt: torch.zeros(*shape, device=dev, dtype=dtype)  # noqa: E731
         self.tokens = z(MAX_T, dtype=torch.int32)
         self.ht, self.yt = z(self.dim, MAX_T), z(self.dim, MAX_T)
-        # two slab buffers [slices <= 16][columns][8] fp32, used alternately (launches are stream-ordered: a consumer has read its
+        # two slab buffers [slices <= 16][columns][8 or 16] fp32, used alternately (launches are stream-ordered: a consumer has read its
         # producer's slabs before the next-but-one GEMM overwrites them; the down projection reads gate | up's while writing its own)
         n = 16 * max(self.nqkv, 2 * self.inter, self.dim) * MAX_T
         self.slabs = [z(n, dtype=torch.float32), z(n, dtype=torch.float32)]
@@ -134,7 +136,7 @@ class PrefillEngine:
 
     @torch.no_grad()
     def __call__(self, prompt: torch.Tensor) -> torch.Tensor:
-        """prompt: int tokens [T], 1 <= T <= 8, occupying positions 0 .. T-1 -> logits [1, 1, vocab] of the last token; the KV
+        """prompt: int tokens [T], 1 <= T <= 16, occupying positions 0 .. T-1 -> logits [1, 1, vocab] of the last token; the KV
         rows 0 .. T-1 of every layer are written."""
         T = int(prompt.numel())
         assert 1 <= T <= MAX_T and T <= self.max_seq

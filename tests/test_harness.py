@@ -255,7 +255,7 @@ def test_generate_main_synthetic_cli(extra):
 
 @pytest.mark.gpu
 def test_compile_prefill_generates_the_same_tokens():
-    """--compile captures the prompt pass too (the hand-fused HIP pass for <= 8 tokens, the patched modules under a hipGraph
+    """--compile captures the prompt pass too (the hand-fused HIP pass for <= 16 tokens, the patched modules under a hipGraph
     otherwise): the prefill graph is captured before the engine exists; the engine then re-lays the weights out (freeing the
     storage a stale graph would still point at).  Every timed sample must produce the tokens of the run WITHOUT a prefill graph
     (--eager_prefill: the op-by-op pass), across several samples (allocator reuse in between) — for the default pass and for

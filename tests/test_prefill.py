@@ -3,7 +3,8 @@
 Reference semantics: the prefill branch of the ops is a dense matmul (kernels/sparse_gemv.py:271,298) inside the stock gpt-fast
 forward (gpt-fast/model.py:107-121,158-186,258-259,289-291).  Floating-point kernels, so:
   * the GEMM launch against oracle.truth64 with every row kept, token by token (SURVEY 8(c) tolerance: 1e-3 * max(1, |truth|) +
-    one output ulp), through the C ABI, at the projections' real shapes incl. the two-image gate | up launch, T = 1, 6, 8;
+    one output ulp), through the C ABI, at the projections' real shapes incl. the two-image gate | up launch, T = 1, 6, 8 (one
+    16-byte word per feature) and 9, 12, 16 (two);
   * the whole pass against the module path (the torch fp32-accumulating reference of the same ops): last-token logits within a
     few output ulps of their scale, the KV rows of every layer, the first sampled token of generate().
 """
@@ -38,10 +39,11 @@ def test_prefill_gemm_vs_oracle(oracle, Z, n0, n1, dtype):
     W0 = _image(w0b, Z, n0, dtype)
     W1 = _image(w1b, Z, n1, dtype) if n1 else None
     ntot = n0 + n1
-    slabs = torch.full((16 * ntot * 8,), float("nan"), device=DEV, dtype=torch.float32)
-    for T in (1, 6, 8):
+    slabs = torch.full((16 * ntot * 16,), float("nan"), device=DEV, dtype=torch.float32)
+    for T in (1, 6, 8, 9, 12, 16):
+        R = 8 if T <= 8 else 16  # tokens per feature row of the hand-over layout
         xs = [O.hash_uniform(Z, 500 + 10 * T + s, 2.0, dtype) for s in range(T)]
-        xt = torch.zeros(Z, 8, device=DEV, dtype=W0.dtype)
+        xt = torch.zeros(Z, R, device=DEV, dtype=W0.dtype)
         for s in range(T):
             xt[:, s] = torch_from_bits(xs[s], dtype, DEV)
         split = ctypes.c_int(0)
@@ -50,8 +52,8 @@ def test_prefill_gemm_vs_oracle(oracle, Z, n0, n1, dtype):
                                  slabs.data_ptr(), slabs.numel() * 4, Z, T, dtype, ctypes.byref(split), runtime.stream_ptr())
         assert rc == 0 and 1 <= split.value <= 16
         torch.cuda.synchronize()
-        v = slabs[: split.value * ntot * 8].view(split.value, ntot, 8)
-        acc = torch.zeros(ntot, 8, device=DEV, dtype=torch.float32)
+        v = slabs[: split.value * ntot * R].view(split.value, ntot, R)
+        acc = torch.zeros(ntot, R, device=DEV, dtype=torch.float32)
         for k in range(split.value):  # slice order, as the consumers sum
             acc = acc + v[k]
         got = O.from_bits(O.to_bits(acc[:, :T].T.contiguous().cpu().numpy().reshape(-1), dtype), dtype).reshape(T, ntot)
@@ -62,7 +64,7 @@ def test_prefill_gemm_vs_oracle(oracle, Z, n0, n1, dtype):
             assert (err <= tolerance(O, truth, dtype)).all(), (Z, n0, n1, dtype, T, s, float(err.max()))
     # argument checks: T out of range, ragged Z, a slab buffer too small
     bad = ctypes.c_int(0)
-    assert L.teal_prefill_gemm(ctypes.byref(gin), W0.data_ptr(), W0.stride(0), n0, None, 0, 0, slabs.data_ptr(), slabs.numel() * 4, Z, 9, dtype,
+    assert L.teal_prefill_gemm(ctypes.byref(gin), W0.data_ptr(), W0.stride(0), n0, None, 0, 0, slabs.data_ptr(), slabs.numel() * 4, Z, 17, dtype,
                                ctypes.byref(bad), runtime.stream_ptr()) == -3
     assert L.teal_prefill_gemm(ctypes.byref(gin), W0.data_ptr(), W0.stride(0), n0, None, 0, 0, slabs.data_ptr(), slabs.numel() * 4, Z - 64, 6, dtype,
                                ctypes.byref(bad), runtime.stream_ptr()) == -3
@@ -71,8 +73,10 @@ def test_prefill_gemm_vs_oracle(oracle, Z, n0, n1, dtype):
 
 
 @pytest.mark.parametrize("arch,tdt,n_layer,T", [("7B", torch.float16, 2, 6), ("7B", torch.float16, 2, 2), ("7B", torch.float16, 2, 8),
-                                                 ("llama-3-8b", torch.bfloat16, 2, 6), ("tiny-gqa-test", torch.float16, 2, 5),
-                                                 ("70B", torch.float16, 1, 6)])
+                                                 ("7B", torch.float16, 2, 9), ("7B", torch.float16, 2, 12), ("7B", torch.float16, 2, 16),
+                                                 ("llama-3-8b", torch.bfloat16, 2, 6), ("llama-3-8b", torch.bfloat16, 2, 13),
+                                                 ("tiny-gqa-test", torch.float16, 2, 5), ("tiny-gqa-test", torch.float16, 2, 11),
+                                                 ("70B", torch.float16, 1, 6), ("70B", torch.float16, 1, 16)])
 def test_fused_prompt_pass_equals_module_path(arch, tdt, n_layer, T):
     from teal_amd.gpt_fast import generate as G
     from teal_amd.gpt_fast.prefill import FusedPrefill
@@ -107,10 +111,10 @@ def test_fused_prompt_pass_equals_module_path(arch, tdt, n_layer, T):
                     assert torch.allclose(l.attention.kv_cache.v_cache[0, :, :T].float(), vw, atol=tol, rtol=tol)
                     assert not l.attention.kv_cache.k_cache[0, :, T:].any(), "rows past the prompt are not touched"
             # a longer prompt takes the fallback
-            long_prompt = torch.randint(0, V, (9,), device=DEV, dtype=torch.int)
+            long_prompt = torch.randint(0, V, (17,), device=DEV, dtype=torch.int)
             out = FusedPrefill(model, graph=False)
             y = out(long_prompt)
-            assert out.used == "fallback" and y.shape == (1, 9, V)
+            assert out.used == "fallback" and y.shape == (1, 17, V)
             # ... and so does a one-token prompt: a decode step in the reference too (its ops run the sparse kernel at S == 1)
             out(long_prompt[:1])
             assert out.used == "fallback"
