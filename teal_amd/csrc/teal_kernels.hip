@@ -448,6 +448,11 @@ int run_gemv(Params& p, int dtype, void* ws, size_t ws_bytes, bool to_ws, hipStr
             c.lpr = 8;
             for (int lpr = 64; lpr > 8; lpr >>= 1)  // widest tile that still gives >= 2/3 of the CUs a tile
                 if (((n1 + lpr * 8 - 1) / (lpr * 8)) * 3 >= ncu * 2) { c.lpr = lpr; break; }
+            // a ragged second round (a 16-wave workgroup owns its CU): between one and 1.5 rounds of 64-column tiles — Llama-30B,
+            // inter 17920 = 280 tiles on 256 CUs — run as ONE round of 128-column tiles when those cover at least half the CUs
+            // (round 6, profiles/r06_ratio_vs_width.txt: 30B gate | up 56.2 us at 280 workgroups)
+            const int t8 = (n1 + 63) / 64, t16 = (n1 + 127) / 128;
+            if (c.lpr == 8 && t8 > ncu && t8 * 2 < ncu * 3 && t16 * 2 >= ncu) c.lpr = 16;
         }
     }
     const int bn = c.lpr * 8;

@@ -208,7 +208,13 @@ class DecodeEngine:
             # row-segment REQUESTS: unpaired — two threshold segments of 128-column tiles (one 256-byte segment per row) and
             # a silu * up producer in the down launch — measured -1.4 % per token on Llama-2-7B, -0.3 % on Llama-3-8B, +0.8 %
             # on Llama-2-70B (layer_bench LB_PAIRAB, profiles/r03_layer_experiments.txt)
-            pair = inter * 3 >= 128 * int(self.L.teal_init()) * 2
+            ncu = int(self.L.teal_init())
+            pair = inter * 3 >= 128 * ncu * 2
+            # ... and where the unpaired launch would be a ragged second round of workgroups (a 16-wave workgroup owns its CU):
+            # Llama-30B, 2 x 17920 / 128 = 280 tiles on 256 CUs ran 56.8 us = 0.53 of the HBM peak; paired, 140 tiles in one
+            # round (round 6, profiles/r06_ratio_vs_width.txt)
+            t_unpaired = 2 * ((inter + 127) // 128)
+            pair = pair or (ncu < t_unpaired < ncu * 3 // 2 and t_unpaired >= ncu)
         self.pair = bool(pair) and can_pair
         self.gate_act = False  # (set by _build: unpaired 16-bit / int8 gate | up stores silu(gate) | up)
         self.s_wo, self.s_down = e(MAX_SLABS, dim, dtype=torch.float32), e(MAX_SLABS, dim, dtype=torch.float32)

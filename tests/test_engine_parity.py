@@ -106,7 +106,10 @@ CASES = [("7B", torch.float16, 0.5, 2, 1, True), ("7B", torch.float16, 0.5, 2, 1
          ("7B", torch.float16, 0.5, 32, 31, None),
          # the widths between 7B and 70B that profiles/r06_ratio_vs_width.txt quotes (Llama-2-13B: 5120 = five rounds of 16 chunks,
          # the non-EXACT instantiations; CodeLlama-34B: 8192-wide, grouped-query, intermediate 22016 = 344 tiles of 128 columns)
-         ("13B", torch.float16, 0.5, 2, 1, None), ("34B", torch.float16, 0.5, 2, 1, None)]
+         ("13B", torch.float16, 0.5, 2, 1, None), ("34B", torch.float16, 0.5, 2, 1, None),
+         # Llama-30B: 6656 wide (non-EXACT), intermediate 17920 — unpaired it is 280 tiles on 256 CUs, so the engine pairs it
+         # (140 paired 128-column tiles: the non-EXACT PAIR instantiation), round 6
+         ("30B", torch.float16, 0.5, 2, 1, None)]
 
 
 def _silu_mul_variants(O, gu_bits, inter, dtype):
@@ -156,7 +159,8 @@ def test_engine_launches_vs_oracle_under_sparsity(oracle, name, tdt, sparsity, n
             eng = DecodeEngine(model, ths, pair=pair)
         assert eng.att_fused_merge and (pair is None or eng.pair == pair)
         if pair is None:
-            assert eng.pair == (name in ("70B", "34B")), (name, eng.pair)  # paired where 128-column paired tiles cover 2/3 of the CUs
+            # paired where 128-column paired tiles cover 2/3 of the CUs, or where the unpaired launch would be a ragged second round
+            assert eng.pair == (name in ("70B", "34B", "30B")), (name, eng.pair)
         k1_in, k1_out, kc, vc, k3_in, k3_out, k4_in, k4_out, k5_in, k5_out, _ = eng.stages[target]
         A, B = eng.resid
         seen = {}
