@@ -21,6 +21,16 @@ sys.path.insert(0, ROOT)
 
 def noise(kind):
     torch.cuda.set_device(0)
+    # never outlive the probe (a killed parent — a test timeout — must not leave a process hammering the GPU next to whatever runs next)
+    import threading
+    parent = os.getppid()
+
+    def _watch():
+        while True:
+            time.sleep(1.0)
+            if os.getppid() != parent:
+                os._exit(0)
+    threading.Thread(target=_watch, daemon=True).start()
     if kind == "matmul":
         a = torch.randn(4096, 4096, device="cuda", dtype=torch.float16)
         while True:
@@ -251,6 +261,11 @@ def main():
     finally:
         if child is not None:
             child.kill()
+            child.wait()
+            try:
+                os.remove(f"/tmp/noise_ready_{os.getpid()}")
+            except OSError:
+                pass
 
 
 if __name__ == "__main__":
