@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--ctx", type=int, nargs="*", default=[1024, 4096, 16384])
     ap.add_argument("--pos", type=int, default=0, help="decode position inside the cache (default: the cache's last but one row); a position well "
                     "inside a long cache shows what a launch reads past the sequence")
+    ap.add_argument("--fold", type=int, default=0, help="1: hand the launch a prepared workspace (the merge folded in by arrival tickets)")
     a = ap.parse_args()
     L = _lib.load(); runtime.init()
     global WSP

@@ -526,7 +526,8 @@ __global__ __launch_bounds__(NT) void decode_attention_split_kernel(
 //     every butterfly level: 22 instead of 32 DPP adds for REP = 8) that leaves head (lane's bits) in each lane, so
 //     that scaling, rounding, the running max and the LDS store run once per row for all heads, not once per head;
 //   * P.V: probabilities of a row are read as one or two 16-byte LDS words ([row][REP] layout), V is unpacked once per
-//     row and the REP x 8 accumulators advance as packed fp32 pairs (v_pk_fma_f32).
+//     row and the REP x 8 accumulators advance as pairs (v_pk_fma_f32 until round 6; the library is built without packed fp32
+//     since — profiles/r06_concurrent_packed_fp32.txt — at 2-3 % on this launch: profiles/r06_attention_context_sweep.txt).
 // Same lane layout, row dealing (round-robin row groups, independent of *pos), rounding points and partial format
 // {m, l, o[hd]} per (query head, split) as decode_attention_split_kernel; the loads run PF row groups ahead.
 // ------------------------------------------------------------------------------------------------

@@ -107,7 +107,8 @@ __device__ __forceinline__ void rstd_rows(const float* __restrict__ sumsq, const
 // instructions per row — addresses, clamps, selects — and a full `s_waitcnt lgkmcnt(0)` per batch: 3.8 TB/s).  Sixteen rows
 // per wave are in flight (two batches of 8 x 8 bytes per lane: 128 KB per CU, what the GEMV keeps in flight); a lane's sums never
 // leave the lane until the epilogue (no butterflies), where the 16 waves are added in fixed order through LDS, one token pair
-// per round.  Accumulation as packed fp32 pairs over the tokens (v_pk_fma_f32).  First build (row groups inside a wave, the
+// per round.  Accumulation over pairs of tokens (packed v_pk_fma_f32 until round 6; plain fused multiply-adds since the library
+// is built without packed fp32, profiles/r06_concurrent_packed_fp32.txt: the 6-token pass 4.09 -> 4.25 ms).  First build (row groups inside a wave, the
 // activations through vector loads, 8 rows in flight): 2.1-3.5 TB/s; profiles/r05_prefill_kernel_stats.txt.
 // ------------------------------------------------------------------------------------------------
 // What the staging loop builds a row's eight activations from (PROD): 0 = xt itself; 1 = RMSNorm of the residual rows ht with the
