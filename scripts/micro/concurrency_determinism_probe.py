@@ -163,6 +163,11 @@ def main():
     ap.add_argument("--noise", default="engine")
     ap.add_argument("--noise-child", default=None)
     ap.add_argument("--n_layer", type=int, default=2)
+    ap.add_argument("--weights", default="16bit", choices=["16bit", "int8", "int4"])
+    ap.add_argument("--arch", default="7B", help="model widths of the probed step (7B, llama-3-8b, 70B ...)")
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--max_seq", type=int, default=32, help="KV cache rows (grouped-query models switch to the grouped attention kernel from 2048 / 4096)")
+    ap.add_argument("--pos", type=int, default=0, help="decode position (default: right behind the 6-token prompt)")
     ap.add_argument("--sparsity", type=float, default=0.5)
     ap.add_argument("--churn", type=int, default=0, help="1: hipMalloc / fill / hipFree of a few large blocks before every step")
     ap.add_argument("--rebuild", type=int, default=0, help="N > 0: build a fresh DecodeEngine every N steps (same model)")
@@ -186,25 +191,43 @@ def main():
             time.sleep(25 if a.noise == "engine" else 8)  # let it get going
     try:
         dev = "cuda"
-        model = G.build_synthetic_model("7B", dev, torch.float16, seed=11, n_layer=a.n_layer)
+        model = G.build_synthetic_model(a.arch, dev, torch.float16 if a.precision == "fp16" else torch.bfloat16, seed=11, n_layer=a.n_layer)
+        if a.weights == "int8":
+            from teal_amd.quantize import quantize_model_int8
+            quantize_model_int8(model)
+        elif a.weights == "int4":
+            from teal_amd.quantize import quantize_model_int4
+            quantize_model_int4(model, 32)
         ths = G.apply_sparsity(model, sparsity=a.sparsity, hist_path=None, greedy_lookup=None, synthetic=True, decode_calibration=False)
         P = 6
         prompt = torch.randint(0, 32000, (P,), device=dev, dtype=torch.int, generator=torch.Generator(device=dev).manual_seed(2))
         model.max_seq_length = -1
-        model.setup_caches(1, 32)
+        model.setup_caches(1, a.max_seq)
         with torch.no_grad():
             model(prompt.view(1, -1), torch.arange(P, device=dev))
+            if a.pos > P:  # a long context: fill the cache rows up to the decode position with random rows
+                for layer in model.layers:
+                    kc = layer.attention.kv_cache
+                    kc.k_cache[:, :, P:a.pos].normal_(0, 0.5)
+                    kc.v_cache[:, :, P:a.pos].normal_(0, 0.5)
+                P = a.pos
             eng = DecodeEngine(model, ths)
             tok = torch.tensor([[17]], device=dev, dtype=torch.int)
             pos = torch.tensor([P], device=dev, dtype=torch.int)
 
             def bufs(stage, i):
                 L = model.layers[i] if i >= 0 else None
+                roped = bool(getattr(eng, "rope_epilogue", False)) and eng.n_qkv.value == 0  # the projection's epilogue rotates and appends
                 if stage == "qkv":
-                    return {"q": eng.qkv[: eng.qdim], "k_row": L.attention.kv_cache.k_cache[0, :, P], "v_row": L.attention.kv_cache.v_cache[0, :, P],
-                            "resid_B": eng.resid[1]}
+                    if roped:
+                        return {"q": eng.qkv[: eng.qdim], "k_row": L.attention.kv_cache.k_cache[0, :, P], "v_row": L.attention.kv_cache.v_cache[0, :, P],
+                                "resid_B": eng.resid[1]}
+                    st = (max(1, eng.n_qkv.value) + 3) & ~3
+                    return {"s_qkv": eng.s_qkv.view(-1)[: eng.nqkv * st], "resid_B": eng.resid[1]}
                 if stage == "attn":
-                    return {"att_ws": eng.att_ws}
+                    if roped:
+                        return {"att_ws": eng.att_ws}
+                    return {"att_ws": eng.att_ws, "k_row": L.attention.kv_cache.k_cache[0, :, P], "v_row": L.attention.kv_cache.v_cache[0, :, P]}
                 if stage == "wo":
                     return {"s_wo": eng.s_wo.view(-1)[: eng.dim * 4]}
                 if stage == "gate_up":

@@ -279,8 +279,11 @@ def test_int4_graph_replay_soak(dtype):
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("noise", ["op_linear_qkv", "op_linear_d"])
-def test_step_is_reproducible_next_to_another_process(noise):
+@pytest.mark.parametrize("noise,extra", [("op_linear_qkv", []), ("op_linear_d", []),
+                                         # the grouped-query attention kernel (v_dot2c_f32_bf16) at 3000 cached positions, bf16 everywhere
+                                         ("op_linear_qkv", ["--arch", "llama-3-8b", "--precision", "bf16", "--max_seq", "4096", "--pos", "3000"]),
+                                         ("op_linear_qkv", ["--weights", "int8"])])
+def test_step_is_reproducible_next_to_another_process(noise, extra):
     """The decode step gives the same bits while ANOTHER PROCESS keeps the GPU busy with a skinny rocBLAS / hipBLASLt GEMM (a
     24-token F.linear at Llama-2-7B widths: Tensile MT64x32x256 / MT32x16x256 stream-K kernels).  Round 6: with v_pk_fma_f32 in
     the GEMV inner loops every step next to such a process differed (the low half of packed results dropped for whole row
@@ -291,7 +294,7 @@ def test_step_is_reproducible_next_to_another_process(noise):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "scripts", "micro", "concurrency_determinism_probe.py"), "--noise", noise,
-                          "--repeats", "1500"], capture_output=True, text=True, timeout=600, cwd=root)
+                          "--repeats", "1500", *extra], capture_output=True, text=True, timeout=600, cwd=root)
     line = [ln for ln in out.stdout.splitlines() if "repeats with noise=" in ln]
     assert out.returncode == 0 and line, (out.stdout[-1500:], out.stderr[-1500:])
     assert " 0 repeats differed" in line[-1], line[-1][:600]
