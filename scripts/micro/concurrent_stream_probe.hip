@@ -4,7 +4,10 @@
 // decode step's outputs differed in whole-accumulator patterns (16 or 8 columns at stride 8 of one tile) only while a second
 // process ran its dense prefill next to it (scripts/micro/concurrency_determinism_probe.py --noise prefill).
 //   hipcc --offload-arch=gfx950 -O3 scripts/micro/concurrent_stream_probe.hip -o scripts/micro/concurrent_stream_probe
-//   ./concurrent_stream_probe <mode> [launches] [tag]     mode 0: non-temporal loads, 1: plain loads, 2: no loads (ALU only), 3: as 0 with 64 VGPRs allocated, 4: with 104
+//   ./concurrent_stream_probe <mode> [launches] [tag]     mode 0: non-temporal loads, 1: plain loads, 2: no loads (ALU only), 3: as 0 with 64 VGPRs allocated, 4: with 104,
+//                                                         5: as 0 with the accumulators advanced by v_pk_fma_f32 (packed fp32, what the product's inner loops used until round 6),
+//                                                         6: no victim — run the MFMA aggressor (small workgroups of v_mfma_f32_16x16x16_f16 loops) until killed,
+//                                                         7: mode 5 with that aggressor on a second stream of the SAME process
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <cstdio>
@@ -15,6 +18,9 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int Z = 4096, N = 11008, BN = 128, LPR = 16, RPW = 4;  // 86 tiles x 3 slices of rows = 258 workgroups of 16 waves
 
@@ -40,7 +46,7 @@ __global__ __launch_bounds__(1024) void stream_kernel(const uint16_t* __restrict
         for (int u = 0; u < 4; ++u) {
             const int rr = min(r + u * 16 * RPW, rend - 1);
             xv[u] = (r + u * 16 * RPW < rend) ? x[rr] : 0.0f;
-            if (MODE == 0) w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)rr * N * 2));
+            if (MODE == 0 || MODE == 5) w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)rr * N * 2));
             else if (MODE == 1) w[u] = *reinterpret_cast<const u32x4*>(wp + (size_t)rr * N * 2);
             else w[u] = u32x4{0x3c003c00u + (uint32_t)rr, 0x38003800u, 0x34003400u + (uint32_t)cl, 0x30003000u};
         }
@@ -49,8 +55,15 @@ __global__ __launch_bounds__(1024) void stream_kernel(const uint16_t* __restrict
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const f16x2 h = __builtin_bit_cast(f16x2, w[u][j]);
-                acc[2 * j] = fmaf((float)h.x, xv[u], acc[2 * j]);
-                acc[2 * j + 1] = fmaf((float)h.y, xv[u], acc[2 * j + 1]);
+                if constexpr (MODE == 5) {  // two fp32 results per instruction: v_pk_fma_f32 (check the ISA: llvm-objdump -d)
+                    f32x2 a2 = {acc[2 * j], acc[2 * j + 1]};
+                    a2 = __builtin_elementwise_fma((f32x2){(float)h.x, (float)h.y}, (f32x2){xv[u], xv[u]}, a2);
+                    acc[2 * j] = a2.x;
+                    acc[2 * j + 1] = a2.y;
+                } else {
+                    acc[2 * j] = fmaf((float)h.x, xv[u], acc[2 * j]);
+                    acc[2 * j + 1] = fmaf((float)h.y, xv[u], acc[2 * j + 1]);
+                }
             }
     }
 #pragma unroll
@@ -72,6 +85,18 @@ __global__ __launch_bounds__(1024) void stream_kernel(const uint16_t* __restrict
     }
 }
 
+// The aggressor: one-wave workgroups (few registers, no LDS: they fit next to anything) spinning on the matrix core.
+__global__ __launch_bounds__(64) void mfma_kernel(float* __restrict__ sink, const int iters) {
+    f16x4 a = {(_Float16)(threadIdx.x * 0.001f), (_Float16)0.5f, (_Float16)0.25f, (_Float16)1.0f};
+    f16x4 b = {(_Float16)1.0f, (_Float16)(blockIdx.x * 0.001f), (_Float16)0.125f, (_Float16)2.0f};
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < iters; ++i) {
+        c = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x16f16(b, a, c, 0, 0, 0);
+    }
+    if (c[0] == 12345.678f) sink[threadIdx.x] = c[1] + c[2] + c[3];
+}
+
 int main(int argc, char** argv) {
     const int mode = argc > 1 ? atoi(argv[1]) : 0, launches = argc > 2 ? atoi(argv[2]) : 20000;
     const char* tag = argc > 3 ? argv[3] : "p";
@@ -88,12 +113,24 @@ int main(int argc, char** argv) {
     const size_t n = (size_t)N * 4;
     std::vector<float> ref(n), cur(n), again(n);
     hipStream_t st; CK(hipStreamCreate(&st));
+    hipStream_t st2; CK(hipStreamCreate(&st2));
+    float* sink; CK(hipMalloc(&sink, 4096));
+    const int agg_blocks = argc > 4 ? atoi(argv[4]) : 2048, agg_iters = argc > 5 ? atoi(argv[5]) : 4000;
+    if (mode == 6) {  // aggressor only, until killed
+        printf("[%s] MFMA aggressor: %d one-wave workgroups x %d x 2 v_mfma_f32_16x16x16_f16 per launch, forever\n", tag, agg_blocks, agg_iters); fflush(stdout);
+        for (;;) {
+            for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(mfma_kernel, dim3(agg_blocks), dim3(64), 0, st2, sink, agg_iters);
+            CK(hipStreamSynchronize(st2));
+        }
+    }
     auto launch = [&]() {
+        if (mode == 7) hipLaunchKernelGGL(mfma_kernel, dim3(agg_blocks), dim3(64), 0, st2, sink, agg_iters);
         const dim3 grid(N / BN, slices), block(1024);
         if (mode == 0) hipLaunchKernelGGL(stream_kernel<0>, grid, block, 0, st, W, x, out, rps);
         else if (mode == 1) hipLaunchKernelGGL(stream_kernel<1>, grid, block, 0, st, W, x, out, rps);
         else if (mode == 2) hipLaunchKernelGGL(stream_kernel<2>, grid, block, 0, st, W, x, out, rps);
         else if (mode == 3) hipLaunchKernelGGL((stream_kernel<0, 64>), grid, block, 0, st, W, x, out, rps);
+        else if (mode == 5 || mode == 7) hipLaunchKernelGGL(stream_kernel<5>, grid, block, 0, st, W, x, out, rps);
         else hipLaunchKernelGGL((stream_kernel<0, 104>), grid, block, 0, st, W, x, out, rps);
     };
     CK(hipMemsetAsync(out, 0, n * 4, st));
