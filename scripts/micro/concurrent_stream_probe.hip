@@ -7,7 +7,8 @@
 //   ./concurrent_stream_probe <mode> [launches] [tag]     mode 0: non-temporal loads, 1: plain loads, 2: no loads (ALU only), 3: as 0 with 64 VGPRs allocated, 4: with 104,
 //                                                         5: as 0 with the accumulators advanced by v_pk_fma_f32 (packed fp32, what the product's inner loops used until round 6),
 //                                                         6: no victim — run the MFMA aggressor (small workgroups of v_mfma_f32_16x16x16_f16 loops) until killed,
-//                                                         7: mode 5 with that aggressor on a second stream of the SAME process
+//                                                         7: mode 5 with that aggressor on a second stream of the SAME process,
+//                                                         8 / 9: mode 5 with 104 / 124 VGPRs allocated (the product kernels' occupancy: one 16-wave workgroup owns the CU's registers)
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <cstdio>
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(1024) void stream_kernel(const uint16_t* __restrict
     // NV: the register allocation of the wave (the kernel itself needs 28): a clobbered high register raises it to 64 / 104
     if constexpr (NV == 64) asm volatile("v_mov_b32 v61, 0" ::: "v61");
     if constexpr (NV == 104) asm volatile("v_mov_b32 v100, 0" ::: "v100");
+    if constexpr (NV == 124) asm volatile("v_mov_b32 v123, 0" ::: "v123");
     const int r0 = slice * rows_per_slice, rend = min(r0 + rows_per_slice, Z);
     for (int r = r0 + wave * RPW + g; r < rend; r += 16 * RPW * 4) {
         u32x4 w[4];
@@ -131,6 +133,8 @@ int main(int argc, char** argv) {
         else if (mode == 2) hipLaunchKernelGGL(stream_kernel<2>, grid, block, 0, st, W, x, out, rps);
         else if (mode == 3) hipLaunchKernelGGL((stream_kernel<0, 64>), grid, block, 0, st, W, x, out, rps);
         else if (mode == 5 || mode == 7) hipLaunchKernelGGL(stream_kernel<5>, grid, block, 0, st, W, x, out, rps);
+        else if (mode == 8) hipLaunchKernelGGL((stream_kernel<5, 104>), grid, block, 0, st, W, x, out, rps);   // packed, 104 VGPRs allocated
+        else if (mode == 9) hipLaunchKernelGGL((stream_kernel<5, 124>), grid, block, 0, st, W, x, out, rps);   // packed, 124 VGPRs allocated: one workgroup fills a CU's registers
         else hipLaunchKernelGGL((stream_kernel<0, 104>), grid, block, 0, st, W, x, out, rps);
     };
     CK(hipMemsetAsync(out, 0, n * 4, st));
