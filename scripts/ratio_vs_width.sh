@@ -14,6 +14,6 @@ run() {  # tag, args...
   echo "$tag rc=$?"
   grep '^{"metric"' $OUT/$tag.log | tail -1 > $OUT/$tag.json
 }
-for s in ${SPARSITIES:-0.4 0.5 0.6 0.7}; do run 7B_s$s --model 7B --sparsity $s; done
-for m in ${MODELS:-13B 30B 34B 70B}; do run ${m}_s0.5 --model $m --sparsity 0.5; done
+for s in ${SPARSITIES-0.4 0.5 0.6 0.7}; do run 7B_s$s --model 7B --sparsity $s; done
+for m in ${MODELS-13B 30B 34B 70B}; do run ${m}_s0.5 --model $m --sparsity 0.5; done
 python scripts/ratio_table.py $OUT | tee $OUT/table.txt
