@@ -738,9 +738,17 @@ def main():
                                             "4096 for the latter); `value` is the reference's default 6-token prompt")
         if not a.no_cpu_baseline and a.weights == "16bit":
             out["cpu_baseline"] = cpu_baseline(model, a)
-    elif rank == 0:
-        out["roofline"] = None
-        out["cpu_baseline"] = None
+    elif world > 1:
+        # N > 1: the timing's collectives are done — the ranks leave the group TOGETHER (barrier first), then rank 0 alone measures
+        # the dominant launch on its own GPU (a per-GPU property: replicas do not change it).  No dense leg, no CPU baseline (N = 1
+        # only, by the bench contract).
+        import torch.distributed as dist
+        barrier(world)
+        dist.destroy_process_group()
+        if rank == 0:
+            out["roofline"] = roofline_engine_gateup(info["engine"], a) if mode == "engine" else roofline_dominant_kernel(model, a)
+            out["roofline"]["note_n_gpus"] = f"measured on rank 0's GPU after the timed region (each of the {world} replicas runs the same launch)"
+            out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(_finite(out), allow_nan=False))  # strict JSON: a non-finite number would print as a bare NaN token
     if _dist_on():
