@@ -31,8 +31,11 @@ PRELOAD = {"teal_gemv_fast_f16.hip": 12, "teal_gemv_fast_bf16.hip": 12, "teal_ge
 # the GPU, the LOW half of v_pk_fma_f32 results is dropped now and then for a whole row group — every decode step next to such a
 # process differed (whole accumulators, even columns only, delta = -x_r * W[r, cols]); the same kernels with v_fma_mix_f32 /
 # v_fmac_f32 in its place are bit-reproducible under the same load, and alone on the GPU both forms give the same bits
-# (profiles/r06_concurrent_packed_fp32.txt).  With the feature off the compiler folds the fp16 -> fp32 conversion into
-# v_fma_mix_f32 (8 instructions per 16 bytes of weights instead of 8 conversions + 4 packed FMAs).
+# (profiles/r06_concurrent_packed_fp32.txt).  That is an observation on THESE kernels: a minimal pure-HIP kernel with the same
+# v_pk_fma_f32 form is not damaged under the same load (profiles/r06_pk_fma_reproducer.txt) and the cause is not established; the
+# separation is empirical — every packed build of the product kernels fails every step, every non-packed build (all widths,
+# dtypes, weight formats) passes.  With the feature off the compiler folds the fp16 -> fp32 conversion into v_fma_mix_f32
+# (8 instructions per 16 bytes of weights instead of 8 conversions + 4 packed FMAs).
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 # Floating-point contraction follows the SOURCE, not the optimiser: `a += x * y` inside one expression is one fma in every
 # instantiation (hipcc's default, -ffp-contract=fast, fuses wherever the DAG combiner sees fit — it saw fit differently in the

@@ -184,21 +184,15 @@ __device__ __forceinline__ uint16_t float_to_bits(float f) {
         // (profiles/r04_layer_phase_timing_8b_bf16.txt: "x ready" 1.75 us against 1.05 us in fp16 before this)
         return __builtin_bit_cast(uint16_t, (__bf16)f);
     }
-    // v_cvt_f16_f32 (round to nearest even) of a value whose producer the compiler cannot see (empty asm: no instruction).  Written as `(_Float16)f` the
-    // conversion of an fmaf() result is folded into v_fma_mixlo_f16 where the selector sees both — and that instruction rounds
-    // the EXACT a * b + c once to fp16, where v_fma_f32 + v_cvt_f16_f32 (what the oracle and the reference's fp32-then-.to(fp16)
-    // arithmetic do) round twice: 1741 of 2^26 random cases differ in the last place on MI355X
-    // (scripts/micro/fma_mixlo_rounding_probe.hip, profiles/r06_fma_mixlo_rounding.txt).  Round 6: without packed fp32 the
-    // fold happened in decode_attention_split_kernel's RoPE and not in the qkv projection's epilogue, and the lean and the
-    // general decode step — specified to be bit-identical — differed in one head every few layers (tests/test_soak.py).
-#ifdef TEAL_PROBE_CVT_ASM
-    uint32_t h;
-    asm("v_cvt_f16_f32_e32 %0, %1" : "=v"(h) : "v"(f));
-    return (uint16_t)h;
-#else
-    asm("" : "+v"(f));  // the value's producer is opaque from here on: nothing to fold the conversion into
+    // v_cvt_f16_f32 (round to nearest even) of a value whose producer the compiler cannot see (empty asm: no instruction).
+    // Written as `(_Float16)f` the conversion of an fmaf() result is folded into v_fma_mixlo_f16 where the selector sees both —
+    // and that instruction rounds the EXACT a * b + c once to fp16, where v_fma_f32 + v_cvt_f16_f32 (what the oracle and the
+    // reference's fp32-then-.to(fp16) arithmetic do) round twice: 1741 of 2^26 random cases differ in the last place on MI355X
+    // (scripts/micro/fma_mixlo_rounding_probe.hip, profiles/r06_fma_mixlo_rounding.txt).  Round 6: without packed fp32 the fold
+    // happened in decode_attention_split_kernel's RoPE and not in the qkv projection's epilogue, and the lean and the general
+    // decode step — specified to be bit-identical — differed in one head every few layers (tests/test_soak.py).
+    asm("" : "+v"(f));
     return __builtin_bit_cast(uint16_t, (_Float16)f);
-#endif
 }
 
 // RoPE of one (even, odd) pair (gpt-fast/model.py:apply_rotary_emb: x0 * cos - x1 * sin, x1 * cos + x0 * sin), written with

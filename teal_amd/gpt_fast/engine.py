@@ -214,7 +214,7 @@ class DecodeEngine:
             # Llama-30B, 2 x 17920 / 128 = 280 tiles on 256 CUs ran 56.8 us = 0.53 of the HBM peak; paired, 140 tiles in one
             # round (round 6, profiles/r06_ratio_vs_width.txt)
             t_unpaired = 2 * ((inter + 127) // 128)
-            pair = pair or (ncu < t_unpaired < ncu * 3 // 2 and t_unpaired >= ncu)
+            pair = pair or ncu < t_unpaired < ncu * 3 // 2
         self.pair = bool(pair) and can_pair
         self.gate_act = False  # (set by _build: unpaired 16-bit / int8 gate | up stores silu(gate) | up)
         self.s_wo, self.s_down = e(MAX_SLABS, dim, dtype=torch.float32), e(MAX_SLABS, dim, dtype=torch.float32)
