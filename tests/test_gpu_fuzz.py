@@ -32,7 +32,11 @@ def _cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _cases(48, 20260927), ids=lambda c: f"{c[0]}-Z{c[1]}-N{c[2]}-d{c[3]}-kv{c[5]}-wl{c[6]}-{'i8' if c[7] else 'w16'}")
+# (TEAL_FUZZ_CASES / TEAL_FUZZ_SEED: a longer or different sweep for a one-off run; the defaults are what the suite runs)
+import os  # noqa: E402
+
+
+@pytest.mark.parametrize("case", _cases(int(os.environ.get("TEAL_FUZZ_CASES", "48")), int(os.environ.get("TEAL_FUZZ_SEED", "20260927"))), ids=lambda c: f"{c[0]}-Z{c[1]}-N{c[2]}-d{c[3]}-kv{c[5]}-wl{c[6]}-{'i8' if c[7] else 'w16'}")
 def test_random_gemv_cases_vs_truth(oracle, case):
     import contextlib
     i, Z, N, dtype, taus, kv, wl, int8, padded = case
